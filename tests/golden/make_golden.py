@@ -1,0 +1,338 @@
+"""Generate golden vectors by IMPORTING THE REFERENCE (container-only; /root/reference never travels).
+
+Run from the repo root:  python tests/golden/make_golden.py
+Writes tests/golden/*.npz (data only: inputs + the reference's outputs).  The reference tree is imported with
+third-party stubs (torchvision / yacs / spacy / fire / fastprogress / tensorboard are absent here)
+and with the documented overrides: CPU anchors (anchors.py:66 defaults to 'cuda'), fp32 anchor regime
+(pre-seeded ``.anchs``), recorded LSTM initial state (mdl.py:279-294 draws a random one every call).
+"""
+import sys
+sys.dont_write_bytecode = True   # never write __pycache__ into /root/reference
+import functools
+import hashlib
+import os
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+from oracle import zsg_oracle as O   # only for the seed-only weight / batch generators
+
+
+def import_reference():
+    os.chdir(REF)
+    sys.path.insert(0, os.path.join(REF, "code"))
+
+    class CN(dict):
+        def __init__(self, d=None, new_allowed=False):
+            super().__init__()
+            for k, v in (d or {}).items():
+                self[k] = CN(v) if isinstance(v, dict) and not isinstance(v, CN) else v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def freeze(self):
+            pass
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    yc = mod("yacs.config", CfgNode=CN)
+    mod("yacs", config=yc)
+    mod("spacy", load=lambda name: None)
+    mod("fire", Fire=lambda f: None)
+    fp = mod("fastprogress.fastprogress", master_bar=None, progress_bar=None)
+    mod("fastprogress", fastprogress=fp)
+    mod("torch.utils.tensorboard", SummaryWriter=object)
+    import fpn_resnet
+
+    def resnet50(pretrained=False):
+        return fpn_resnet.ResNet(1, fpn_resnet.Bottleneck, [3, 4, 6, 3])
+    tvm = mod("torchvision.models", resnet50=resnet50)
+    tvt_f = mod("torchvision.transforms.functional")
+    tvt = mod("torchvision.transforms", functional=tvt_f)
+    mod("torchvision", models=tvm, transforms=tvt)
+    import anchors
+    import evaluator
+    import loss
+    import mdl
+    from extended_config import cfg
+    os.chdir(REPO)
+    cfg.device = "cpu"
+    return dict(anchors=anchors, evaluator=evaluator, loss=loss, mdl=mdl, fpn_resnet=fpn_resnet, cfg=cfg)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KB")
+
+
+def adversarial_boxes(rng, n, anchors32):
+    """random + degenerate / full-image / anchor-identical / tie-heavy boxes (y1x1y2x2 in [-1,1])."""
+    c = rng.uniform(-0.6, 0.6, (n, 2))
+    s = rng.uniform(0.1, 0.9, (n, 2))
+    b = np.clip(np.concatenate([c - s / 2, c + s / 2], 1), -1, 1).astype(np.float32)
+    extra = [
+        [-1, -1, 1, 1], [0, 0, 0, 0], [0.25, 0.25, 0.25, 0.75], [-1, -1, -0.99, -0.99],
+        [-0.5, -0.5, 0.5, 0.5], [-0.001, -0.001, 0.001, 0.001], [0.0, -1.0, 1.0, 1.0],
+    ]
+    ids = rng.integers(0, anchors32.shape[0], 9)
+    extra += [np.clip(anchors32[i], -1, 1).tolist() for i in ids]          # anchor-identical (clipped)
+    extra += [anchors32[i].tolist() for i in ids[:3]]                      # anchor-identical (unclipped)
+    return np.concatenate([b, np.array(extra, dtype=np.float32)], 0)
+
+
+def main():
+    R = import_reference()
+    A, L, E, M, cfg = R["anchors"], R["loss"], R["evaluator"], R["mdl"], R["cfg"]
+    ratios = eval(cfg["ratios"], {})
+    scales = cfg["scale_factor"] * np.array(eval(cfg["scales"], {}))
+    cpu = torch.device("cpu")
+    rng = np.random.default_rng(20260928)
+
+    # ---- G1 create_grid ---------------------------------------------------------------------
+    g1 = {}
+    for hw in [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1), (1, 7), (75, 75), (4, 9)]:
+        g1[f"g_{hw[0]}_{hw[1]}"] = A.create_grid(hw).numpy()
+    save("g1_grid", **g1)
+
+    # ---- G2 create_anchors ------------------------------------------------------------------
+    fs300 = [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1)]
+    fs600 = [(38, 38), (19, 19), (10, 10), (5, 5)]
+    a300 = A.create_anchors(fs300, ratios, scales, device=cpu)
+    a600 = A.create_anchors(fs600, ratios, scales, device=cpu)
+    assert a300.dtype == torch.float64 and a300.shape == (17460, 4) and a600.shape == (17370, 4)
+    samp = rng.integers(0, 17370, 64)
+    save("g2_anchors", a300_f32=a300.float().numpy(), a300_sha256=np.frombuffer(
+        hashlib.sha256(a300.numpy().tobytes()).digest(), dtype=np.uint8),
+        a600_sha256=np.frombuffer(hashlib.sha256(a600.numpy().tobytes()).digest(), dtype=np.uint8),
+        sample_ids=samp, a300_f64_rows=a300.numpy()[samp], a600_f64_rows=a600.numpy()[samp],
+        ratios=np.array(ratios), scales=scales)
+    anc32 = a300.float()
+
+    # ---- G3 IoU / argmax / mask -------------------------------------------------------------
+    boxes = adversarial_boxes(rng, 237, anc32.numpy())
+    iou = A.IoU_values(torch.from_numpy(boxes), anc32)
+    mx, am = iou.max(1)
+    pos = (iou > 0.6)
+    rows, cols = torch.nonzero(pos, as_tuple=True)
+    matches = A.simple_match_anchors(anc32, torch.from_numpy(boxes), match_thr=0.6)
+    assert bool(((matches >= 0) == pos).all())
+    srow = rng.integers(0, boxes.shape[0], 8)
+    save("g3_iou", boxes=boxes, argmax=am.numpy().astype(np.int32), maxval=mx.numpy(),
+         pos_rows=rows.numpy().astype(np.int32), pos_cols=cols.numpy().astype(np.int32),
+         sample_rows=srow, sample_iou=iou.numpy()[srow][:, ::7])
+
+    # ---- G4 encode / decode -----------------------------------------------------------------
+    small_fs = [(5, 5), (3, 3), (1, 1)]
+    anc_s = A.create_anchors(small_fs, ratios, scales, device=cpu).float()      # A = 315
+    bx = torch.from_numpy(boxes[:12].copy())
+    enc = A.bbox_to_reg_params(anc_s, bx)
+    regs = torch.from_numpy(rng.normal(0, 0.7, (12, anc_s.shape[0], 4)).astype(np.float32))
+    dec = A.reg_params_to_bbox(anc_s, regs)
+    save("g4_codec", anchors=anc_s.numpy(), boxes=bx.numpy(), enc=enc.numpy(), regs=regs.numpy(), dec=dec.numpy())
+
+    # ---- G5/G6 loss + evaluator -------------------------------------------------------------
+    def run_loss_eval(tag, anc, B, flags=None, nan_case=False, full_out=True):
+        c = type(cfg)(dict(cfg))
+        for k, v in (flags or {}).items():
+            c[k] = v
+        lf = L.get_default_loss(ratios, scales, c)
+        ev = E.get_default_eval(ratios, scales, c)
+        lf.anchs = anc
+        ev.anchs = anc
+        Aa = anc.shape[0]
+        bt = O.synthetic_batch(B, 32, 32, seed=77 + B)
+        annot = bt["annot"]
+        if nan_case:
+            annot = annot.clone()
+            annot[0] = torch.tensor([0.3, 0.3, 0.3, 0.3])     # zero-area box -> log(0) -> NaN branch of loss.py:128
+        att = torch.from_numpy(rng.normal(-3.0, 1.5, (B, Aa, 1)).astype(np.float32)).requires_grad_()
+        bbx = torch.from_numpy(rng.normal(0, 0.6, (B, Aa, 4)).astype(np.float32)).requires_grad_()
+        out = dict(att_out=att, bbx_out=bbx, feat_sizes=torch.zeros(1, 2).long(), num_f_out=torch.tensor([1]))
+        inp = dict(annot=annot, idxs=bt["idxs"], img_size=bt["img_size"])
+        ls = lf(out, inp)
+        ls["loss"].backward()
+        with torch.no_grad():
+            em = ev(out, inp)
+            att_s = torch.sigmoid(att).squeeze(-1)
+            top2 = torch.topk(att_s, 2, dim=1)[0]
+        d = dict(att=att.detach().numpy(), bbx=bbx.detach().numpy(), annot=annot.numpy(), img_size=bt["img_size"].numpy(),
+                 loss=np.float64(ls["loss"].item()), cls_ls=np.float64(ls["cls_ls"].item()), box_ls=np.float64(ls["box_ls"].item()),
+                 Acc=em["Acc"].numpy(), MaxPos=em["MaxPos"].numpy(), pred_boxes=em["pred_boxes"].numpy(),
+                 pred_scores=em["pred_scores"].numpy(), score_gap=(top2[:, 0] - top2[:, 1]).numpy(),
+                 pred_ids=att_s.max(1)[1].numpy())
+        if att.grad is not None and full_out:
+            d["g_att"] = att.grad.numpy()
+            d["g_bbx"] = bbx.grad.numpy()
+        elif att.grad is not None:
+            d["g_att_s"] = att.grad.numpy()[:, ::11]
+            d["g_bbx_s"] = bbx.grad.numpy()[:, ::11]
+            d["g_att_abs_sum"] = np.float64(att.grad.abs().double().sum().item())
+            d["g_bbx_abs_sum"] = np.float64(bbx.grad.abs().double().sum().item())
+            d.pop("att"), d.pop("bbx")
+            d["att_seed_note"] = np.array([0])
+        return d
+
+    g5 = {}
+    for B in (1, 2, 16):
+        for k, v in run_loss_eval(f"b{B}", anc_s, B).items():
+            g5[f"b{B}_{k}"] = v
+    for k, v in run_loss_eval("nomulti", anc_s, 4, dict(use_multi=False)).items():
+        g5[f"nomulti_{k}"] = v
+    for k, v in run_loss_eval("nofocal", anc_s, 4, dict(use_focal=False)).items():
+        g5[f"nofocal_{k}"] = v
+    for k, v in run_loss_eval("softmax", anc_s, 4, dict(use_multi=False, use_softmax=True)).items():
+        g5[f"softmax_{k}"] = v
+    for k, v in run_loss_eval("nan", anc_s, 2, nan_case=True).items():
+        g5[f"nan_{k}"] = v
+    g5["anchors"] = anc_s.numpy()
+    save("g5_loss_eval_small", **g5)
+
+    # one full-A case (inputs regenerated from a seed by the test to keep the file small)
+    torch.manual_seed(5)
+    B = 2
+    bt = O.synthetic_batch(B, 32, 32, seed=99)
+    gfull = torch.Generator().manual_seed(4242)
+    att = (torch.randn(B, 17460, 1, generator=gfull) * 1.5 - 3.0).requires_grad_()
+    bbx = (torch.randn(B, 17460, 4, generator=gfull) * 0.6).requires_grad_()
+    lf = L.get_default_loss(ratios, scales, cfg)
+    ev = E.get_default_eval(ratios, scales, cfg)
+    lf.anchs = anc32
+    ev.anchs = anc32
+    out = dict(att_out=att, bbx_out=bbx, feat_sizes=torch.zeros(1, 2).long(), num_f_out=torch.tensor([1]))
+    inp = dict(annot=bt["annot"], idxs=bt["idxs"], img_size=bt["img_size"])
+    ls = lf(out, inp)
+    ls["loss"].backward()
+    em = ev(out, inp)
+    save("g5_loss_eval_full", annot=bt["annot"].numpy(), img_size=bt["img_size"].numpy(),
+         loss=np.float64(ls["loss"].item()), cls_ls=np.float64(ls["cls_ls"].item()), box_ls=np.float64(ls["box_ls"].item()),
+         g_att_s=att.grad.numpy()[:, ::13], g_bbx_s=bbx.grad.numpy()[:, ::13],
+         g_att_abs_sum=np.float64(att.grad.abs().double().sum().item()),
+         g_bbx_abs_sum=np.float64(bbx.grad.abs().double().sum().item()),
+         Acc=em["Acc"].detach().numpy(), MaxPos=em["MaxPos"].detach().numpy(), pred_boxes=em["pred_boxes"].detach().numpy(),
+         pred_scores=em["pred_scores"].detach().numpy(), gen_seed=np.array([4242]))
+
+    # ---- G7 apply_lstm ----------------------------------------------------------------------
+    sd = O.seeded_state_dict("resnet50", seed=3)
+    net = M.get_default_net(num_anchors=9, cfg=cfg)
+    missing = net.load_state_dict(sd, strict=False)
+    assert all(k.startswith("backbone.encoder.fpn.") for k in missing.missing_keys), missing.missing_keys
+    assert not missing.unexpected_keys
+    Bq = 5
+    gq = torch.Generator().manual_seed(11)
+    qvec = torch.randn(Bq, 20, 300, generator=gq) * 0.35
+    qlens = torch.tensor([7.0, 20.0, 7.0, 1.0, 12.0])
+    h0 = torch.randn(2, Bq, 128, generator=gq)
+    c0 = torch.randn(2, Bq, 128, generator=gq)
+    net.lstm_init_hidden = lambda bs: (h0, c0)
+    net.train()
+    we = net.apply_lstm(qvec[:, :20].contiguous(), qlens, 20)
+    gw = torch.randn(Bq, 256, generator=gq)
+    net.zero_grad()
+    (we * gw).sum().backward()
+    lg = {k.replace("lstm.", "").replace(".", "_"): (p.grad.numpy() if p.grad.dim() == 1 else p.grad.numpy()[::4, ::3])
+          for k, p in net.named_parameters() if k.startswith("lstm.")}
+    perm = qlens.sort(0, descending=True)[1]
+    save("g7_lstm", qvec=qvec.numpy(), qlens=qlens.numpy(), h0=h0.numpy(), c0=c0.numpy(), we=we.detach().numpy(),
+         gw=gw.numpy(), perm=perm.numpy(), seed=np.array([3]), **{"grad_" + k: v for k, v in lg.items()})
+
+    # ---- G8 FPN + Bottleneck ----------------------------------------------------------------
+    FR = R["fpn_resnet"]
+    fpn = net.backbone.fpn
+    gf = torch.Generator().manual_seed(21)
+    c3 = torch.randn(1, 512, 38, 38, generator=gf)
+    c4 = torch.randn(1, 1024, 19, 19, generator=gf)
+    c5 = torch.randn(1, 2048, 10, 10, generator=gf)
+    with torch.no_grad():
+        outs = fpn([c3, c4, c5])
+    save("g8_fpn", seed=np.array([3]), in_seed=np.array([21]),
+         **{f"p{i}": (o.numpy() if o.numel() < 40000 else o.numpy()[:, ::8, ::3, ::3]) for i, o in enumerate(outs)})
+    blk = net.backbone.encoder.layer2[0]     # stride-2 bottleneck with downsample
+    blk.train()
+    xb = torch.randn(2, 256, 12, 12, generator=gf).requires_grad_()
+    for m_ in blk.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            m_.running_mean.zero_()
+            m_.running_var.fill_(1)
+    yb = blk(xb)
+    gy = torch.randn(yb.shape, generator=gf)
+    blk.zero_grad()
+    (yb * gy).sum().backward()
+    save("g8_bottleneck", seed=np.array([3]), x=xb.detach().numpy(), gy=gy.numpy(), y=yb.detach().numpy(), gx=xb.grad.numpy(),
+         g_conv2=blk.conv2.weight.grad.numpy()[::2, ::2], g_bn3_w=blk.bn3.weight.grad.numpy(), g_bn3_b=blk.bn3.bias.grad.numpy(),
+         g_ds=blk.downsample[0].weight.grad.numpy()[::4, ::4], rm_bn2=blk.bn2.running_mean.numpy(), rv_bn2=blk.bn2.running_var.numpy())
+
+    # ---- G9 head ordering on a 5x5 level ----------------------------------------------------
+    xh = torch.randn(2, 514, 5, 5, generator=gf)
+    with torch.no_grad():
+        yh = net.permute_correctly(net.att_reg_box(xh), 5)
+    save("g9_head", seed=np.array([3]), x=xh.numpy(), y=yh.numpy())
+
+    # ---- G10 end-to-end forward/backward, B=2 ------------------------------------------------
+    for tag, HW in (("e2e_128", 128), ("e2e_300", 300)):
+        sd = O.seeded_state_dict("resnet50", seed=7)
+        net = M.get_default_net(num_anchors=9, cfg=cfg)
+        net.load_state_dict(sd, strict=False)
+        net.train()
+        bt = O.synthetic_batch(2, HW, HW, seed=1234)
+        gq = torch.Generator().manual_seed(55)
+        h0 = torch.randn(2, 2, 128, generator=gq)
+        c0 = torch.randn(2, 2, 128, generator=gq)
+        net.lstm_init_hidden = lambda bs: (h0, c0)
+        out = net(bt)
+        fs = [tuple(int(v) for v in r) for r in out["feat_sizes"].tolist()]
+        anc = A.create_anchors(fs, ratios, scales, device=cpu).float()
+        lf = L.get_default_loss(ratios, scales, cfg)
+        ev = E.get_default_eval(ratios, scales, cfg)
+        lf.anchs = anc
+        ev.anchs = anc
+        ls = lf(out, bt)
+        net.zero_grad()
+        ls["loss"].backward()
+        em = ev(out, bt)
+        grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        keep = ["backbone.encoder.conv1.weight", "backbone.encoder.bn1.weight", "backbone.encoder.bn1.bias",
+                "backbone.encoder.layer1.0.conv1.weight", "backbone.encoder.layer4.2.bn3.weight",
+                "backbone.fpn.P3_1.bias", "backbone.fpn.P6.bias", "att_reg_box.5.bias", "att_reg_box.5.weight",
+                "att_reg_box.0.0.bias", "lstm.bias_ih_l0", "lstm.bias_hh_l0_reverse", "lstm.weight_hh_l0_reverse"]
+        d = dict(feat_sizes=np.array(fs), seed=np.array([7]), batch_seed=np.array([1234]), h0=h0.numpy(), c0=c0.numpy(),
+                 loss=np.float64(ls["loss"].item()), cls_ls=np.float64(ls["cls_ls"].item()), box_ls=np.float64(ls["box_ls"].item()),
+                 Acc=em["Acc"].detach().numpy(), MaxPos=em["MaxPos"].detach().numpy(), pred_boxes=em["pred_boxes"].detach().numpy(),
+                 pred_scores=em["pred_scores"].detach().numpy(),
+                 rm_bn1=net.backbone.encoder.bn1.running_mean.numpy(), rv_bn1=net.backbone.encoder.bn1.running_var.numpy(),
+                 rm_l4=net.backbone.encoder.layer4[2].bn3.running_mean.numpy(),
+                 rv_l4=net.backbone.encoder.layer4[2].bn3.running_var.numpy())
+        ao, bo = out["att_out"].detach().numpy(), out["bbx_out"].detach().numpy()
+        if HW == 128:
+            d["att_out"], d["bbx_out"] = ao, bo
+        else:
+            d["att_out_s"], d["bbx_out_s"] = ao[:, ::7], bo[:, ::7]
+            d["att_abs_sum"] = np.float64(np.abs(ao).astype(np.float64).sum())
+            d["bbx_abs_sum"] = np.float64(np.abs(bo).astype(np.float64).sum())
+        names = sorted(grads)
+        d["grad_names"] = np.array(names)
+        d["grad_norms"] = np.array([grads[k].double().norm().item() for k in names])
+        for k in keep:
+            d["grad__" + k] = grads[k].numpy()
+        save("g10_" + tag, **d)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
