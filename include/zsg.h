@@ -1,0 +1,223 @@
+/*
+ * zsg.h — C ABI of libzsg.so: the MI355X (gfx950) HIP kernels behind the ZSGNet training step.
+ *
+ * Drop-in boundary.  The reference (TheShadow29/zsgnet-pytorch) is pure Python on PyTorch and has
+ * NO native interface of its own: every device kernel it runs is an implicit nn / F / torch call.  Each entry
+ * point below therefore cites the reference call site whose implicit PyTorch/cuDNN kernel(s) it replaces.  The host
+ * side (the Python modules of zsgnet-pytorch_amd) mirrors the reference's nn.Module / loss / evaluator signatures and binds these
+ * symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All tensors are fp32 unless stated, device memory owned by the
+ *     caller (PyTorch): the library never allocates, frees or retains device memory.
+ *   - activations are NHWC ("pixel-major"): element (b,y,x,c) at  off + b*bstride + (y*W + x)*ld + c.
+ *     weights are OHWI: element (co,r,s,ci) at ((co*R + r)*S + s)*C + ci   (== torch channels_last of an OIHW tensor).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and never synchronises.
+ *   - return 0 on success, <0 on error: -1 bad argument/shape, -2 workspace too small, -3 HIP error.
+ *     zsg_last_error() returns a thread-local message.  Nothing throws across the ABI.
+ */
+#ifndef ZSG_H
+#define ZSG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZSG_VERSION 100
+#define ZSG_MAX_SEG 8
+
+int zsg_version(void);
+const char* zsg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution family (fp32 MFMA v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d forward and its autograd backward at: encoder mdl.py:149-156 (-> fpn_resnet.py:80-100),
+ * FPN fpn_resnet.py:157-172, head mdl.py:379-380, SSD ssd_vgg.py:72-95; LSTM input projection (mdl.py:227).
+ *
+ * One launch covers up to ZSG_MAX_SEG "segments" that share weights / channel counts but have their own geometry
+ * (pyramid levels of the shared head; stride-parity classes of a strided dgrad).  A segment enumerates output rows
+ * (b, y, x) over rows_y x rows_x per image; row (b,y,x) and tap (jy,jx) gather the source pixel
+ *      (y*sy + ty.d0 + jy*ty.dstep,  x*sx + tx.d0 + jx*tx.dstep)      (zero outside [0,src_H) x [0,src_W))
+ * and multiply it with weight tap (ty.w0 + jy*ty.wstep, tx.w0 + jx*tx.wstep).  The row is stored at output pixel
+ *      (y*osy + opy, x*osx + opx) of an out_W-wide image.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n;      /* taps along this axis                      */
+    int32_t w0;     /* first weight tap index                    */
+    int32_t wstep;  /* weight tap index step                     */
+    int32_t d0;     /* source offset of the first tap (pixels)   */
+    int32_t dstep;  /* source offset step per tap                */
+} zsg_taps;
+
+typedef struct {
+    int32_t rows_y, rows_x;          /* row grid per image                                   */
+    int32_t src_H, src_W;            /* bounds of the gathered tensor                        */
+    int32_t sy, sx;                  /* row -> source multiply                               */
+    int32_t out_W;                   /* output image width (pixels)                          */
+    int32_t osy, osx, opy, opx;      /* row -> output pixel                                  */
+    int32_t reserved;
+    int64_t src_off, src_bstride;    /* elements                                             */
+    int64_t out_off, out_bstride;    /* elements                                             */
+    zsg_taps ty, tx;
+} zsg_seg;
+
+typedef struct {
+    int32_t B;            /* images                                                                         */
+    int32_t C;            /* reduction channels per tap (multiple of 4)                                     */
+    int32_t N;            /* output channels                                                                */
+    int32_t src_ld;       /* source pixel stride (elements, multiple of 4)                                  */
+    int32_t out_ld;       /* output pixel stride (elements)                                                 */
+    int32_t wR, wS;       /* weight tap grid; weight row n starts at n*wt_ld, tap (r,s) at (r*wS+s)*wC       */
+    int32_t wC;           /* channels per weight tap (>= C; C < wC selects a channel sub-range with wc0)     */
+    int32_t wc0;          /* first weight channel used                                                      */
+    int32_t wt_ld;        /* elements between consecutive weight rows                                       */
+    int32_t relu;         /* epilogue: max(.,0)                                                             */
+    int32_t merge_x;      /* 1: C==4 and all x-taps of a row are one contiguous run (stem / RGB input)       */
+    int32_t nseg;
+    int32_t tile_hint;    /* 0 auto, else (BM<<16)|BN                                                       */
+    zsg_seg seg[ZSG_MAX_SEG];
+} zsg_conv_desc;
+
+/* out = epilogue( sum_taps src * wt ) ;  epilogue: + bias[n] ; + add_src[same index as out] ; relu ;
+ * * (mask_src[same index] > 0).   bias / add_src / mask_src may be NULL.  add_src may alias out (accumulate). */
+int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
+                   const float* add_src, const float* mask_src, void* stream);
+
+/* Weight gradient.  dw[n][(r*wS+s)*wC + wc0 + c] += sum_rows dy[row][n] * src[gather(row, r, s)][c]
+ * (atomic fp32 accumulation: the caller zeroes dw once per step; shared-weight levels simply accumulate).
+ * The descriptor is the FORWARD descriptor of the convolution (src = forward input, "out" geometry = dy). */
+int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, void* stream);
+
+/* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
+ * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */
+int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t dst_ld, void* stream);
+/* dst[r][0:dst_ld] = [ src[r*src_ld + 0:C] | 0 ... ] */
+int zsg_pad_rows(const float* src, int64_t rows, int32_t C, int32_t src_ld, float* dst, int32_t dst_ld, void* stream);
+
+/* out[g][c] (+)= sum_{r<rows} x[g*gstride + r*ld + c0 + c],  c < C   (bias gradients; per-image language-vector grads) */
+int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32_t rows, int32_t ld, int32_t c0, int32_t C,
+               float* out, int32_t accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BatchNorm2d (train-mode batch statistics, momentum/eps as nn.BatchNorm2d) fused with ReLU / residual add.
+ * Replaces nn.BatchNorm2d + ReLU(inplace) + `out += residual` of fpn_resnet.py:80-100 (53 layers, utils.py:395).
+ * x: [rows][C] contiguous NHWC (ld == C), C % 4 == 0.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t zsg_bn_workspace_bytes(int64_t rows, int32_t C);
+/* mean/invstd out; running_mean/var updated in place (unbiased var), NULL to skip. */
+int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* invstd, float* running_mean,
+                 float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
+/* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
+int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
+                      float* invstd, void* stream);
+/* out = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, const float* residual, int32_t relu, float* out, void* stream);
+/* g = dout * (out > 0 if relu_out != NULL);  dgamma = sum g*xhat ; dbeta = sum g ;
+ * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) ; optional g_out = g (gradient of the residual branch).
+ * dgamma/dbeta are ACCUMULATED (+=) when accumulate != 0, else overwritten. */
+int zsg_bn_backward(const float* dout, const float* relu_out, const float* x, int64_t rows, int32_t C,
+                    const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
+                    float* dgamma, float* dbeta, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pooling / resampling / elementwise (NHWC, C % 4 == 0).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(k, s, p, ceil_mode) — mdl.py:152 (3,2,1), ssd_vgg.py:122,124,132.  idx: uint8 window position. */
+int zsg_maxpool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p,
+                    int32_t Ho, int32_t Wo, float* out, uint8_t* idx, void* stream);
+int zsg_maxpool_bwd(const float* dout, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                    int32_t s, int32_t p, int32_t Ho, int32_t Wo, float* dx, void* stream);
+/* out = a + nearest_upsample(p -> Hd x Wd)   (F.interpolate(size=) + add, fpn_resnet.py:161-162,166-167) */
+int zsg_upsample_add_fwd(const float* a, const float* p, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd,
+                         int32_t C, float* out, void* stream);
+/* dp (+)= nearest-upsample adjoint of dout */
+int zsg_upsample_add_bwd(const float* dout, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd, int32_t C,
+                         float* dp, int32_t accumulate, void* stream);
+/* out = max(x,0) (fpn_resnet.py:172 F.relu(p6)) ; dx = dout * (x > 0) [+ dx] */
+int zsg_relu_fwd(const float* x, int64_t n, float* out, void* stream);
+int zsg_relu_bwd(const float* dout, const float* x, int64_t n, float* dx, int32_t accumulate, void* stream);
+/* adaptive_avg_pool2d(.,1) — fpn_resnet.py:177 ; x [B][HW][C] -> out [B][C] ; and its adjoint */
+int zsg_avgpool_fwd(const float* x, int32_t B, int32_t HW, int32_t C, float* out, void* stream);
+int zsg_avgpool_bwd(const float* dout, int32_t B, int32_t HW, int32_t C, float* dx, int32_t accumulate, void* stream);
+/* channel L2 normalisation x / ||x||_2 (no eps) — ssd_vgg.py:80, mdl.py:118-130 ; rows x C */
+int zsg_l2norm_fwd(const float* x, int64_t rows, int32_t C, float* out, float* norm, void* stream);
+int zsg_l2norm_bwd(const float* dout, const float* out, const float* norm, int64_t rows, int32_t C, float* dx,
+                   void* stream);
+/* image NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel zero) */
+int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t W, float* out, void* stream);
+/* head input  out[b][y][x][0:ld] = [feat(Cf) | we[b](Cw) | gridy,gridx | 0...]  — BackBone.concat_we, mdl.py:69-104.
+ * gy [h], gx [w] are the create_grid centres (anchors.py:47-63).  Cf or Cw may be 0 (ablations mdl.py:363-375). */
+int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, const float* gx, int32_t B, int32_t h,
+                       int32_t w, int32_t Cf, int32_t Cw, int32_t use_grid, int32_t ld, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BiLSTM query encoder — nn.LSTM(300,128,bidirectional) on a PackedSequence + last-token gather, mdl.py:296-336.
+ * gin: input projections x_t W_ih^T + b_ih  [B][T][4H] (made with zsg_conv_igemm);  one launch per direction.
+ * The sorted-position rule (h0/c0 [B][H] of this direction are indexed by the rank of the sample in a stable
+ * descending sort of the lengths, mdl.py:309) is evaluated on device.
+ * forward direction: lens = qlens (float, as the collater makes them, dat_loader.py:193);
+ * reverse direction: one cell step on x[len-1]: pass T=1, lens=NULL (all ones).
+ * Saves for backward: gates [B][T][4H] (post-activation i,f,g,o), cst [B][T][H] (c_t), hprev [B][T][H] (h_{t-1}).
+ * out: h at the last valid step, written to we[b*we_ld + we_off : +H].
+ * ------------------------------------------------------------------------------------------------------------- */
+int zsg_lstm_gather_last(const float* qvec, const float* qlens, int32_t B, int32_t T, int32_t E, float* out,
+                         void* stream);
+int zsg_lstm_fwd(const float* gin, const float* w_hh, const float* b_hh, const float* h0, const float* c0,
+                 const float* qlens_rank, const float* lens, int32_t B, int32_t T, int32_t H, float* gates,
+                 float* cst, float* hprev, float* we, int32_t we_ld, int32_t we_off, void* stream);
+/* dgates [B][T][4H] (zero beyond the sample's length) from dwe; weight grads then come from zsg_conv_wgrad/colsum */
+int zsg_lstm_bwd(const float* dwe, int32_t we_ld, int32_t we_off, const float* w_hh, const float* gates,
+                 const float* cst, const float* c0, const float* qlens_rank, const float* lens, int32_t B, int32_t T,
+                 int32_t H, float* dgates, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Anchor matching + focal / smooth-L1 loss, forward and backward in one call — ZSGLoss.forward, loss.py:43-143
+ * (IoU_values anchors.py:90-116, simple_match_anchors :153-165, bbox_to_reg_params :168-179).
+ * out5: network output [B][A][5] = (dy,dx,dh,dw,att);  annot [B][4] y1x1y2x2;  anchors [A][4] fp32 tlbr.
+ * losses[3] = (loss, cls_ls, box_ls);  grad5 [B][A][5] = d loss / d out5 (already includes lamb_reg, 1/B, 1/#pos).
+ * match_idx [B] int32 = arg-max-IoU anchor (lowest index wins; bit-exact IoU: no FMA contraction, IEEE divide).
+ * flags: bit0 use_focal, bit1 use_multi, bit2 use_softmax.  NaN branch (loss.py:128-133) is taken on device.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t zsg_loss_workspace_bytes(int32_t B, int32_t A);
+int zsg_loss_fwd_bwd(const float* out5, const float* annot, const float* anchors, int32_t B, int32_t A, float alpha,
+                     float gamma, float lamb_reg, float match_thr, int32_t flags, float grad_scale, float* losses,
+                     float* grad5, int32_t* match_idx, int32_t* npos, void* ws, size_t ws_bytes, void* stream);
+
+/* Evaluator.forward, evaluator.py:48-117 (reg_params_to_bbox anchors.py:182-197): arg-max score anchor -> decode ->
+ * IoU >= thr.  metrics[2] = (Acc, MaxPos); pred_boxes [B][4] pixels x1y1x2y2; pred_scores [B]; pred_idx [B] int32. */
+int zsg_eval(const float* out5, const float* annot, const float* anchors, const float* img_size, int32_t B, int32_t A,
+             float acc_thr, float* metrics, float* pred_boxes, float* pred_scores, int32_t* pred_idx, int32_t* best_idx,
+             float* ws_ok /* [2*B] */, void* stream);
+/* IoU table [B][A] (tests / diagnostics) */
+int zsg_iou(const float* boxes, const float* anchors, int32_t B, int32_t A, float* iou, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused Adam over a flat parameter buffer — torch.optim.Adam(betas=(0.9,0.99)) at main_dist.py:50 / utils.py:413.
+ * step_count: device int32[1], incremented by the kernel (graph-capturable).  grad_scale folds 1/world_size.
+ * ------------------------------------------------------------------------------------------------------------- */
+int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int32_t* step_count, void* stream);
+
+int zsg_memset_f32(float* p, int64_t n, float value, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Per-launch timing (HIP events on the launch stream) used by bench.py's roofline leg.  Not used in timed steps.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double ms;        /* summed kernel time between the bracketing events */
+    double flops;     /* algorithmic 2*MAC for conv kernels, else 0       */
+    double bytes;     /* algorithmic bytes moved (HBM-bound kernels)      */
+} zsg_prof_entry;
+int zsg_prof_enable(int32_t on);
+int zsg_prof_collect(zsg_prof_entry* out, int32_t max_entries); /* syncs the recorded events; returns #entries */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZSG_H */

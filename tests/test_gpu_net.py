@@ -1,0 +1,183 @@
+"""End-to-end GPU parity: the product ZSGNet / ZSGLoss / Evaluator / FusedAdam (HIP kernels through the C ABI) against
+the CPU oracle on the same seeded inputs and against the reference goldens (g10).  fp32 tolerances: network outputs
+abs 2e-3 (summation order through ~60 layers), gradients rel 1e-2 of their norm, loss rel 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zsg_oracle as O  # noqa: E402
+
+RATIOS, SCALES = O.default_ratios_scales()
+
+
+@pytest.fixture(scope="module")
+def Z():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from zsgnet_pytorch_amd import config, evaluator, loss, mdl, optim
+    return config, evaluator, loss, mdl, optim
+
+
+def build(Z, arch="resnet50", seed=7, **flags):
+    config, evaluator, loss, mdl, optim = Z
+    cfg = config.get_cfg(resnet_arch=arch, **flags)
+    net = mdl.get_default_net(9, cfg)
+    sd = O.seeded_state_dict(arch, seed)
+    net.load_state_dict(sd)
+    net.to("cuda")
+    r, s = config.ratios_scales(cfg)
+    return cfg, net, sd, loss.get_default_loss(r, s, cfg), evaluator.get_default_eval(r, s, cfg)
+
+
+def to_dev(bt):
+    return {k: v.cuda() for k, v in bt.items()}
+
+
+def rel_err(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("tag,hw", [("e2e_128", 128), ("e2e_300", 300)])
+def test_forward_backward_vs_reference_golden(Z, gold, tag, hw):
+    g = gold("g10_" + tag)
+    cfg, net, sd, lf, ev = build(Z, seed=int(g["seed"][0]))
+    net.train()
+    bt = O.synthetic_batch(2, hw, hw, seed=int(g["batch_seed"][0]))
+    inp = to_dev(bt)
+    inp["h0"], inp["c0"] = torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"])
+    out = net(inp)
+    assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist() and int(out["num_f_out"]) == len(g["feat_sizes"])
+    att, bbx = out["att_out"].detach().cpu().numpy(), out["bbx_out"].detach().cpu().numpy()
+    if hw == 128:
+        np.testing.assert_allclose(att, g["att_out"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(bbx, g["bbx_out"], rtol=2e-3, atol=2e-3)
+    else:
+        np.testing.assert_allclose(att[:, ::7], g["att_out_s"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(bbx[:, ::7], g["bbx_out_s"], rtol=2e-3, atol=2e-3)
+    ls = lf(out, inp)
+    for k in ("loss", "cls_ls", "box_ls"):
+        np.testing.assert_allclose(ls[k].item(), g[k], rtol=2e-4, err_msg=k)
+    ls["loss"].backward()
+    names = list(g["grad_names"])
+    norms = dict(zip(names, g["grad_norms"]))
+    bad = []
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        gn = float(p.grad.double().norm())
+        if abs(gn - norms[n]) > 1e-2 * norms[n] + 1e-7:
+            bad.append((n, gn, norms[n]))
+    assert not bad, f"{len(bad)} gradient norms off: {bad[:8]}"
+    for k in g.files:
+        if k.startswith("grad__"):
+            e = rel_err(dict(net.named_parameters())[k[6:]].grad.cpu(), torch.from_numpy(g[k]))
+            assert e < 1e-2, f"{k}: relative error {e:.3g}"
+    # running statistics after one train-mode forward
+    st = net.state_dict()
+    np.testing.assert_allclose(st["backbone.encoder.bn1.running_mean"].cpu().numpy(), g["rm_bn1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st["backbone.encoder.layer4.2.bn3.running_var"].cpu().numpy(), g["rv_l4"], rtol=1e-3, atol=1e-6)
+    assert int(st["backbone.encoder.bn1.num_batches_tracked"]) == 1
+    em = ev(out, inp)
+    assert em["Acc"].item() == g["Acc"] and em["MaxPos"].item() == g["MaxPos"]
+    np.testing.assert_allclose(em["pred_scores"].cpu().numpy(), g["pred_scores"], rtol=1e-3)
+
+
+@pytest.mark.parametrize("arch,B,hw", [("resnet18", 2, 96), ("resnet50", 3, 160), ("resnet101", 1, 128)])
+def test_forward_backward_vs_oracle(Z, arch, B, hw):
+    """other encoders / ragged sizes (odd pyramid shapes, query lengths 1..T with ties) against the CPU oracle"""
+    cfg, net, sd, lf, ev = build(Z, arch=arch, seed=11)
+    net.train()
+    bt = O.synthetic_batch(B, hw, hw + 32, seed=5, tmax=13)
+    bt["qlens"][-1] = bt["qlens"][0] if B > 1 else bt["qlens"][0]
+    gq = torch.Generator().manual_seed(2)
+    h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
+    inp = to_dev(bt)
+    inp["h0"], inp["c0"] = h0, c0
+    out = net(inp)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    ref = O.zsgnet_forward(sd, bt, h0, c0, arch=arch)
+    assert out["feat_sizes"].tolist() == ref["feat_sizes"].tolist()
+    np.testing.assert_allclose(out["att_bbx_out"].detach().cpu()[..., 4:5].numpy(), ref["att_out"].detach().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out["bbx_out"].detach().cpu().numpy(), ref["bbx_out"].detach().numpy(), rtol=2e-3, atol=2e-3)
+    fs = [tuple(r) for r in ref["feat_sizes"].tolist()]
+    anc = torch.from_numpy(O.create_anchors(fs, RATIOS, SCALES).astype(np.float32))
+    lr = O.torch_loss(ref, bt["annot"], anc)
+    ls = lf(out, inp)
+    np.testing.assert_allclose(ls["loss"].item(), lr["loss"].item(), rtol=2e-4)
+    lr["loss"].backward()
+    ls["loss"].backward()
+    worst = []
+    for n, p in net.named_parameters():
+        e = rel_err(p.grad.cpu(), sd[n].grad)
+        if e > 2e-2:
+            worst.append((n, e))
+    assert not worst, f"gradient mismatch vs oracle: {worst[:8]}"
+
+
+def test_eval_mode_and_state_dict_roundtrip(Z):
+    cfg, net, sd, lf, ev = build(Z, seed=3)
+    bt = O.synthetic_batch(2, 128, 128, seed=9)
+    gq = torch.Generator().manual_seed(4)
+    h0, c0 = torch.randn(2, 2, 128, generator=gq), torch.randn(2, 2, 128, generator=gq)
+    inp = to_dev(bt)
+    inp["h0"], inp["c0"] = h0, c0
+    for k in sd:                                   # non-trivial running statistics
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape) * 0.05
+        if k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape) + 0.5
+    net.load_state_dict(sd)
+    net.eval()
+    with torch.no_grad():
+        out = net(inp)
+    ref = O.zsgnet_forward({k: v.clone() for k, v in sd.items()}, bt, h0, c0, training=False)
+    np.testing.assert_allclose(out["bbx_out"].cpu().numpy(), ref["bbx_out"].numpy(), rtol=2e-3, atol=2e-3)
+    back = {k: v.cpu() for k, v in net.state_dict().items()}
+    assert set(back) == set(sd)
+    for k in sd:
+        assert torch.equal(back[k], sd[k]), k
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({"bogus": torch.zeros(1)})
+    ddp_style = {"module." + k: v for k, v in sd.items()}
+    ddp_style["module.backbone.encoder.fc.weight"] = torch.zeros(1000, 2048)
+    net.load_state_dict(ddp_style)
+
+
+def test_train_steps_match_oracle_and_reduce_loss(Z):
+    """3 full steps (zero_grad -> fwd -> loss -> bwd -> fused Adam -> eval, utils.py:407-414) against the CPU oracle
+    stepping torch.optim.Adam on the same batch; then the loss must go down."""
+    config, evaluator, loss, mdl, optim = Z
+    cfg, net, sd, lf, ev = build(Z, arch="resnet18", seed=21)
+    net.train()
+    opt = optim.FusedAdam(net, lr=1e-3, betas=(0.9, 0.99))
+    params = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    buffers = {k: v.clone() for k, v in sd.items() if k not in params}
+    opt_ref = torch.optim.Adam(list(params.values()), lr=1e-3, betas=(0.9, 0.99))
+    bt = O.synthetic_batch(2, 96, 96, seed=77)
+    anc = torch.from_numpy(O.create_anchors(O.feat_sizes_for(96, 96), RATIOS, SCALES).astype(np.float32))
+    inp = to_dev(bt)
+    gq = torch.Generator().manual_seed(6)
+    losses = []
+    for it in range(3):
+        h0, c0 = torch.randn(2, 2, 128, generator=gq), torch.randn(2, 2, 128, generator=gq)
+        inp["h0"], inp["c0"] = h0, c0
+        opt.zero_grad()
+        out = net(inp)
+        ls = lf(out, inp)
+        ls["loss"].mean().backward()
+        opt.step()
+        em = ev(out, inp)
+        lr, _ = O.cpu_train_step(params, buffers, opt_ref, bt, h0, c0, anc, arch="resnet18")
+        losses.append((ls["loss"].item(), lr["loss"].item()))
+        assert 0.0 <= em["Acc"].item() <= 1.0
+    for a, b in losses:
+        np.testing.assert_allclose(a, b, rtol=5e-3)
+    assert losses[-1][0] < losses[0][0]
+    got = net.state_dict()
+    for k in ("att_reg_box.5.bias", "backbone.fpn.P3_2.weight", "backbone.encoder.layer2.0.conv1.weight", "lstm.weight_hh_l0"):
+        e = rel_err(got[k].cpu() - sd[k], params[k].detach() - sd[k])
+        assert e < 5e-2, f"{k}: parameter update differs from the oracle by {e:.3g}"

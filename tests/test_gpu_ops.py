@@ -1,0 +1,414 @@
+"""GPU parity of every HIP op (called through the C ABI) against the CPU oracle / torch-CPU fp32 references.
+Tolerances are stated per test: index / mask outputs exact, fp32 sums rel 1e-4 (summation order), losses rel 1e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import zsg_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def Z():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import zsgnet_pytorch_amd._lib as L
+    import zsgnet_pytorch_amd.ops as ops
+    return L, ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def nhwc(x, cpad=None):
+    B, Cc, H, W = x.shape
+    cpad = cpad or pad4(Cc)
+    o = torch.zeros(B, H, W, cpad)
+    o[..., :Cc] = x.permute(0, 2, 3, 1)
+    return o
+
+
+def ohwi(w, cpad=None):
+    Co, Ci, k, _ = w.shape
+    cpad = cpad or pad4(Ci)
+    o = torch.zeros(Co, k, k, cpad)
+    o[..., :Ci] = w.permute(0, 2, 3, 1)
+    return o
+
+
+def view_of(ops, t, B, H, W, Cc, ld=None):
+    return ops.TView(t.view(-1), B, Cc, ld or Cc, [ops.Level(0, H, W, H * W * (ld or Cc))])
+
+
+def assert_close(got, ref, rtol, atol, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax((err - tol).flatten()))
+        idx = np.unravel_index(i, tuple(err.shape))
+        raise AssertionError(f"{what}: {int(bad.sum())}/{err.numel()} mismatches; worst at {idx}: got {got.flatten()[i]:.6g} "
+                             f"ref {ref.flatten()[i]:.6g} (max abs err {err.max():.3g}, ref scale {ref.abs().max():.3g})")
+
+
+CONV_CASES = [
+    # B, Ci, Co, H, W, k, s, p, d, bias, relu, merge_x, tile
+    (2, 64, 64, 19, 19, 1, 1, 0, 1, False, False, False, 0),
+    (2, 64, 128, 20, 17, 3, 1, 1, 1, True, True, False, 0),
+    (2, 128, 128, 21, 21, 3, 2, 1, 1, False, False, False, 0),
+    (3, 256, 64, 9, 11, 1, 2, 0, 1, False, False, False, 0),
+    (2, 3, 64, 45, 37, 7, 2, 3, 1, False, False, True, 0),
+    (2, 3, 64, 31, 30, 3, 1, 1, 1, True, True, True, 0),
+    (1, 514, 256, 10, 10, 3, 1, 1, 1, True, True, False, 0),
+    (2, 256, 45, 10, 10, 3, 1, 1, 1, True, False, False, 0),
+    (1, 64, 96, 12, 12, 3, 1, 6, 6, True, False, False, 0),
+    (2, 128, 256, 5, 5, 3, 1, 0, 1, True, True, False, 0),
+    (2, 64, 256, 16, 16, 1, 1, 0, 1, False, False, False, (128 << 16) | 128),
+    (2, 64, 256, 16, 16, 3, 1, 1, 1, False, False, False, (128 << 16) | 64),
+    (2, 64, 256, 16, 16, 3, 1, 1, 1, False, False, False, (64 << 16) | 64),
+    (16, 300, 512, 1, 20, 1, 1, 0, 1, True, False, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+def test_conv_fwd_dgrad_wgrad(Z, case):
+    L, ops = Z
+    B, Ci, Co, H, W, k, s, p, d, bias, relu, mx, tile = case
+    g = torch.Generator().manual_seed(100 + Ci + Co + k)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    y_ref = F.conv2d(xr, wr, br, s, p, d)
+    if relu:
+        y_ref = F.relu(y_ref)
+    Ho, Wo = y_ref.shape[2:]
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    cp = pad4(Ci)
+    st = L.stream_ptr()
+
+    xd, wd = dev(nhwc(x)), dev(ohwi(w))
+    out = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+    src = view_of(ops, xd, B, H, W, cp)
+    ov = view_of(ops, out, B, Ho, Wo, Co)
+    desc = ops.fwd_desc(src, ov, cp, Co, k, s, p, d, wC=cp, relu=relu, merge_x=mx, tile_hint=tile)
+    bd = dev(b) if bias else None
+    L.check(L.lib.zsg_conv_igemm(C.byref(desc), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr() if bias else None, None,
+                                 None, st), "igemm")
+    assert_close(out.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, "conv fwd")
+
+    # backward: dy is the gradient w.r.t. the pre-ReLU output
+    gpre = gy * (y_ref > 0) if relu else gy
+    Cop = pad4(Co)
+    dyd = dev(nhwc(gpre, Cop))
+    dyv = view_of(ops, dyd, B, Ho, Wo, Cop)
+    # wgrad
+    dw = torch.zeros(Co, k, k, cp, device="cuda")
+    wdesc = ops.fwd_desc(src, dyv, cp, Co, k, s, p, d, wC=cp)
+    L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), st), "wgrad")
+    assert_close(dw[..., :Ci].permute(0, 3, 1, 2), wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), "conv wgrad")
+    if cp > Ci:
+        assert float(dw[..., Ci:].abs().max()) == 0.0
+    if bias:
+        db = torch.zeros(Co, device="cuda")
+        L.check(L.lib.zsg_colsum(dyd.data_ptr(), 1, 0, B * Ho * Wo, Cop, 0, Co, db.data_ptr(), 0, st), "colsum")
+        assert_close(db, br.grad, 5e-4, 5e-4 * float(br.grad.abs().max()), "bias grad")
+    # dgrad (skipped for RGB inputs: the image needs no gradient)
+    if not mx:
+        wt = torch.full((cp, k, k, Cop), float("nan"), device="cuda")
+        L.check(L.lib.zsg_transpose_w(wd.data_ptr(), wt.data_ptr(), Co, k * k, cp, Cop, st), "transpose_w")
+        assert torch.equal(wt[..., :Co].cpu(), ohwi(w).permute(3, 1, 2, 0).contiguous())
+        dx = torch.full((B, H, W, cp), float("nan"), device="cuda")
+        dxv = view_of(ops, dx, B, H, W, cp)
+        ddesc = ops.dgrad_desc(dyv, dxv, Cop, cp, k, s, p, d)
+        L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, st), "dgrad")
+        assert_close(dx[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), "conv dgrad")
+        # accumulate + relu-mask epilogue: out = (prev + acc) * (mask > 0)
+        prev = torch.randn(B, H, W, cp, generator=g)
+        mask = torch.randn(B, H, W, cp, generator=g)
+        dx2, maskd = dev(prev), dev(mask)
+        L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx2.data_ptr(), None, dx2.data_ptr(), maskd.data_ptr(), st), "dgrad+")
+        ref2 = (prev[..., :Ci] + xr.grad.permute(0, 2, 3, 1)) * (mask[..., :Ci] > 0)
+        assert_close(dx2[..., :Ci], ref2, 5e-4, 5e-4 * float(ref2.abs().max()), "dgrad accumulate+mask")
+    torch.cuda.synchronize()
+
+
+def test_conv_multilevel_shared_weights(Z):
+    """grouped launch over pyramid levels (shared head), output scattered into the [B, A, 5]-style buffer"""
+    L, ops = Z
+    g = torch.Generator().manual_seed(5)
+    B, Ci, Co, k = 2, 64, 45, 3
+    sizes = [(7, 7), (4, 4), (2, 2), (1, 1)]
+    w = torch.randn(Co, Ci, k, k, generator=g) / 24
+    b = torch.randn(Co, generator=g)
+    xs = [torch.randn(B, Ci, h, ww, generator=g) for h, ww in sizes]
+    refs = [F.conv2d(x, w, b, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Co) for x in xs]
+    ref = torch.cat(refs, dim=1)                     # [B, P, Co]
+    P = ref.shape[1]
+    packed = torch.cat([nhwc(x).reshape(-1) for x in xs]).cuda()
+    lv_in, lv_out, off_in, off_px = [], [], 0, 0
+    for (h, ww) in sizes:
+        lv_in.append(ops.Level(off_in, h, ww, h * ww * Ci))
+        lv_out.append(ops.Level(off_px * Co, h, ww, P * Co))
+        off_in += B * h * ww * Ci
+        off_px += h * ww
+    src = ops.TView(packed, B, Ci, Ci, lv_in)
+    out = torch.full((B, P, Co), float("nan"), device="cuda")
+    ov = ops.TView(out.view(-1), B, Co, Co, lv_out)
+    desc = ops.fwd_desc(src, ov, Ci, Co, k, 1, 1, 1, wC=Ci)
+    wd, bd = dev(ohwi(w)), dev(b)
+    L.check(L.lib.zsg_conv_igemm(C.byref(desc), packed.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr(), None, None, L.stream_ptr()), "igemm")
+    assert_close(out, ref, 2e-4, 2e-4, "multi-level conv")
+    # wgrad accumulates over the levels
+    gy = torch.randn(B, P, Co, generator=g)
+    Cop = 48
+    gyp = torch.zeros(B, P, Cop)
+    gyp[..., :Co] = gy
+    gyd = dev(gyp)
+    lv_dy = []
+    off_px = 0
+    for (h, ww) in sizes:
+        lv_dy.append(ops.Level(off_px * Cop, h, ww, P * Cop))
+        off_px += h * ww
+    dyv = ops.TView(gyd.view(-1), B, Cop, Cop, lv_dy)
+    dw = torch.zeros(Co, k, k, Ci, device="cuda")
+    wdesc = ops.fwd_desc(src, dyv, Ci, Co, k, 1, 1, 1, wC=Ci)
+    L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), packed.data_ptr(), gyd.data_ptr(), dw.data_ptr(), L.stream_ptr()), "wgrad")
+    wr = w.clone().requires_grad_()
+    tot = sum((F.conv2d(x, wr, None, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Co) * gy[:, o:o + x.shape[2] * x.shape[3]]).sum()
+              for x, o in zip(xs, np.cumsum([0] + [h * ww for h, ww in sizes])[:-1]))
+    tot.backward()
+    assert_close(dw.permute(0, 3, 1, 2), wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), "multi-level wgrad")
+
+
+@pytest.mark.parametrize("rows,Cc", [(2 * 19 * 19, 64), (3 * 7 * 5, 256), (1000, 2048), (5000, 12)])
+def test_batchnorm(Z, rows, Cc):
+    L, _ = Z
+    g = torch.Generator().manual_seed(rows + Cc)
+    x = torch.randn(rows, Cc, generator=g) * 2 + 0.7
+    gam, bet = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    res = torch.randn(rows, Cc, generator=g)
+    rm, rv = torch.randn(Cc, generator=g) * 0.1, torch.rand(Cc, generator=g) + 0.5
+    xr, gr, br, rr = x.clone().requires_grad_(), gam.clone().requires_grad_(), bet.clone().requires_grad_(), res.clone().requires_grad_()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    x4 = xr.t().reshape(1, Cc, rows, 1)
+    y = F.batch_norm(x4, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    out_ref = F.relu(y + rr.t().reshape(1, Cc, rows, 1))
+    gy = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(gy)
+    st = L.stream_ptr()
+    wsb = L.lib.zsg_bn_workspace_bytes(rows, Cc)
+    ws = torch.empty(wsb // 4 + 4, device="cuda")
+    xd, gd, bd, resd, rmd, rvd = dev(x), dev(gam), dev(bet), dev(res), dev(rm), dev(rv)
+    mean, invstd = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    L.check(L.lib.zsg_bn_stats(xd.data_ptr(), rows, Cc, mean.data_ptr(), invstd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 0.1, 1e-5,
+                               ws.data_ptr(), wsb, st), "bn_stats")
+    assert_close(mean, x.mean(0), 1e-5, 1e-5, "bn mean")
+    assert_close(invstd, 1 / torch.sqrt(x.var(0, unbiased=False) + 1e-5), 1e-4, 0, "bn invstd")
+    assert_close(rmd, rm_ref, 1e-5, 1e-6, "running_mean")
+    assert_close(rvd, rv_ref, 1e-4, 1e-6, "running_var")
+    out = torch.empty(rows, Cc, device="cuda")
+    L.check(L.lib.zsg_bn_apply(xd.data_ptr(), rows, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), resd.data_ptr(), 1,
+                               out.data_ptr(), st), "bn_apply")
+    assert_close(out, out_ref.reshape(Cc, rows).t(), 1e-4, 1e-5, "bn out")
+    dout = dev(gy.reshape(Cc, rows).t())
+    dx, gout = torch.empty(rows, Cc, device="cuda"), torch.empty(rows, Cc, device="cuda")
+    dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    L.check(L.lib.zsg_bn_backward(dout.data_ptr(), out.data_ptr(), xd.data_ptr(), rows, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+                                  dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, ws.data_ptr(), wsb, st), "bn_backward")
+    sc = float(xr.grad.abs().max())
+    assert_close(dx, xr.grad, 1e-3, 1e-4 * sc, "bn dx")
+    assert_close(gout, rr.grad, 1e-5, 1e-6, "bn residual grad")
+    assert_close(dg, gr.grad, 1e-3, 1e-4 * float(gr.grad.abs().max()), "bn dgamma")
+    assert_close(db, br.grad, 1e-3, 1e-4 * float(br.grad.abs().max()), "bn dbeta")
+    # eval-mode statistics
+    L.check(L.lib.zsg_bn_eval_stats(rmd.data_ptr(), rvd.data_ptr(), Cc, 1e-5, mean.data_ptr(), invstd.data_ptr(), st), "bn_eval_stats")
+    assert_close(invstd, 1 / torch.sqrt(rvd.cpu() + 1e-5), 1e-6, 0, "eval invstd")
+
+
+@pytest.mark.parametrize("k,s,p,ceil,H,W", [(3, 2, 1, False, 37, 40), (2, 2, 0, False, 30, 30), (2, 2, 0, True, 15, 19), (3, 1, 1, False, 9, 9)])
+def test_maxpool(Z, k, s, p, ceil, H, W):
+    L, _ = Z
+    g = torch.Generator().manual_seed(k * 10 + s)
+    B, Cc = 2, 8
+    x = torch.relu(torch.randn(B, Cc, H, W, generator=g))          # many exact ties at 0, like post-ReLU maps
+    xr = x.clone().requires_grad_()
+    y = F.max_pool2d(xr, k, s, p, ceil_mode=ceil)
+    Ho, Wo = y.shape[2:]
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = dev(x.permute(0, 2, 3, 1))
+    out = torch.empty(B, Ho, Wo, Cc, device="cuda")
+    idx = torch.empty(B * Ho * Wo * Cc, dtype=torch.uint8, device="cuda")
+    st = L.stream_ptr()
+    L.check(L.lib.zsg_maxpool_fwd(xd.data_ptr(), B, H, W, Cc, k, s, p, Ho, Wo, out.data_ptr(), idx.data_ptr(), st), "maxpool")
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), y.detach())
+    dx = torch.empty(B, H, W, Cc, device="cuda")
+    dyd = dev(gy.permute(0, 2, 3, 1))
+    L.check(L.lib.zsg_maxpool_bwd(dyd.data_ptr(), idx.data_ptr(), B, H, W, Cc, k, s, p, Ho, Wo, dx.data_ptr(), st), "maxpool_bwd")
+    assert_close(dx.permute(0, 3, 1, 2), xr.grad, 1e-6, 1e-6, "maxpool bwd")
+
+
+@pytest.mark.parametrize("Hs,Ws,Hd,Wd", [(10, 10, 19, 19), (19, 19, 38, 38), (4, 5, 8, 9), (3, 3, 5, 5)])
+def test_upsample_add(Z, Hs, Ws, Hd, Wd):
+    L, _ = Z
+    g = torch.Generator().manual_seed(Hs * Wd)
+    B, Cc = 2, 8
+    a, p = torch.randn(B, Cc, Hd, Wd, generator=g), torch.randn(B, Cc, Hs, Ws, generator=g)
+    pr = p.clone().requires_grad_()
+    out_ref = a + F.interpolate(pr, size=(Hd, Wd))
+    gy = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(gy)
+    ad, pd = dev(a.permute(0, 2, 3, 1)), dev(p.permute(0, 2, 3, 1))
+    out = torch.empty(B, Hd, Wd, Cc, device="cuda")
+    st = L.stream_ptr()
+    L.check(L.lib.zsg_upsample_add_fwd(ad.data_ptr(), pd.data_ptr(), B, Hs, Ws, Hd, Wd, Cc, out.data_ptr(), st), "upsample")
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), out_ref.detach())
+    dp = torch.empty(B, Hs, Ws, Cc, device="cuda")
+    L.check(L.lib.zsg_upsample_add_bwd(dev(gy.permute(0, 2, 3, 1)).data_ptr(), B, Hs, Ws, Hd, Wd, Cc, dp.data_ptr(), 0, st), "upsample_bwd")
+    assert_close(dp.permute(0, 3, 1, 2), pr.grad, 1e-6, 1e-6, "upsample bwd")
+
+
+def test_small_ops(Z):
+    L, _ = Z
+    st = L.stream_ptr()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 3, 256, generator=g)
+    xd = dev(x)
+    o = torch.empty_like(xd)
+    L.check(L.lib.zsg_relu_fwd(xd.data_ptr(), x.numel(), o.data_ptr(), st), "relu")
+    assert torch.equal(o.cpu(), torch.relu(x))
+    gy = torch.randn(x.shape, generator=g)
+    dx = dev(torch.ones_like(x))
+    L.check(L.lib.zsg_relu_bwd(dev(gy).data_ptr(), xd.data_ptr(), x.numel(), dx.data_ptr(), 1, st), "relu_bwd")
+    assert_close(dx, 1 + gy * (x > 0), 1e-6, 1e-6)
+    avg = torch.empty(2, 256, device="cuda")
+    L.check(L.lib.zsg_avgpool_fwd(xd.data_ptr(), 2, 9, 256, avg.data_ptr(), st), "avgpool")
+    assert_close(avg, x.reshape(2, 9, 256).mean(1), 1e-6, 1e-6)
+    ga = torch.randn(2, 256, generator=g)
+    dxa = torch.empty(2, 9, 256, device="cuda")
+    L.check(L.lib.zsg_avgpool_bwd(dev(ga).data_ptr(), 2, 9, 256, dxa.data_ptr(), 0, st), "avgpool_bwd")
+    assert_close(dxa, (ga / 9)[:, None, :].expand(2, 9, 256), 1e-6, 1e-7)
+    img = torch.rand(2, 3, 13, 11, generator=g)
+    n4 = torch.empty(2, 13, 11, 4, device="cuda")
+    L.check(L.lib.zsg_nchw_to_nhwc4(dev(img).data_ptr(), 2, 3, 13, 11, n4.data_ptr(), st), "nhwc4")
+    assert torch.equal(n4.cpu()[..., :3], img.permute(0, 2, 3, 1)) and float(n4[..., 3].abs().max()) == 0
+    # fuse_lang_grid == oracle.fuse_lang_grid (channel order feat | we | y | x)
+    feat, we = torch.randn(2, 256, 5, 3, generator=g), torch.randn(2, 256, generator=g)
+    ref = O.fuse_lang_grid(feat, we).permute(0, 2, 3, 1)
+    grid = O.create_grid(5, 3).reshape(5, 3, 2)
+    out = torch.full((2, 5, 3, 516), float("nan"), device="cuda")
+    L.check(L.lib.zsg_fuse_lang_grid(dev(feat.permute(0, 2, 3, 1)).data_ptr(), dev(we).data_ptr(), dev(torch.from_numpy(grid[:, 0, 0].copy())).data_ptr(),
+                                     dev(torch.from_numpy(grid[0, :, 1].copy())).data_ptr(), 2, 5, 3, 256, 256, 1, 516, out.data_ptr(), st), "fuse")
+    assert torch.equal(out.cpu()[..., :514], ref) and float(out[..., 514:].abs().max()) == 0
+    # pad_rows / colsum per group
+    src = torch.randn(7, 45, generator=g)
+    dst = torch.full((7, 48), float("nan"), device="cuda")
+    L.check(L.lib.zsg_pad_rows(dev(src).data_ptr(), 7, 45, 45, dst.data_ptr(), 48, st), "pad_rows")
+    assert torch.equal(dst.cpu()[:, :45], src) and float(dst[:, 45:].abs().max()) == 0
+    big = torch.randn(3, 700, 40, generator=g)
+    cs = torch.zeros(3, 16, device="cuda")
+    L.check(L.lib.zsg_colsum(dev(big).data_ptr(), 3, 700 * 40, 700, 40, 8, 16, cs.data_ptr(), 0, st), "colsum")
+    assert_close(cs, big[:, :, 8:24].sum(1), 1e-4, 1e-4)
+
+
+def test_l2norm(Z):
+    L, _ = Z
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(50, 512, generator=g)
+    xr = x.clone().requires_grad_()
+    y = xr / xr.norm(dim=1, keepdim=True)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = dev(x)
+    out, nrm, dx = torch.empty_like(xd), torch.empty(50, device="cuda"), torch.empty_like(xd)
+    st = L.stream_ptr()
+    L.check(L.lib.zsg_l2norm_fwd(xd.data_ptr(), 50, 512, out.data_ptr(), nrm.data_ptr(), st), "l2norm")
+    assert_close(out, y, 1e-5, 1e-6)
+    L.check(L.lib.zsg_l2norm_bwd(dev(gy).data_ptr(), out.data_ptr(), nrm.data_ptr(), 50, 512, dx.data_ptr(), st), "l2norm_bwd")
+    assert_close(dx, xr.grad, 1e-4, 1e-5)
+
+
+def test_adam_matches_torch(Z):
+    L, _ = Z
+    g = torch.Generator().manual_seed(1)
+    n = 4099
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-2, betas=(0.9, 0.99))
+    pd, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for it in range(5):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        L.check(L.lib.zsg_adam_step(pd.data_ptr(), dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.99, 1e-8, 0.0, 1.0,
+                                    step.data_ptr(), L.stream_ptr()), "adam")
+    assert int(step.item()) == 5
+    assert_close(pd, pr.detach(), 1e-5, 1e-6, "adam params")
+
+
+def test_lstm_against_golden_and_oracle(Z, gold):
+    """BiLSTM forward + BPTT (csrc/lstm.hip + MFMA input GEMMs) vs the reference golden (g7) — rtol 1e-4."""
+    L, ops = Z
+    gz = gold("g7_lstm")
+    sd = {k: v for k, v in O.seeded_state_dict("resnet50", int(gz["seed"][0])).items() if k.startswith("lstm.")}
+    qvec, qlens = torch.from_numpy(gz["qvec"]), torch.from_numpy(gz["qlens"])
+    h0, c0 = torch.from_numpy(gz["h0"]), torch.from_numpy(gz["c0"])
+    B, T, E, H = qvec.shape[0], qvec.shape[1], 300, 128
+    st = L.stream_ptr()
+    qd, ld = dev(qvec), dev(qlens)
+    we = torch.zeros(B, 256, device="cuda")
+    saved = {}
+    for di, suf in enumerate(["", "_reverse"]):
+        Tn = T if di == 0 else 1
+        if di == 0:
+            xin = qd
+        else:
+            xin = torch.empty(B, 1, E, device="cuda")
+            L.check(L.lib.zsg_lstm_gather_last(qd.data_ptr(), ld.data_ptr(), B, T, E, xin.data_ptr(), st), "gather")
+        gin = torch.empty(B, Tn, 4 * H, device="cuda")
+        src = ops.TView(xin.view(-1), B, E, E, [ops.Level(0, 1, Tn, Tn * E)])
+        gv = ops.TView(gin.view(-1), B, 4 * H, 4 * H, [ops.Level(0, 1, Tn, Tn * 4 * H)])
+        d = ops.fwd_desc(src, gv, E, 4 * H, 1, 1, 0, 1, wC=E)
+        wih, bih = dev(sd["lstm.weight_ih_l0" + suf]), dev(sd["lstm.bias_ih_l0" + suf])
+        whh, bhh = dev(sd["lstm.weight_hh_l0" + suf]), dev(sd["lstm.bias_hh_l0" + suf])
+        L.check(L.lib.zsg_conv_igemm(C.byref(d), xin.data_ptr(), wih.data_ptr(), gin.data_ptr(), bih.data_ptr(), None, None, st), "lstm_in")
+        gates, cst, hprev = (torch.zeros(B, Tn, 4 * H, device="cuda"), torch.zeros(B, Tn, H, device="cuda"), torch.zeros(B, Tn, H, device="cuda"))
+        h0d, c0d = dev(h0[di]), dev(c0[di])
+        L.check(L.lib.zsg_lstm_fwd(gin.data_ptr(), whh.data_ptr(), bhh.data_ptr(), h0d.data_ptr(), c0d.data_ptr(), ld.data_ptr(),
+                                   ld.data_ptr() if di == 0 else None, B, Tn, H, gates.data_ptr(), cst.data_ptr(), hprev.data_ptr(),
+                                   we.data_ptr(), 256, di * H, st), "lstm_fwd")
+        saved[suf] = (xin, src, gates, cst, hprev, whh, c0d, Tn)
+    assert_close(we, torch.from_numpy(gz["we"]), 1e-4, 1e-5, "lstm output")
+    gwd = dev(torch.from_numpy(gz["gw"]))
+    for di, suf in enumerate(["", "_reverse"]):
+        xin, src, gates, cst, hprev, whh, c0d, Tn = saved[suf]
+        dg = torch.full((B, Tn, 4 * H), float("nan"), device="cuda")
+        L.check(L.lib.zsg_lstm_bwd(gwd.data_ptr(), 256, di * H, whh.data_ptr(), gates.data_ptr(), cst.data_ptr(), c0d.data_ptr(), ld.data_ptr(),
+                                   ld.data_ptr() if di == 0 else None, B, Tn, H, dg.data_ptr(), st), "lstm_bwd")
+        dgv = ops.TView(dg.view(-1), B, 4 * H, 4 * H, [ops.Level(0, 1, Tn, Tn * 4 * H)])
+        dwih = torch.zeros(4 * H, E, device="cuda")
+        L.check(L.lib.zsg_conv_wgrad(C.byref(ops.fwd_desc(src, dgv, E, 4 * H, 1, 1, 0, 1, wC=E)), xin.data_ptr(), dg.data_ptr(), dwih.data_ptr(), st), "w_ih")
+        hp = ops.TView(hprev.view(-1), B, H, H, [ops.Level(0, 1, Tn, Tn * H)])
+        dwhh = torch.zeros(4 * H, H, device="cuda")
+        L.check(L.lib.zsg_conv_wgrad(C.byref(ops.fwd_desc(hp, dgv, H, 4 * H, 1, 1, 0, 1, wC=H)), hprev.data_ptr(), dg.data_ptr(), dwhh.data_ptr(), st), "w_hh")
+        db = torch.zeros(4 * H, device="cuda")
+        L.check(L.lib.zsg_colsum(dg.data_ptr(), 1, 0, B * Tn, 4 * H, 0, 4 * H, db.data_ptr(), 0, st), "bias")
+        tag = "l0" + suf
+        assert_close(dwih[::4, ::3], torch.from_numpy(gz["grad_weight_ih_" + tag]), 1e-3, 1e-5, "d w_ih" + suf)
+        assert_close(dwhh[::4, ::3], torch.from_numpy(gz["grad_weight_hh_" + tag]), 1e-3, 1e-5, "d w_hh" + suf)
+        assert_close(db, torch.from_numpy(gz["grad_bias_ih_" + tag]), 1e-3, 1e-5, "d b_ih" + suf)
+        assert_close(db, torch.from_numpy(gz["grad_bias_hh_" + tag]), 1e-3, 1e-5, "d b_hh" + suf)

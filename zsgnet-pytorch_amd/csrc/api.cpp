@@ -1,0 +1,86 @@
+// api.cpp — version / error plumbing and the optional per-launch HIP-event profiler of libzsg.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void zsg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int zsg_version(void) { return ZSG_VERSION; }
+extern "C" const char* zsg_last_error(void) { return g_err; }
+
+// ---- profiler ----------------------------------------------------------------------------------------------------
+int g_zsg_prof_on = 0;
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+static std::vector<ProfRec> g_recs;
+static std::mutex g_prof_mu;
+
+ZsgProfScope::ZsgProfScope(const char* name, hipStream_t s, double flops, double bytes) : slot(-1), st(s) {
+    if (!g_zsg_prof_on) return;
+    ProfRec r;
+    r.name = name;
+    r.flops = flops;
+    r.bytes = bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    slot = (int)g_recs.size();
+    g_recs.push_back(r);
+}
+ZsgProfScope::~ZsgProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEventRecord(g_recs[slot].b, st);
+}
+
+extern "C" int zsg_prof_enable(int32_t on) {
+    g_zsg_prof_on = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int zsg_prof_collect(zsg_prof_entry* out, int32_t max_entries) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, zsg_prof_entry> agg;
+    std::vector<std::string> order;
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        hipEventSynchronize(r.b);
+        hipEventElapsedTime(&ms, r.a, r.b);
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+        auto it = agg.find(r.name);
+        if (it == agg.end()) {
+            zsg_prof_entry e;
+            memset(&e, 0, sizeof(e));
+            strncpy(e.name, r.name, sizeof(e.name) - 1);
+            it = agg.insert({r.name, e}).first;
+            order.push_back(r.name);
+        }
+        it->second.launches += 1;
+        it->second.ms += ms;
+        it->second.flops += r.flops;
+        it->second.bytes += r.bytes;
+    }
+    g_recs.clear();
+    int n = 0;
+    for (auto& k : order) {
+        if (n >= max_entries) break;
+        out[n++] = agg[k];
+    }
+    return n;
+}

@@ -1,0 +1,233 @@
+// bn.hip — train-mode BatchNorm2d over NHWC [rows][C] (+ ReLU, + residual), forward and backward.  HBM-bound.
+// Each thread owns 4 consecutive channels (16-byte loads); a block spans up to 256 channels x a chunk of rows.
+// Statistics: per-chunk fp32 partial (sum, sum of squares) -> a finalize kernel merges them in fp64.
+#include "common.h"
+
+struct BnGeom {
+    int lanes;      // float4 lanes across channels inside a block (<= 64)
+    int rowlanes;   // 256 / lanes
+    int slabs;      // channel slabs of lanes*4
+    int rpb;        // rows per block
+    int chunks;     // row chunks
+};
+
+static BnGeom bn_geom(int64_t rows, int C) {
+    BnGeom g;
+    const int c4 = C / 4;
+    g.lanes = c4 >= 64 ? 64 : (c4 >= 32 ? 32 : (c4 >= 16 ? 16 : (c4 >= 8 ? 8 : (c4 >= 4 ? 4 : (c4 >= 2 ? 2 : 1)))));
+    g.rowlanes = 256 / g.lanes;
+    g.slabs = cdiv(c4, g.lanes);
+    int64_t rpb = (rows * g.slabs + 1023) / 1024;
+    if (rpb < 4 * g.rowlanes) rpb = 4 * g.rowlanes;
+    g.rpb = (int)rpb;
+    g.chunks = cdiv(rows, g.rpb);
+    return g;
+}
+
+extern "C" size_t zsg_bn_workspace_bytes(int64_t rows, int32_t C) {
+    BnGeom g = bn_geom(rows, C);
+    return ((size_t)g.chunks * 2 * C + 2 * (size_t)C) * sizeof(float);
+}
+
+// MODE 0: (sum x, sum x^2).  MODE 1: backward (sum g, sum g*xhat) with g = dout * (relu_out > 0).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                         const float* __restrict__ relu_out, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, int64_t rows, int C, int lanes,
+                                                         int rpb, float* __restrict__ part) {
+    __shared__ f32x4 red[2][256];
+    const int rowlanes = 256 / lanes;
+    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int c = (blockIdx.y * lanes + l) * 4;
+    const bool cok = c < C;
+    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    if (MODE == 1 && cok) {
+        mu = *(const f32x4*)(mean + c);
+        is = *(const f32x4*)(invstd + c);
+    }
+    if (cok) {
+        for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
+            const f32x4 v = *(const f32x4*)(x + r * C + c);
+            if (MODE == 0) {
+                s0 += v;
+                s1 += v * v;
+            } else {
+                f32x4 g = *(const f32x4*)(dout + r * C + c);
+                if (relu_out) {
+                    const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                }
+                s0 += g;
+                s1 += g * ((v - mu) * is);
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0 && cok) {
+        for (int k = 1; k < rowlanes; ++k) {
+            s0 += red[0][k * lanes + l];
+            s1 += red[1][k * lanes + l];
+        }
+        float* o = part + (size_t)blockIdx.x * 2 * C;
+        *(f32x4*)(o + c) = s0;
+        *(f32x4*)(o + C + c) = s1;
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows, float* mean,
+                                         float* invstd, float* rmean, float* rvar, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int k = 0; k < chunks; ++k) {
+        s += (double)part[(size_t)k * 2 * C + c];
+        ss += (double)part[(size_t)k * 2 * C + C + c];
+    }
+    const double n = (double)rows;
+    const double m = s / n;
+    double var = ss / n - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
+}
+
+__global__ void bn_eval_stats_kernel(const float* rmean, const float* rvar, int C, float eps, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t rows, int C, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ residual, int relu,
+                                                       float* __restrict__ out, int lanes, int rpb) {
+    const int rowlanes = 256 / lanes;
+    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int c = (blockIdx.y * lanes + l) * 4;
+    if (c >= C) return;
+    const f32x4 mu = *(const f32x4*)(mean + c);
+    const f32x4 sc = *(const f32x4*)(invstd + c) * *(const f32x4*)(gamma + c);
+    const f32x4 be = *(const f32x4*)(beta + c);
+    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
+    for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
+        f32x4 v = (*(const f32x4*)(x + r * C + c) - mu) * sc + be;
+        if (residual) v += *(const f32x4*)(residual + r * C + c);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(f32x4*)(out + r * C + c) = v;
+    }
+}
+
+// coef[0][c] = sum g / n ; coef[1][c] = sum g*xhat / n ; dgamma/dbeta written or accumulated.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows, float* coef,
+                                       float* dgamma, float* dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int k = 0; k < chunks; ++k) {
+        s += (double)part[(size_t)k * 2 * C + c];
+        ss += (double)part[(size_t)k * 2 * C + C + c];
+    }
+    coef[c] = (float)(s / (double)rows);
+    coef[C + c] = (float)(ss / (double)rows);
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ relu_out,
+                                                           const float* __restrict__ x, int64_t rows, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ coef,
+                                                           float* __restrict__ dx, float* __restrict__ g_out, int lanes, int rpb) {
+    const int rowlanes = 256 / lanes;
+    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int c = (blockIdx.y * lanes + l) * 4;
+    if (c >= C) return;
+    const f32x4 mu = *(const f32x4*)(mean + c);
+    const f32x4 is = *(const f32x4*)(invstd + c);
+    const f32x4 sc = is * *(const f32x4*)(gamma + c);
+    const f32x4 c1 = *(const f32x4*)(coef + c);
+    const f32x4 c2 = *(const f32x4*)(coef + C + c);
+    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
+    for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
+        f32x4 g = *(const f32x4*)(dout + r * C + c);
+        if (relu_out) {
+            const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 xh = (*(const f32x4*)(x + r * C + c) - mu) * is;
+        if (g_out) *(f32x4*)(g_out + r * C + c) = g;
+        *(f32x4*)(dx + r * C + c) = sc * (g - c1 - xh * c2);
+    }
+}
+
+extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* invstd, float* running_mean,
+                            float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(x && mean && invstd && ws && rows > 0 && C > 0 && (C % 4) == 0, "bn_stats: bad argument (C=%d rows=%lld)", C, (long long)rows);
+    if (ws_bytes < zsg_bn_workspace_bytes(rows, C)) ZSG_FAIL(-2, "bn_stats: workspace too small");
+    BnGeom g = bn_geom(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_stats", st, 0, (double)rows * C * 4);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
+                       rows, C, g.lanes, g.rpb, part);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, g.chunks, C, rows, mean, invstd,
+                       running_mean, running_var, momentum, eps);
+    ZSG_CHECK_LAUNCH("bn_stats");
+    return 0;
+}
+
+extern "C" int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
+                                 float* invstd, void* stream) {
+    ZSG_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "bn_eval_stats: bad argument");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean, running_var, C, eps,
+                       mean, invstd);
+    ZSG_CHECK_LAUNCH("bn_eval_stats");
+    return 0;
+}
+
+extern "C" int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* residual, int32_t relu, float* out, void* stream) {
+    ZSG_REQUIRE(x && mean && invstd && gamma && beta && out && rows > 0 && C > 0 && (C % 4) == 0, "bn_apply: bad argument");
+    BnGeom g = bn_geom(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_apply", st, 0, (double)rows * C * 4 * (residual ? 3 : 2));
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, mean, invstd, gamma, beta, residual,
+                       relu, out, g.lanes, g.rpb);
+    ZSG_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+
+extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const float* x, int64_t rows, int32_t C, const float* mean,
+                               const float* invstd, const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta,
+                               int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(dout && x && mean && invstd && gamma && dx && ws && rows > 0 && C > 0 && (C % 4) == 0, "bn_backward: bad argument");
+    if (ws_bytes < zsg_bn_workspace_bytes(rows, C)) ZSG_FAIL(-2, "bn_backward: workspace too small");
+    BnGeom g = bn_geom(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_backward", st, 0, (double)rows * C * 4 * ((relu_out ? 3 : 2) * 2 + 1 + (g_out ? 1 : 0)));
+    float* part = (float*)ws;
+    float* coef = part + (size_t)g.chunks * 2 * C;
+    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, mean, invstd, rows, C,
+                       g.lanes, g.rpb, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
+                       accumulate);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, x, rows, C, mean, invstd, gamma,
+                       coef, dx, g_out, g.lanes, g.rpb);
+    ZSG_CHECK_LAUNCH("bn_backward");
+    return 0;
+}

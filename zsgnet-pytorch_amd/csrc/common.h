@@ -1,0 +1,82 @@
+// common.h — shared host/device helpers for libzsg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "zsg.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ZSG_WAVE 64
+#define ZSG_NUM_CU 256
+#define ZSG_NUM_XCD 8
+
+// ---- error plumbing -------------------------------------------------------------------------------------------
+void zsg_set_error(const char* fmt, ...);
+#define ZSG_FAIL(code, ...)          \
+    do {                             \
+        zsg_set_error(__VA_ARGS__);  \
+        return (code);               \
+    } while (0)
+#define ZSG_REQUIRE(cond, ...)                   \
+    do {                                         \
+        if (!(cond)) ZSG_FAIL(-1, __VA_ARGS__);  \
+    } while (0)
+#define ZSG_CHECK_LAUNCH(name)                                                            \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) ZSG_FAIL(-3, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- per-launch profiling (prof.cpp) --------------------------------------------------------------------------
+struct ZsgProfScope {
+    int slot;
+    hipStream_t st;
+    ZsgProfScope(const char* name, hipStream_t s, double flops, double bytes);
+    ~ZsgProfScope();
+};
+extern int g_zsg_prof_on;
+#define ZSG_PROF(name, stream, flops, bytes) ZsgProfScope prof__(name, (hipStream_t)(stream), (flops), (bytes))
+
+// ---- device helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Raw buffer loads: the descriptor bounds-checks every lane (offset >= 2 GB window -> zeros, no fault), which is how
+// the gather kernels implement zero padding / tails without branches around their loads (guide T8/T20).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned byte_off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned byte_off) {
+    unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(float, v);
+}
+#define ZSG_OOB 0xFFFFFFF0u
+
+// XCD-aware, bijective remap of a linear block id: blocks that land on one XCD (id % 8) get a contiguous chunk of
+// the logical grid so that neighbouring tiles share that XCD's L2 (guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks / ZSG_NUM_XCD, r = nblocks % ZSG_NUM_XCD;
+    const int xcd = bid % ZSG_NUM_XCD, idx = bid / ZSG_NUM_XCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,319 @@
+// igemm.hip — implicit-GEMM convolution (forward and data-gradient) on fp32 MFMA, NHWC x OHWI, gfx950.
+//
+// GEMM view:  Out[row][n] = sum_{taps} sum_{c<C} Src[gather(row, tap)][c] * Wt[n][tap][c]
+//   rows  = (segment, b, y, x)      -> M   (pixels; A operand, channels contiguous)
+//   n     = output channel          -> N   (B operand = weight rows, channels contiguous)
+//   K     = taps x C, walked tap-major in BK=32 chunks.
+// Both operands are K-contiguous, so a tile row is staged with 16-byte loads and each lane reads its MFMA
+// fragments with ds_read_b128: lane (i = lane&31, h = lane>>5) reads k = kq*8 + 4h .. +3 of row i and feeds
+// value j to the j-th of four v_mfma_f32_32x32x2_f32 (k permuted identically for A and B, the sum is over all k).
+// LDS rows are padded to 36 floats (9 x 16 B: odd) so the b128 reads of 16 distinct rows are conflict-free.
+// Pipeline: global->registers for tile t+1 is issued before the MFMAs of tile t; registers->LDS after them into
+// the other buffer; one barrier per K-tile.
+#include "common.h"
+
+#define IG_BK 32
+#define IG_LDK 36
+
+struct IgSegDev {
+    int rows_y, rows_x, rows;   // rows = B*rows_y*rows_x
+    int tile0;                  // first M tile of the segment
+    int src_H, src_W, sy, sx;
+    int out_W, osy, osx, opy, opx;
+    int src_off, src_bstride, out_off, out_bstride;   // elements, < 2^31
+    zsg_taps ty, tx;
+};
+
+struct IgParams {
+    const float* src;
+    const float* wt;
+    float* out;
+    const float* bias;
+    const float* add_src;
+    const float* mask_src;
+    int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, relu, nseg;
+    int m_tiles, n_tiles;
+    IgSegDev seg[ZSG_MAX_SEG];
+};
+
+template <int BM, int BN, bool MERGE_X>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
+    constexpr int RA = BM / 32;          // A rows staged per thread
+    constexpr int RB = BN / 32;          // B rows staged per thread
+    constexpr int TM = BM / 64;          // 32x32 MFMA tiles per wave along M (waves 2x2)
+    constexpr int TN = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [2][BM][IG_LDK]
+    float* Bs = smem + 2 * BM * IG_LDK;                // [2][BN][IG_LDK]
+    int* rowout = (int*)(smem + 2 * (BM + BN) * IG_LDK);   // [BM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = tid & 7;               // 16-byte k-group staged by this thread
+    const int r0 = tid >> 3;             // first staged row
+
+    const int bid = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+    const int mt = bid / p.n_tiles, nt = bid % p.n_tiles;
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < ZSG_MAX_SEG; ++s)
+        if (s < p.nseg && mt >= p.seg[s].tile0) si = s;
+    const IgSegDev sg = p.seg[si];       // by value: keeps the geometry in SGPRs for the whole K loop
+    const int srcH = sg.src_H, srcW = sg.src_W, src_ld = p.src_ld, Cdim = p.C;
+    const int m0 = (mt - sg.tile0) * BM;
+    const int n0 = nt * BN;
+
+    // ---- per-row gather state (fixed for the whole K loop) --------------------------------------------------
+    int a_by[RA], a_bx[RA], a_off[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        const bool ok = m < sg.rows;
+        const int mm = ok ? m : 0;
+        const int per = sg.rows_y * sg.rows_x;
+        const int b = mm / per;
+        const int rem = mm - b * per;
+        const int y = rem / sg.rows_x;
+        const int x = rem - y * sg.rows_x;
+        a_by[j] = ok ? (y * sg.sy + sg.ty.d0) : -(1 << 28);      // invalid rows fail the bounds test for every tap
+        a_bx[j] = x * sg.sx + sg.tx.d0;
+        a_off[j] = sg.src_off + b * sg.src_bstride;
+        if (g == 0)
+            rowout[r0 + 32 * j] =
+                ok ? sg.out_off + b * sg.out_bstride + ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld
+                   : -1;
+    }
+    int b_off[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        b_off[j] = (n < p.N) ? n * p.wt_ld + p.wc0 : -1;
+    }
+
+    const int n_cc = MERGE_X ? 1 : (p.C + IG_BK - 1) / IG_BK;
+    const int n_jx = MERGE_X ? 1 : sg.tx.n;
+    const int n_it = sg.ty.n * n_jx * n_cc;
+
+    f32x4 ra[RA], rb[RB];
+    const rsrc_t rsrc_a = make_rsrc(p.src);
+    const rsrc_t rsrc_b = make_rsrc(p.wt);
+    int jy = 0, jx = 0, cc = 0;          // K-iteration counters of the NEXT tile to load (wave-uniform)
+
+    auto load_tile = [&]() {
+        const int wr = sg.ty.w0 + jy * sg.ty.wstep;
+        const int dyy = jy * sg.ty.dstep;
+        int ws_, dxx, koff;
+        bool kok;
+        if (MERGE_X) {                    // C == 4: the tx.n taps of this row are one contiguous run
+            ws_ = sg.tx.w0;
+            dxx = g;
+            koff = 4 * g;
+            kok = g < sg.tx.n;
+        } else {
+            ws_ = sg.tx.w0 + jx * sg.tx.wstep;
+            dxx = jx * sg.tx.dstep;
+            koff = cc * IG_BK + 4 * g;
+            kok = koff < Cdim;
+        }
+        const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int yy = a_by[j] + dyy, xx = a_bx[j] + dxx;
+            // branch-free validity (bitwise &): out-of-image taps / dead rows / channel tail get an out-of-range
+            // buffer offset, for which the hardware returns zeros
+            const bool ok = kok & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
+            const unsigned off = 4u * (unsigned)(a_off[j] + (yy * srcW + xx) * src_ld + (MERGE_X ? 0 : koff));
+            ra[j] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const bool ok = kok & (b_off[j] >= 0);
+            rb[j] = buf_load4(rsrc_b, ok ? 4u * (unsigned)(b_off[j] + wtap) : ZSG_OOB);
+        }
+        // advance counters
+        if (++cc == n_cc) {
+            cc = 0;
+            if (++jx == n_jx) {
+                jx = 0;
+                ++jy;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * IG_LDK;
+        float* b = Bs + buf * BN * IG_LDK;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) *(f32x4*)(a + (r0 + 32 * j) * IG_LDK + 4 * g) = ra[j];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) *(f32x4*)(b + (r0 + 32 * j) * IG_LDK + 4 * g) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_row = wm * (BM / 2) + li;
+    const int b_row = wn * (BN / 2) + li;
+
+    for (int it = 0; it < n_it; ++it) {
+        const bool more = (it + 1) < n_it;
+        if (more) load_tile();
+        const float* a = As + (it & 1) * BM * IG_LDK + a_row * IG_LDK + 4 * lh;
+        const float* b = Bs + (it & 1) * BN * IG_LDK + b_row * IG_LDK + 4 * lh;
+#pragma unroll
+        for (int kq = 0; kq < IG_BK / 8; ++kq) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * IG_LDK + kq * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * IG_LDK + kq * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile((it + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual add, relu, relu-mask ---------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + li;
+        const bool nok = n < p.N;
+        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int ro = rowout[row];
+                if (ro >= 0 && nok) {
+                    float v = acc[i][j][e] + bv;
+                    const size_t o = (size_t)ro + n;
+                    if (p.add_src) v += p.add_src[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+
+static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, double* flops) {
+    ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv: nseg=%d", d->nseg);
+    ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0 &&
+                    (d->wt_ld % 4) == 0,
+                "conv: C=%d src_ld=%d wC=%d wc0=%d wt_ld=%d must be multiples of 4", d->C, d->src_ld, d->wC, d->wc0, d->wt_ld);
+    ZSG_REQUIRE(d->N > 0 && d->B > 0, "conv: N=%d B=%d", d->N, d->B);
+    p.C = d->C; p.N = d->N; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.wS = d->wS; p.wC = d->wC; p.wc0 = d->wc0;
+    p.wt_ld = d->wt_ld; p.relu = d->relu; p.nseg = d->nseg;
+    int tiles = 0;
+    double fl = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const zsg_seg& a = d->seg[s];
+        IgSegDev& o = p.seg[s];
+        const int64_t rows = (int64_t)d->B * a.rows_y * a.rows_x;
+        ZSG_REQUIRE(rows > 0 && rows < (1ll << 30), "conv: seg %d rows=%lld", s, (long long)rows);
+        const int64_t src_hi = a.src_off + (int64_t)d->B * a.src_bstride;
+        const int64_t out_hi = a.out_off + (int64_t)d->B * a.out_bstride;
+        ZSG_REQUIRE(src_hi < (1ll << 29) && out_hi < (1ll << 29), "conv: tensor exceeds 2^29 elements (2 GB window)");
+        ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0, "conv: seg %d source not 16-byte aligned", s);
+        if (d->merge_x)
+            ZSG_REQUIRE(d->C == 4 && d->src_ld == 4 && a.tx.n <= 8 && a.tx.dstep == 1 && a.tx.wstep == 1 && d->wC == 4,
+                        "conv: merge_x needs C=4, unit x taps, <= 8 taps");
+        o.rows_y = a.rows_y; o.rows_x = a.rows_x; o.rows = (int)rows; o.tile0 = tiles;
+        o.src_H = a.src_H; o.src_W = a.src_W; o.sy = a.sy; o.sx = a.sx;
+        o.out_W = a.out_W; o.osy = a.osy; o.osx = a.osx; o.opy = a.opy; o.opx = a.opx;
+        o.src_off = (int)a.src_off; o.src_bstride = (int)a.src_bstride;
+        o.out_off = (int)a.out_off; o.out_bstride = (int)a.out_bstride;
+        o.ty = a.ty; o.tx = a.tx;
+        tiles += cdiv(rows, BM);
+        fl += 2.0 * rows * d->N * (double)a.ty.n * a.tx.n * d->C;
+    }
+    p.m_tiles = tiles;
+    p.n_tiles = cdiv(d->N, BN);
+    if (flops) *flops = fl;
+    return 0;
+}
+
+template <int BM, int BN, bool MX>
+static int launch_cfg(const IgParams& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * (BM + BN) * IG_LDK * sizeof(float) + BM * sizeof(int);
+    static bool attr_done = false;      // idempotent; a benign race sets it twice
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, MX>), dim3(p.m_tiles * p.n_tiles), dim3(256), lds, st, p);
+    ZSG_CHECK_LAUNCH("igemm");
+    return 0;
+}
+
+// cost model: blocks are issued in rounds of one per CU; small tiles pay more operand traffic per MFMA.
+static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN) {
+    if (d->tile_hint) {
+        *BM = d->tile_hint >> 16;
+        *BN = d->tile_hint & 0xffff;
+        return;
+    }
+    static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const double eff[3] = {1.0, 0.93, 0.86};
+    double best = 1e300;
+    for (int c = 0; c < 3; ++c) {
+        const int bm = cand[c][0], bn = cand[c][1];
+        if (bn == 128 && d->N <= 64) continue;
+        int64_t tiles = 0;
+        for (int s = 0; s < d->nseg; ++s) tiles += cdiv((int64_t)d->B * d->seg[s].rows_y * d->seg[s].rows_x, bm);
+        const int64_t blocks = tiles * cdiv(d->N, bn);
+        const double cost = (double)cdiv(blocks, ZSG_NUM_CU) * bm * bn / eff[c];
+        if (cost < best) {
+            best = cost;
+            *BM = bm;
+            *BN = bn;
+        }
+    }
+}
+
+extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
+                              const float* add_src, const float* mask_src, void* stream) {
+    ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
+    int BM = 128, BN = 128;
+    pick_tile(d, &BM, &BN);
+    IgParams p;
+    memset(&p, 0, sizeof(p));
+    double flops = 0;
+    int rc = fill_params(d, p, BM, BN, &flops);
+    if (rc) return rc;
+    p.src = src; p.wt = wt; p.out = out; p.bias = bias; p.add_src = add_src; p.mask_src = mask_src;
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("conv_igemm", st, flops, 0);
+    if (d->merge_x) {
+        if (BM == 128 && BN == 64) return launch_cfg<128, 64, true>(p, st);
+        if (BM == 64 && BN == 64) return launch_cfg<64, 64, true>(p, st);
+        // merge_x layers have N <= 64 in every supported model; fall back to the narrow tile
+        fill_params(d, p, 128, 64, nullptr);
+        return launch_cfg<128, 64, true>(p, st);
+    }
+    if (BM == 128 && BN == 128) return launch_cfg<128, 128, false>(p, st);
+    if (BM == 128 && BN == 64) return launch_cfg<128, 64, false>(p, st);
+    if (BM == 64 && BN == 64) return launch_cfg<64, 64, false>(p, st);
+    ZSG_FAIL(-1, "conv_igemm: unsupported tile %dx%d", BM, BN);
+}

@@ -1,0 +1,311 @@
+// loss.hip — anchor matching + focal / smooth-L1 loss (forward AND backward in one call) and the evaluator.
+// Index contract: IoU is evaluated with the reference's exact fp32 operation order (no FMA contraction, IEEE divide),
+// arg-max ties go to the lowest anchor index, so match indices / positive masks are bit-exact against the oracle.
+// Reductions: per-thread fp32 -> wavefront shuffle -> LDS across waves, accumulated in fp64.
+#include "common.h"
+#pragma clang fp contract(off)
+
+#define LS_THREADS 512
+
+__device__ __forceinline__ float iou_exact(const f32x4 b, const f32x4 a) {   // b = first argument ("anchors" of IoU_values)
+    const float tly = fmaxf(b[0], a[0]), tlx = fmaxf(b[1], a[1]);
+    const float bry = fminf(b[2], a[2]), brx = fminf(b[3], a[3]);
+    const float sy = fmaxf(bry - tly, 0.f), sx = fmaxf(brx - tlx, 0.f);
+    const float inter = sy * sx;
+    const float barea = (b[2] - b[0]) * (b[3] - b[1]);
+    const float aarea = (a[2] - a[0]) * (a[3] - a[1]);
+    const float uni = (barea + aarea) - inter;
+    return inter / (uni + 1e-8f);
+}
+
+__device__ __forceinline__ float focal_pow(float x, float gamma) {   // torch.pow(x, 2) is x*x exactly (loss.py:117)
+    return gamma == 2.f ? x * x : (gamma == 1.f ? x : powf(x, gamma));
+}
+
+struct ArgMax {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ArgMax argmax_merge(ArgMax x, ArgMax y) {   // larger value, then lower index; NaN never wins
+    const bool take = (y.v > x.v) || (y.v == x.v && y.i < x.i);
+    return take ? y : x;
+}
+__device__ ArgMax block_argmax(ArgMax m, ArgMax* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax y;
+        y.v = __shfl_xor(m.v, o, 64);
+        y.i = __shfl_xor(m.i, o, 64);
+        m = argmax_merge(m, y);
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wave] = m;
+    __syncthreads();
+    ArgMax r = sm[0];
+    for (int w = 1; w < nw; ++w) r = argmax_merge(r, sm[w]);
+    __syncthreads();
+    return r;
+}
+__device__ double block_sum_d(double v, double* sm) {
+    v = wave_sum_d(v);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wave] = v;
+    __syncthreads();
+    double r = 0;
+    for (int w = 0; w < nw; ++w) r += sm[w];
+    __syncthreads();
+    return r;
+}
+
+// smooth-L1 (beta = 1) of (reg - target(anchor, box)); returns the 4-sum and the four derivatives.
+__device__ __forceinline__ float box_terms(const float* __restrict__ o5, const f32x4 an, const f32x4 bx, float d[4]) {
+    const float acy = (an[0] + an[2]) / 2.f, acx = (an[1] + an[3]) / 2.f;
+    const float ah = an[2] - an[0], aw = an[3] - an[1];
+    const float bcy = (bx[0] + bx[2]) / 2.f, bcx = (bx[1] + bx[3]) / 2.f;
+    const float bh = bx[2] - bx[0], bw = bx[3] - bx[1];
+    const float dh = ah + 1e-8f, dw = aw + 1e-8f;
+    float gt[4];
+    gt[0] = (bcy - acy) / dh;
+    gt[1] = (bcx - acx) / dw;
+    gt[2] = logf(bh / dh);
+    gt[3] = logf(bw / dw);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float df = o5[k] - gt[k];
+        const float ad = fabsf(df);
+        s += ad < 1.f ? 0.5f * df * df : ad - 0.5f;
+        d[k] = ad < 1.f ? df : (df > 0.f ? 1.f : (df < 0.f ? -1.f : df));
+    }
+    return s;
+}
+
+struct LossWs {          // per-sample records in the workspace (doubles first for alignment)
+    double box_sum, cls_sum, row_max, row_lse;
+    int best, npos, pad0, pad1;
+};
+
+// pass 1: one block per sample — arg-max IoU, positive count, loss sums.
+__global__ __launch_bounds__(LS_THREADS) void loss_stats_kernel(const float* __restrict__ out5, const float* __restrict__ annot,
+                                                                const float* __restrict__ anchors, int A, float alpha, float gamma,
+                                                                float thr, int flags, LossWs* __restrict__ ws) {
+    __shared__ ArgMax sm_a[LS_THREADS / 64];
+    __shared__ double sm_d[LS_THREADS / 64];
+    const int b = blockIdx.x;
+    const bool use_focal = flags & 1, use_multi = flags & 2, use_softmax = flags & 4;
+    const f32x4 bx = *(const f32x4*)(annot + 4 * b);
+    const float* o = out5 + (size_t)b * A * 5;
+
+    ArgMax m = {-INFINITY, 0x7fffffff};
+    for (int a = threadIdx.x; a < A; a += LS_THREADS) {
+        const float v = iou_exact(bx, *(const f32x4*)(anchors + 4 * a));
+        if (v > m.v) { m.v = v; m.i = a; }
+    }
+    m = block_argmax(m, sm_a);
+    const int best = m.i == 0x7fffffff ? 0 : m.i;     // all-NaN row: torch returns the first NaN's index; degenerate
+
+    double row_max = 0, row_lse = 0;
+    if (use_softmax) {
+        float mx = -INFINITY;
+        for (int a = threadIdx.x; a < A; a += LS_THREADS) mx = fmaxf(mx, o[a * 5 + 4]);
+        ArgMax t = {mx, 0};
+        t = block_argmax(t, sm_a);
+        double se = 0;
+        for (int a = threadIdx.x; a < A; a += LS_THREADS) se += exp((double)o[a * 5 + 4] - (double)t.v);
+        se = block_sum_d(se, sm_d);
+        row_max = t.v;
+        row_lse = (double)t.v + log(se);
+    }
+
+    double box = 0, cls = 0;
+    int cnt = 0;
+    for (int a = threadIdx.x; a < A; a += LS_THREADS) {
+        const f32x4 an = *(const f32x4*)(anchors + 4 * a);
+        const float v = iou_exact(bx, an);
+        const bool pos = (use_multi && v > thr) || a == best;
+        const float t = pos ? 1.f : 0.f;
+        cnt += pos;
+        float d[4];
+        const float s = box_terms(o + a * 5, an, bx, d);
+        box += (double)(s * t);                         // multiply (not select): inf * 0 = NaN, as the reference
+        const float x = o[a * 5 + 4];
+        if (!use_softmax) {
+            const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            float w = 1.f;
+            if (use_focal) {
+                const float p = 1.0f / (1.0f + expf(-x));
+                w = focal_pow(t * (1.f - p) + (1.f - t) * p, gamma) * ((1.f - t) * alpha + t * (1.f - alpha));
+            }
+            cls += (double)(w * bce);
+        }
+    }
+    box = block_sum_d(box, sm_d);
+    cls = block_sum_d(cls, sm_d);
+    const int npos = (int)(block_sum_d((double)cnt, sm_d) + 0.5);
+    if (threadIdx.x == 0) {
+        if (use_softmax) cls = row_lse - (double)o[best * 5 + 4];
+        LossWs r;
+        r.box_sum = box; r.cls_sum = cls; r.row_max = row_max; r.row_lse = row_lse; r.best = best; r.npos = npos; r.pad0 = r.pad1 = 0;
+        ws[b] = r;
+    }
+}
+
+// pass 2: totals (every block recomputes them from the B records), loss scalars, gradients.
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ out5, const float* __restrict__ annot,
+                                                        const float* __restrict__ anchors, int B, int A, float alpha, float gamma,
+                                                        float lamb, float thr, int flags, float grad_scale,
+                                                        const LossWs* __restrict__ ws, float* __restrict__ losses,
+                                                        float* __restrict__ grad5, int* __restrict__ match_idx, int* __restrict__ npos_out) {
+    const bool use_focal = flags & 1, use_multi = flags & 2, use_softmax = flags & 4;
+    const int b = blockIdx.y;
+    double box = 0, cls = 0;
+    long long npos_all = 0;
+    for (int k = 0; k < B; ++k) {
+        box += ws[k].box_sum / (double)ws[k].npos;
+        cls += ws[k].cls_sum;
+        npos_all += ws[k].npos;
+    }
+    box /= (double)B;
+    cls /= (double)npos_all;
+    const bool bad = (box != box) || (cls != cls);       // loss.py:128-133: constants, no gradient reaches the network
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+        const double bl = bad ? 0.01 : box, cl = bad ? 1.0 : cls;
+        losses[0] = (float)(lamb * bl + cl);
+        losses[1] = (float)cl;
+        losses[2] = (float)bl;
+    }
+    const LossWs me = ws[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        match_idx[b] = me.best;
+        if (npos_out) npos_out[b] = me.npos;
+    }
+    if (!grad5) return;
+    const f32x4 bx = *(const f32x4*)(annot + 4 * b);
+    const float* o = out5 + (size_t)b * A * 5;
+    float* g = grad5 + (size_t)b * A * 5;
+    const float kbox = bad ? 0.f : grad_scale * lamb / ((float)B * (float)me.npos);
+    const float kcls = bad ? 0.f : grad_scale / (float)npos_all;
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
+        const f32x4 an = *(const f32x4*)(anchors + 4 * a);
+        const float v = iou_exact(bx, an);
+        const bool pos = (use_multi && v > thr) || a == me.best;
+        const float t = pos ? 1.f : 0.f;
+        float d[4];
+        box_terms(o + a * 5, an, bx, d);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[a * 5 + k] = pos ? kbox * d[k] : 0.f;
+        const float x = o[a * 5 + 4];
+        float ga;
+        if (use_softmax) {
+            ga = (float)exp((double)x - me.row_lse) - (a == me.best ? 1.f : 0.f);
+        } else {
+            const float p = 1.0f / (1.0f + expf(-x));
+            float w = 1.f;
+            if (use_focal) w = focal_pow(t * (1.f - p) + (1.f - t) * p, gamma) * ((1.f - t) * alpha + t * (1.f - alpha));
+            ga = w * (p - t);
+        }
+        g[a * 5 + 4] = kcls * ga;
+    }
+}
+
+extern "C" size_t zsg_loss_workspace_bytes(int32_t B, int32_t A) {
+    (void)A;
+    return (size_t)B * sizeof(LossWs);
+}
+
+extern "C" int zsg_loss_fwd_bwd(const float* out5, const float* annot, const float* anchors, int32_t B, int32_t A, float alpha, float gamma,
+                                float lamb_reg, float match_thr, int32_t flags, float grad_scale, float* losses, float* grad5,
+                                int32_t* match_idx, int32_t* npos, void* ws, size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(out5 && annot && anchors && losses && match_idx && ws && B > 0 && A > 0, "loss_fwd_bwd: bad argument");
+    ZSG_REQUIRE(!((flags & 4) && (flags & 2)), "loss_fwd_bwd: use_softmax requires use_multi == False (loss.py:107)");
+    if (ws_bytes < zsg_loss_workspace_bytes(B, A)) ZSG_FAIL(-2, "loss_fwd_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("loss_fwd_bwd", st, 0, (double)B * A * 5 * 4 * 3);
+    hipLaunchKernelGGL(loss_stats_kernel, dim3(B), dim3(LS_THREADS), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags, (LossWs*)ws);
+    const int chunks = min(32, cdiv(A, 256));
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks, B), dim3(256), 0, st, out5, annot, anchors, B, A, alpha, gamma, lamb_reg, match_thr,
+                       flags, grad_scale, (const LossWs*)ws, losses, grad5, match_idx, npos);
+    ZSG_CHECK_LAUNCH("loss_fwd_bwd");
+    return 0;
+}
+
+// ---- evaluator ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 decode_box(const f32x4 an, const float* __restrict__ r) {   // anchors.py:182-197
+    const float acy = (an[0] + an[2]) / 2.f, acx = (an[1] + an[3]) / 2.f;
+    const float ah = an[2] - an[0], aw = an[3] - an[1];
+    const float cy = ah * r[0] + acy, cx = aw * r[1] + acx;
+    const float h = expf(r[2]) * ah, w = expf(r[3]) * aw;
+    f32x4 o = {cy - h / 2.f, cx - w / 2.f, cy + h / 2.f, cx + w / 2.f};
+    return o;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void eval_kernel(const float* __restrict__ out5, const float* __restrict__ annot,
+                                                          const float* __restrict__ anchors, const float* __restrict__ img_size, int A,
+                                                          float acc_thr, float* __restrict__ ok2, float* __restrict__ pred_boxes,
+                                                          float* __restrict__ pred_scores, int* __restrict__ pred_idx,
+                                                          int* __restrict__ best_idx) {
+    __shared__ ArgMax sm_a[LS_THREADS / 64];
+    const int b = blockIdx.x;
+    const f32x4 bx = *(const f32x4*)(annot + 4 * b);
+    const float* o = out5 + (size_t)b * A * 5;
+    ArgMax ms = {-INFINITY, 0x7fffffff}, mi = {-INFINITY, 0x7fffffff};
+    for (int a = threadIdx.x; a < A; a += LS_THREADS) {
+        const float p = 1.0f / (1.0f + expf(-o[a * 5 + 4]));          // arg-max over sigmoid scores, evaluator.py:74-75
+        if (p > ms.v) { ms.v = p; ms.i = a; }
+        const float v = iou_exact(bx, *(const f32x4*)(anchors + 4 * a));
+        if (v > mi.v) { mi.v = v; mi.i = a; }
+    }
+    ms = block_argmax(ms, sm_a);
+    mi = block_argmax(mi, sm_a);
+    if (threadIdx.x == 0) {
+        const int ps = ms.i == 0x7fffffff ? 0 : ms.i, pb = mi.i == 0x7fffffff ? 0 : mi.i;
+        const f32x4 box_s = decode_box(*(const f32x4*)(anchors + 4 * ps), o + ps * 5);
+        const f32x4 box_b = decode_box(*(const f32x4*)(anchors + 4 * pb), o + pb * 5);
+        ok2[2 * b] = iou_exact(box_s, bx) >= acc_thr ? 1.f : 0.f;
+        ok2[2 * b + 1] = iou_exact(box_b, bx) >= acc_thr ? 1.f : 0.f;
+        const float hh = img_size[2 * b], ww = img_size[2 * b + 1];
+        // (box+1)/2 * (h,w) then y1x1y2x2 -> x1y1x2y2  (evaluator.py:96-98, reshape :10-17)
+        pred_boxes[4 * b + 0] = ww * ((box_s[1] + 1.f) / 2.f);
+        pred_boxes[4 * b + 1] = hh * ((box_s[0] + 1.f) / 2.f);
+        pred_boxes[4 * b + 2] = ww * ((box_s[3] + 1.f) / 2.f);
+        pred_boxes[4 * b + 3] = hh * ((box_s[2] + 1.f) / 2.f);
+        pred_scores[b] = ms.v;
+        if (pred_idx) pred_idx[b] = ps;
+        if (best_idx) best_idx[b] = pb;
+    }
+}
+__global__ void eval_mean_kernel(const float* __restrict__ ok2, int B, float* __restrict__ metrics) {
+    if (threadIdx.x < 2) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += ok2[2 * b + threadIdx.x];
+        metrics[threadIdx.x] = s / (float)B;
+    }
+}
+
+extern "C" int zsg_eval(const float* out5, const float* annot, const float* anchors, const float* img_size, int32_t B, int32_t A,
+                        float acc_thr, float* metrics, float* pred_boxes, float* pred_scores, int32_t* pred_idx, int32_t* best_idx,
+                        float* ws_ok, void* stream) {
+    ZSG_REQUIRE(out5 && annot && anchors && img_size && metrics && pred_boxes && pred_scores && ws_ok && B > 0 && A > 0, "eval: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("eval", st, 0, (double)B * A * 5 * 4);
+    hipLaunchKernelGGL(eval_kernel, dim3(B), dim3(LS_THREADS), 0, st, out5, annot, anchors, img_size, A, acc_thr, ws_ok, pred_boxes,
+                       pred_scores, pred_idx, best_idx);
+    hipLaunchKernelGGL(eval_mean_kernel, dim3(1), dim3(64), 0, st, ws_ok, B, metrics);
+    ZSG_CHECK_LAUNCH("eval");
+    return 0;
+}
+
+__global__ void iou_kernel(const float* __restrict__ boxes, const float* __restrict__ anchors, int B, int A, float* __restrict__ iou) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * A) return;
+    const int b = (int)(i / A), a = (int)(i % A);
+    iou[i] = iou_exact(*(const f32x4*)(boxes + 4 * b), *(const f32x4*)(anchors + 4 * a));
+}
+extern "C" int zsg_iou(const float* boxes, const float* anchors, int32_t B, int32_t A, float* iou, void* stream) {
+    ZSG_REQUIRE(boxes && anchors && iou && B > 0 && A > 0, "iou: bad argument");
+    hipLaunchKernelGGL(iou_kernel, dim3(cdiv((int64_t)B * A, 256)), dim3(256), 0, (hipStream_t)stream, boxes, anchors, B, A, iou);
+    ZSG_CHECK_LAUNCH("iou");
+    return 0;
+}

@@ -1,0 +1,428 @@
+// misc.hip — HBM-bound NHWC kernels around the convolutions: pooling, nearest-upsample+add, ReLU, average pool,
+// channel L2-norm, image layout conversion, language/grid fusion, weight transposes, column sums.
+// All of them move 16 bytes per lane with channel-contiguous (coalesced) accesses.
+#include "common.h"
+
+static inline int grid_for(int64_t n_items, int block = 256, int cap = ZSG_NUM_CU * 16) {
+    int64_t b = (n_items + block - 1) / block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+// ---- max pool -------------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C4, int k, int s, int p, int Ho, int Wo,
+                                   float* __restrict__ out, uint8_t* __restrict__ idx) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * s - p + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wi = wo * s - p + q;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *(const f32x4*)(x + (((int64_t)b * H + hi) * W + wi) * C4 * 4 + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) {      // first maximum wins; NaN propagates (torch rule)
+                        best[e] = v[e];
+                        bi[e] = r * k + q;
+                    }
+            }
+        }
+        *(f32x4*)(out + i * 4) = best;
+        if (idx) {
+            uchar4 u = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+            *(uchar4*)(idx + i * 4) = u;
+        }
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx, int B, int H, int W, int C4, int k,
+                                   int s, int p, int Ho, int Wo, float* __restrict__ dx) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int wi = (int)(t % W);
+        t /= W;
+        const int hi = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 acc = {0, 0, 0, 0};
+        // windows (ho, r) with ho*s - p + r == hi
+        for (int r = 0; r < k; ++r) {
+            const int hn = hi + p - r;
+            if (hn < 0 || (hn % s) != 0) continue;
+            const int ho = hn / s;
+            if (ho >= Ho) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wn = wi + p - q;
+                if (wn < 0 || (wn % s) != 0) continue;
+                const int wo = wn / s;
+                if (wo >= Wo) continue;
+                const int64_t o = ((((int64_t)b * Ho + ho) * Wo + wo) * C4 + c4) * 4;
+                const uchar4 u = *(const uchar4*)(idx + o);
+                const f32x4 g = *(const f32x4*)(dout + o);
+                const int code = r * k + q;
+                acc[0] += (u.x == code) ? g[0] : 0.f;
+                acc[1] += (u.y == code) ? g[1] : 0.f;
+                acc[2] += (u.z == code) ? g[2] : 0.f;
+                acc[3] += (u.w == code) ? g[3] : 0.f;
+            }
+        }
+        *(f32x4*)(dx + i * 4) = acc;
+    }
+}
+
+extern "C" int zsg_maxpool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, int32_t Ho,
+                               int32_t Wo, float* out, uint8_t* idx, void* stream) {
+    ZSG_REQUIRE(x && out && (C % 4) == 0 && k > 0 && k <= 15 && s > 0, "maxpool_fwd: bad argument");
+    const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("maxpool_fwd", st, 0, ((double)B * H * W + (double)B * Ho * Wo * 1.25) * C * 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, B, H, W, C / 4, k, s, p, Ho, Wo, out, idx);
+    ZSG_CHECK_LAUNCH("maxpool_fwd");
+    return 0;
+}
+
+extern "C" int zsg_maxpool_bwd(const float* dout, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
+                               int32_t p, int32_t Ho, int32_t Wo, float* dx, void* stream) {
+    ZSG_REQUIRE(dout && idx && dx && (C % 4) == 0 && k > 0 && s > 0, "maxpool_bwd: bad argument");
+    const int64_t n = (int64_t)B * H * W * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("maxpool_bwd", st, 0, ((double)B * H * W + (double)B * Ho * Wo * 1.25) * C * 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dout, idx, B, H, W, C / 4, k, s, p, Ho, Wo, dx);
+    ZSG_CHECK_LAUNCH("maxpool_bwd");
+    return 0;
+}
+
+// ---- nearest upsample + add (F.interpolate(size=...), legacy 'nearest': src = floor(dst * in/out)) -------------
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    const int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+__global__ void upsample_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ p, int B, int Hs, int Ws, int Hd, int Wd,
+                                        int C4, float sh, float sw, float* __restrict__ out) {
+    const int64_t total = (int64_t)B * Hd * Wd * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int x = (int)(t % Wd);
+        t /= Wd;
+        const int y = (int)(t % Hd);
+        const int b = (int)(t / Hd);
+        const int ys = nearest_src(y, sh, Hs), xs = nearest_src(x, sw, Ws);
+        const f32x4 u = *(const f32x4*)(p + ((((int64_t)b * Hs + ys) * Ws + xs) * C4 + c4) * 4);
+        *(f32x4*)(out + i * 4) = *(const f32x4*)(a + i * 4) + u;
+    }
+}
+
+__global__ void upsample_add_bwd_kernel(const float* __restrict__ dout, int B, int Hs, int Ws, int Hd, int Wd, int C4, float sh, float sw,
+                                        float* __restrict__ dp, int accumulate) {
+    const int64_t total = (int64_t)B * Hs * Ws * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int xs = (int)(t % Ws);
+        t /= Ws;
+        const int ys = (int)(t % Hs);
+        const int b = (int)(t / Hs);
+        f32x4 acc = {0, 0, 0, 0};
+        // destination pixels whose nearest source is (ys, xs): scan the small candidate range
+        const int y_lo = max(0, (int)floorf((float)ys / sh) - 1), y_hi = min(Hd - 1, (int)ceilf((float)(ys + 1) / sh) + 1);
+        const int x_lo = max(0, (int)floorf((float)xs / sw) - 1), x_hi = min(Wd - 1, (int)ceilf((float)(xs + 1) / sw) + 1);
+        for (int y = y_lo; y <= y_hi; ++y) {
+            if (nearest_src(y, sh, Hs) != ys) continue;
+            for (int x = x_lo; x <= x_hi; ++x) {
+                if (nearest_src(x, sw, Ws) != xs) continue;
+                acc += *(const f32x4*)(dout + ((((int64_t)b * Hd + y) * Wd + x) * C4 + c4) * 4);
+            }
+        }
+        if (accumulate) acc += *(const f32x4*)(dp + i * 4);
+        *(f32x4*)(dp + i * 4) = acc;
+    }
+}
+
+extern "C" int zsg_upsample_add_fwd(const float* a, const float* p, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd, int32_t C,
+                                    float* out, void* stream) {
+    ZSG_REQUIRE(a && p && out && (C % 4) == 0, "upsample_add_fwd: bad argument");
+    const int64_t n = (int64_t)B * Hd * Wd * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("upsample_add_fwd", st, 0, (double)n * 16 * 2.25);
+    hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, p, B, Hs, Ws, Hd, Wd, C / 4,
+                       (float)Hs / (float)Hd, (float)Ws / (float)Wd, out);
+    ZSG_CHECK_LAUNCH("upsample_add_fwd");
+    return 0;
+}
+
+extern "C" int zsg_upsample_add_bwd(const float* dout, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd, int32_t C, float* dp,
+                                    int32_t accumulate, void* stream) {
+    ZSG_REQUIRE(dout && dp && (C % 4) == 0, "upsample_add_bwd: bad argument");
+    const int64_t n = (int64_t)B * Hs * Ws * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("upsample_add_bwd", st, 0, (double)B * Hd * Wd * C * 4 * 1.25);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dout, B, Hs, Ws, Hd, Wd, C / 4,
+                       (float)Hs / (float)Hd, (float)Ws / (float)Wd, dp, accumulate);
+    ZSG_CHECK_LAUNCH("upsample_add_bwd");
+    return 0;
+}
+
+// ---- relu ------------------------------------------------------------------------------------------------------
+__global__ void relu_fwd_kernel(const float* __restrict__ x, int64_t n4, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = *(const f32x4*)(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int64_t n4, float* __restrict__ dx, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        f32x4 g = *(const f32x4*)(dout + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
+        if (accumulate) g += *(const f32x4*)(dx + i * 4);
+        *(f32x4*)(dx + i * 4) = g;
+    }
+}
+extern "C" int zsg_relu_fwd(const float* x, int64_t n, float* out, void* stream) {
+    ZSG_REQUIRE(x && out && (n % 4) == 0, "relu_fwd: bad argument");
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, out);
+    ZSG_CHECK_LAUNCH("relu_fwd");
+    return 0;
+}
+extern "C" int zsg_relu_bwd(const float* dout, const float* x, int64_t n, float* dx, int32_t accumulate, void* stream) {
+    ZSG_REQUIRE(dout && x && dx && (n % 4) == 0, "relu_bwd: bad argument");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, x, n / 4, dx, accumulate);
+    ZSG_CHECK_LAUNCH("relu_bwd");
+    return 0;
+}
+
+// ---- adaptive average pool to 1x1 --------------------------------------------------------------------------------
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int HW, int C, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = 0; k < HW; ++k) s += x[((int64_t)b * HW + k) * C + c];
+    out[i] = s / (float)HW;
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dout, int B, int HW, int C, float* __restrict__ dx, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * HW * C) return;
+    const int c = i % C, b = i / (HW * C);
+    const float g = dout[b * C + c] / (float)HW;
+    dx[i] = (accumulate ? dx[i] : 0.f) + g;
+}
+extern "C" int zsg_avgpool_fwd(const float* x, int32_t B, int32_t HW, int32_t C, float* out, void* stream) {
+    ZSG_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "avgpool_fwd: bad argument");
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv((int64_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, B, HW, C, out);
+    ZSG_CHECK_LAUNCH("avgpool_fwd");
+    return 0;
+}
+extern "C" int zsg_avgpool_bwd(const float* dout, int32_t B, int32_t HW, int32_t C, float* dx, int32_t accumulate, void* stream) {
+    ZSG_REQUIRE(dout && dx && B > 0 && HW > 0 && C > 0, "avgpool_bwd: bad argument");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cdiv((int64_t)B * HW * C, 256)), dim3(256), 0, (hipStream_t)stream, dout, B, HW, C, dx,
+                       accumulate);
+    ZSG_CHECK_LAUNCH("avgpool_bwd");
+    return 0;
+}
+
+// ---- channel L2 norm (one wave per pixel row) ----------------------------------------------------------------------
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ out, float* __restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[row * C + c];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    const float nrm = sqrtf(s);
+    if (lane == 0) norm[row] = nrm;
+    for (int c = lane; c < C; c += 64) out[row * C + c] = x[row * C + c] / nrm;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ norm,
+                                  int64_t rows, int C, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += dout[row * C + c] * out[row * C + c];
+    s = wave_sum(s);
+    const float inv = 1.0f / norm[row];
+    for (int c = lane; c < C; c += 64) dx[row * C + c] = (dout[row * C + c] - out[row * C + c] * s) * inv;
+}
+extern "C" int zsg_l2norm_fwd(const float* x, int64_t rows, int32_t C, float* out, float* norm, void* stream) {
+    ZSG_REQUIRE(x && out && norm && rows > 0 && C > 0, "l2norm_fwd: bad argument");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, out, norm);
+    ZSG_CHECK_LAUNCH("l2norm_fwd");
+    return 0;
+}
+extern "C" int zsg_l2norm_bwd(const float* dout, const float* out, const float* norm, int64_t rows, int32_t C, float* dx, void* stream) {
+    ZSG_REQUIRE(dout && out && norm && dx && rows > 0 && C > 0, "l2norm_bwd: bad argument");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dout, out, norm, rows, C, dx);
+    ZSG_CHECK_LAUNCH("l2norm_bwd");
+    return 0;
+}
+
+// ---- image NCHW -> NHWC4 ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ img, int B, int C, int HW, float* __restrict__ out) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, px = i % HW;
+        f32x4 v = {0, 0, 0, 0};
+        for (int c = 0; c < C && c < 4; ++c) v[c] = img[(b * C + c) * HW + px];
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+extern "C" int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t W, float* out, void* stream) {
+    ZSG_REQUIRE(img && out && C >= 1 && C <= 4, "nchw_to_nhwc4: bad argument (C=%d)", C);
+    const int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, img, B, C, H * W, out);
+    ZSG_CHECK_LAUNCH("nchw_to_nhwc4");
+    return 0;
+}
+
+// ---- head input: [feat | we | grid | 0-pad] -----------------------------------------------------------------------
+__global__ void fuse_lang_grid_kernel(const float* __restrict__ feat, const float* __restrict__ we, const float* __restrict__ gy,
+                                      const float* __restrict__ gx, int B, int h, int w, int Cf, int Cw, int use_grid, int ld,
+                                      float* __restrict__ out) {
+    const int ld4 = ld / 4;
+    const int64_t total = (int64_t)B * h * w * ld4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld4) * 4;
+        const int64_t pix = i / ld4;
+        const int x = (int)(pix % w);
+        const int y = (int)((pix / w) % h);
+        const int b = (int)(pix / ((int64_t)w * h));
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = c + e;
+            float t = 0.f;
+            if (ch < Cf) t = feat[pix * Cf + ch];
+            else if (ch < Cf + Cw) t = we[b * Cw + (ch - Cf)];
+            else if (use_grid && ch == Cf + Cw) t = gy[y];
+            else if (use_grid && ch == Cf + Cw + 1) t = gx[x];
+            v[e] = t;
+        }
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+extern "C" int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, const float* gx, int32_t B, int32_t h, int32_t w,
+                                  int32_t Cf, int32_t Cw, int32_t use_grid, int32_t ld, float* out, void* stream) {
+    ZSG_REQUIRE(out && (ld % 4) == 0 && ld >= Cf + Cw + (use_grid ? 2 : 0) && (Cf == 0 || feat) && (Cw == 0 || we) && (!use_grid || (gy && gx)),
+                "fuse_lang_grid: bad argument");
+    const int64_t n = (int64_t)B * h * w * (ld / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("fuse_lang_grid", st, 0, (double)B * h * w * (ld + Cf) * 4);
+    hipLaunchKernelGGL(fuse_lang_grid_kernel, dim3(grid_for(n)), dim3(256), 0, st, feat, we, gy, gx, B, h, w, Cf, Cw, use_grid, ld, out);
+    ZSG_CHECK_LAUNCH("fuse_lang_grid");
+    return 0;
+}
+
+// ---- weight transpose [N][T][C] -> [C][T][dst_ld >= N] (pad columns zeroed) ------------------------------------------
+__global__ void transpose_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int T, int C, int dst_ld) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int n = n0 + j, c = c0 + tx;
+        tile[j][tx] = (n < N && c < C) ? src[((int64_t)n * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, n = n0 + tx;
+        if (c < C && n < dst_ld) dst[((int64_t)c * T + t) * dst_ld + n] = tile[tx][j];
+    }
+}
+extern "C" int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t dst_ld, void* stream) {
+    ZSG_REQUIRE(src && dst && N > 0 && T > 0 && C > 0 && dst_ld >= N, "transpose_w: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("transpose_w", st, 0, (double)N * T * C * 8);
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(C, 32), cdiv(dst_ld, 32), T), dim3(256), 0, st, src, dst, N, T, C, dst_ld);
+    ZSG_CHECK_LAUNCH("transpose_w");
+    return 0;
+}
+
+// ---- column sums ---------------------------------------------------------------------------------------------------------
+// grid (col blocks of 64, row splits, groups); block 256 = 64 columns x 4 row lanes; atomics merge the row splits.
+__global__ void colsum_kernel(const float* __restrict__ x, int64_t gstride, int rows, int ld, int c0, int C, float* __restrict__ out,
+                              int rows_per_block) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int g = blockIdx.z;
+    const int r_begin = blockIdx.y * rows_per_block;
+    const int r_end = min(rows, r_begin + rows_per_block);
+    float s = 0.f;
+    if (col < C)
+        for (int r = r_begin + rl; r < r_end; r += 4) s += x[g * gstride + (int64_t)r * ld + c0 + col];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        unsafeAtomicAdd(out + (int64_t)g * C + col, s);
+    }
+}
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int zsg_memset_f32(float* p, int64_t n, float value, void* stream) {
+    ZSG_REQUIRE(p || n == 0, "memset_f32: null");
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (value == 0.f) {
+        hipError_t e = hipMemsetAsync(p, 0, (size_t)n * 4, st);
+        if (e != hipSuccess) ZSG_FAIL(-3, "memset_f32: %s", hipGetErrorString(e));
+        return 0;
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, n, value);
+    ZSG_CHECK_LAUNCH("memset_f32");
+    return 0;
+}
+extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32_t rows, int32_t ld, int32_t c0, int32_t C, float* out,
+                          int32_t accumulate, void* stream) {
+    ZSG_REQUIRE(x && out && groups > 0 && rows > 0 && C > 0, "colsum: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)groups * C * 4, st);
+        if (e != hipSuccess) ZSG_FAIL(-3, "colsum: %s", hipGetErrorString(e));
+    }
+    ZSG_PROF("colsum", st, 0, (double)groups * rows * C * 4);
+    int splits = cdiv(rows, 256);
+    const int cb = cdiv(C, 64);
+    while (splits > 1 && (int64_t)splits * cb * groups > 2048) splits = (splits + 1) / 2;
+    const int rpb = cdiv(rows, splits);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, cdiv(rows, rpb), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb);
+    ZSG_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+// ---- dst[r][0:dst_ld] = [src[r][0:C] | 0]  (e.g. the 45-channel head gradient -> 48-channel GEMM operand) -------------
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t rows, int C, int src_ld, float* __restrict__ dst, int dst_ld) {
+    const int64_t total = rows * dst_ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dst_ld;
+        const int c = (int)(i % dst_ld);
+        dst[i] = c < C ? src[r * src_ld + c] : 0.f;
+    }
+}
+extern "C" int zsg_pad_rows(const float* src, int64_t rows, int32_t C, int32_t src_ld, float* dst, int32_t dst_ld, void* stream) {
+    ZSG_REQUIRE(src && dst && rows > 0 && C > 0 && dst_ld >= C && src_ld >= C, "pad_rows: bad argument");
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(rows * dst_ld)), dim3(256), 0, (hipStream_t)stream, src, rows, C, src_ld, dst, dst_ld);
+    ZSG_CHECK_LAUNCH("pad_rows");
+    return 0;
+}

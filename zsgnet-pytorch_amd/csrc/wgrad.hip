@@ -1,0 +1,271 @@
+// wgrad.hip — convolution weight gradient on fp32 MFMA (split-K over pixels, fp32 atomic accumulation), gfx950.
+//
+// GEMM view:  dW[n][col] += sum_rows dY[row][n] * Src[gather(row, tap(col))][c(col)]
+//   n    = output channel (rows of dW)                     -> M of the GEMM
+//   col  = (tap, c) flattened tap-major                    -> N of the GEMM  (weight row layout, OHWI)
+//   rows = (segment, b, y, x) pixels of dY                 -> K of the GEMM, BK = 16 pixels per tile
+// Both operands are stored pixel-major with the GEMM M/N index contiguous ("MN-contiguous"), so LDS tiles are
+// [k][m] and a lane reads TM (TN) consecutive m (n) values of its k row with one ds_read_b32/b64: MFMA sub-tile t
+// covers rows m = TM*i + t — a row permutation that the epilogue undoes.  K tiles never straddle a segment, so the
+// pixel -> (b,y,x) decode uses wave-uniform geometry.  Split-K partial sums are added with hardware fp32 atomics
+// into dW (zeroed once per step by the caller; shared head weights accumulate over pyramid levels for free).
+#include "common.h"
+
+#define WG_BK 16
+#define WG_PAD 4
+
+struct WgSegDev {
+    int rows_y, rows_x, rows, kt0;
+    int src_H, src_W, sy, sx;
+    int out_W, osy, osx, opy, opx;
+    int src_off, src_bstride, out_off, out_bstride;
+    float inv_per, inv_rx;
+};
+
+struct WgParams {
+    const float* src;
+    const float* dy;
+    float* dw;
+    int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, nseg;
+    int ncols, txn;
+    int m_tiles, n_tiles, splits, kt_total, kt_chunk;
+    zsg_taps ty, tx;
+    WgSegDev seg[ZSG_MAX_SEG];
+};
+
+__device__ __forceinline__ int fdiv(int a, int d, float rcp) {   // a < 2^24, exact after one correction step
+    int q = (int)((float)a * rcp);
+    int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int LDA = BM + WG_PAD, LDB = BN + WG_PAD;
+    constexpr int GA = BM / 4, PA = 256 / GA, NA = WG_BK / PA;      // A staging: groups/row, rows/pass, passes
+    constexpr int GB = BN / 4, PB = 256 / GB, NB = WG_BK / PB;
+    __shared__ __attribute__((aligned(16))) float As[2][WG_BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_BK][LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nmn = p.m_tiles * p.n_tiles;
+    const int split = blockIdx.x / nmn;
+    const int mn = xcd_remap(blockIdx.x % nmn, nmn);
+    const int mt = mn / p.n_tiles, nt = mn % p.n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt_begin = split * p.kt_chunk;
+    const int kt_end = min(p.kt_total, kt_begin + p.kt_chunk);
+
+    // ---- fixed per-thread column state -----------------------------------------------------------------------
+    const int ga = tid % GA, ka = tid / GA;
+    const int gb = tid % GB, kb = tid / GB;
+    const int na = m0 + 4 * ga;                    // first dY channel of this thread's 16-byte group
+    const bool a_colok = na < p.N;
+    const bool a_vec = ((p.out_ld & 3) == 0) && (na + 4 <= p.N);
+    const int q = n0 + 4 * gb;                     // first logical weight column of this thread's group
+    const bool b_colok = q < p.ncols;
+    int b_dy, b_dx, b_c;
+    {
+        const int qq = b_colok ? q : 0;
+        const int tapi = qq / p.C;
+        b_c = qq - tapi * p.C;
+        const int jy = tapi / p.txn, jx = tapi - jy * p.txn;
+        b_dy = p.ty.d0 + jy * p.ty.dstep;
+        b_dx = p.tx.d0 + jx * p.tx.dstep;
+    }
+    const rsrc_t rs_a = make_rsrc(p.dy);
+    const rsrc_t rs_b = make_rsrc(p.src);
+
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < ZSG_MAX_SEG; ++s)
+        if (s < p.nseg && kt_begin >= p.seg[s].kt0) si = s;
+    WgSegDev sg = p.seg[si];
+    int kt_next = kt_begin;
+
+    f32x4 ra[NA], rb[NB];
+    auto load_tile = [&]() {
+        if (si + 1 < p.nseg && kt_next >= p.seg[si + 1].kt0) {     // wave-uniform segment switch
+            ++si;
+            sg = p.seg[si];
+        }
+        const int rbase = (kt_next - sg.kt0) * WG_BK;
+        const int per = sg.rows_y * sg.rows_x;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int r = rbase + ka + PA * j;
+            const bool rok = r < sg.rows;
+            const int rr = rok ? r : 0;
+            const int b = fdiv(rr, per, sg.inv_per);
+            const int rem = rr - b * per;
+            const int y = fdiv(rem, sg.rows_x, sg.inv_rx);
+            const int x = rem - y * sg.rows_x;
+            const unsigned off = 4u * (unsigned)(sg.out_off + b * sg.out_bstride +
+                                                  ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld + na);
+            if (a_vec) {
+                ra[j] = buf_load4(rs_a, (rok & a_colok) ? off : ZSG_OOB);
+            } else {                                                  // unaligned / ragged channel count (N = 45)
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = buf_load1(rs_a, (rok & (na + e < p.N)) ? off + 4u * e : ZSG_OOB);
+                ra[j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r = rbase + kb + PB * j;
+            const bool rok = r < sg.rows;
+            const int rr = rok ? r : 0;
+            const int b = fdiv(rr, per, sg.inv_per);
+            const int rem = rr - b * per;
+            const int y = fdiv(rem, sg.rows_x, sg.inv_rx);
+            const int x = rem - y * sg.rows_x;
+            const int yy = y * sg.sy + b_dy, xx = x * sg.sx + b_dx;
+            const bool ok = rok & b_colok & ((unsigned)yy < (unsigned)sg.src_H) & ((unsigned)xx < (unsigned)sg.src_W);
+            const unsigned off = 4u * (unsigned)(sg.src_off + b * sg.src_bstride + (yy * sg.src_W + xx) * p.src_ld + b_c);
+            rb[j] = buf_load4(rs_b, ok ? off : ZSG_OOB);
+        }
+        ++kt_next;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *(f32x4*)&As[buf][ka + PA * j][4 * ga] = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *(f32x4*)&Bs[buf][kb + PB * j][4 * gb] = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int am = wm * (32 * TM) + TM * li;       // this lane's first m inside the block tile
+    const int bn = wn * (32 * TN) + TN * li;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile();
+#pragma unroll
+        for (int kk = 0; kk < WG_BK / 2; ++kk) {
+            const int k = 2 * kk + lh;
+            float fa[TM], fb[TN];
+            if (TM == 2) {
+                const float2 v = *(const float2*)&As[buf][k][am];
+                fa[0] = v.x;
+                fa[TM - 1] = v.y;
+            } else {
+                fa[0] = As[buf][k][am];
+            }
+            if (TN == 2) {
+                const float2 v = *(const float2*)&Bs[buf][k][bn];
+                fb[0] = v.x;
+                fb[TN - 1] = v.y;
+            } else {
+                fb[0] = Bs[buf][k][bn];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (kt_begin >= kt_end) return;
+
+    // ---- epilogue: undo the row/column permutation, atomically add into dW ------------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int qc = n0 + bn + j;
+        const bool cok = qc < p.ncols;
+        const int qq = cok ? qc : 0;
+        const int tapi = qq / p.C;
+        const int c = qq - tapi * p.C;
+        const int jy = tapi / p.txn, jx = tapi - jy * p.txn;
+        const int wr = p.ty.w0 + jy * p.ty.wstep, ws = p.tx.w0 + jx * p.tx.wstep;
+        const int coff = (wr * p.wS + ws) * p.wC + p.wc0 + c;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row_i = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int n = m0 + wm * (32 * TM) + TM * row_i + i;
+                if (cok && n < p.N) unsafeAtomicAdd(p.dw + (size_t)n * p.wt_ld + coff, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, void* stream) {
+    ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad: null argument");
+    ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad: nseg=%d", d->nseg);
+    ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0,
+                "conv_wgrad: C=%d src_ld=%d wC=%d wc0=%d must be multiples of 4", d->C, d->src_ld, d->wC, d->wc0);
+    WgParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = src; p.dy = dy; p.dw = dw;
+    p.C = d->C; p.N = d->N; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.wS = d->wS; p.wC = d->wC; p.wc0 = d->wc0;
+    p.wt_ld = d->wt_ld; p.nseg = d->nseg;
+    p.ty = d->seg[0].ty; p.tx = d->seg[0].tx;
+    p.txn = p.tx.n;
+    p.ncols = p.ty.n * p.tx.n * d->C;
+    int kt = 0;
+    double rows_all = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const zsg_seg& a = d->seg[s];
+        ZSG_REQUIRE(memcmp(&a.ty, &p.ty, sizeof(zsg_taps)) == 0 && memcmp(&a.tx, &p.tx, sizeof(zsg_taps)) == 0,
+                    "conv_wgrad: segments must share one tap structure (pass the forward descriptor)");
+        const int64_t rows = (int64_t)d->B * a.rows_y * a.rows_x;
+        ZSG_REQUIRE(rows > 0 && rows < (1ll << 24), "conv_wgrad: seg %d rows=%lld (must be < 2^24)", s, (long long)rows);
+        ZSG_REQUIRE(a.src_off + (int64_t)d->B * a.src_bstride < (1ll << 29) && a.out_off + (int64_t)d->B * a.out_bstride < (1ll << 29),
+                    "conv_wgrad: tensor exceeds 2^29 elements (2 GB window)");
+        ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0, "conv_wgrad: seg %d source not 16-byte aligned", s);
+        WgSegDev& o = p.seg[s];
+        o.rows_y = a.rows_y; o.rows_x = a.rows_x; o.rows = (int)rows; o.kt0 = kt;
+        o.src_H = a.src_H; o.src_W = a.src_W; o.sy = a.sy; o.sx = a.sx;
+        o.out_W = a.out_W; o.osy = a.osy; o.osx = a.osx; o.opy = a.opy; o.opx = a.opx;
+        o.src_off = (int)a.src_off; o.src_bstride = (int)a.src_bstride;
+        o.out_off = (int)a.out_off; o.out_bstride = (int)a.out_bstride;
+        o.inv_per = 1.0f / (float)(a.rows_y * a.rows_x);
+        o.inv_rx = 1.0f / (float)a.rows_x;
+        kt += cdiv(rows, WG_BK);
+        rows_all += (double)rows;
+    }
+    p.kt_total = kt;
+    const int TM = (d->N > 64) ? 2 : 1;
+    const int TN = (p.ncols > 64) ? 2 : 1;
+    p.m_tiles = cdiv(d->N, 64 * TM);
+    p.n_tiles = cdiv(p.ncols, 64 * TN);
+    const int nmn = p.m_tiles * p.n_tiles;
+    int splits = (2 * ZSG_NUM_CU + nmn - 1) / nmn;
+    if (splits > kt / 2) splits = kt / 2;
+    if (splits < 1) splits = 1;
+    p.kt_chunk = cdiv(kt, splits);
+    p.splits = cdiv(kt, p.kt_chunk);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("conv_wgrad", st, 2.0 * rows_all * d->N * p.ncols, 0);
+    dim3 grid(nmn * p.splits), block(256);
+    if (TM == 2 && TN == 2) hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, block, 0, st, p);
+    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((wgrad_kernel<2, 1>), grid, block, 0, st, p);
+    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((wgrad_kernel<1, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, block, 0, st, p);
+    ZSG_CHECK_LAUNCH("conv_wgrad");
+    return 0;
+}

@@ -1,0 +1,788 @@
+"""ZSGNet on MI355X: same module surface as the reference `code/mdl.py` (get_default_net / ZSGNet.forward), with
+every device op a hand-written HIP kernel reached through the C ABI (include/zsg.h).
+
+Reference behaviour mirrored here (file:line in /root/reference/code):
+  * ZSGNet.forward mdl.py:338-403 — dict in (img [B,3,H,W], qvec [B,T,300], qlens [B]) -> dict out
+    (att_out [B,A,1], bbx_out [B,A,4], feat_sizes [L,2] int64, num_f_out [1] int64).
+  * RetinaBackBone.encode_feats mdl.py:148-159 (ResNet stem + layer1..4, Bottleneck fpn_resnet.py:61-100,
+    BasicBlock :26-58) and FPN_backbone.forward fpn_resnet.py:154-178.
+  * BackBone.concat_we mdl.py:69-104 (channel order [feat | language vector | grid y,x]).
+  * shared 6-conv head mdl.py:235-244 + permute_correctly :246-254 (free here: NHWC output == [B, h*w*9, 5]).
+  * BiLSTM query encoder apply_lstm mdl.py:296-336, random initial state lstm_init_hidden :279-294.
+
+Execution model: for a given input geometry the network is lowered ONCE into two static launch programs
+(forward, backward) over preallocated NHWC buffers (`ops.Program`); a step replays them on torch's current stream.
+The whole forward is a single autograd node, so the reference trainer's `loss.backward()` / `optimizer.step()`
+keep working while no autograd graph is built per layer.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import anchors as anchors_mod
+from ._lib import lib, require_gpu, stream_ptr
+from .ops import Level, Program, TView, conv_out, dgrad_desc, fwd_desc
+from .params import ParamStore, pad4, register_named
+
+ARCHS = {
+    "resnet18": ("basic", (2, 2, 2, 2)),
+    "resnet34": ("basic", (3, 4, 6, 3)),
+    "resnet50": ("bottleneck", (3, 4, 6, 3)),
+    "resnet101": ("bottleneck", (3, 4, 23, 3)),
+}
+
+
+@dataclass
+class ConvL:
+    name: str
+    cin: int
+    cout: int
+    k: int
+    stride: int = 1
+    pad: int = 0
+    dil: int = 1
+    bias: bool = False
+    merge_x: bool = False
+
+    @property
+    def cpad(self):
+        return pad4(self.cin)
+
+
+@dataclass
+class BnL:
+    name: str
+    c: int
+    index: int = 0      # slot in the flat running-stat buffers
+
+
+class Act(TView):
+    """TView + autograd bookkeeping used while lowering (grad buffer, whether it already holds a partial sum, and
+    whether the gradient stored there is w.r.t. the pre-ReLU value so producers must apply the ReLU mask)."""
+
+    def __init__(self, buf, B, C, ld, levels, name=""):
+        super().__init__(buf, B, C, ld, levels)
+        self.name = name
+        self.grad: Optional["Act"] = None
+        self.gfilled = False
+        self.needs_mask = False
+        self.requires_grad = True
+
+    def lvl(self, i) -> "Act":
+        a = Act(self.buf, self.B, self.C, self.ld, [self.levels[i]], f"{self.name}[{i}]")
+        a.requires_grad = self.requires_grad
+        return a
+
+
+class ZSGNet(nn.Module):
+    """The main model (reference mdl.py:171-403).  `backbone_kind` in {'retina', 'ssd_vgg'}."""
+
+    def __init__(self, backbone_kind: str = "retina", n_anchors: int = 9, cfg: Any = None, arch: str = "resnet50"):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone_kind = backbone_kind
+        self.arch = arch
+        self.n_anchors = n_anchors
+        self.emb_dim = int(cfg["emb_dim"])
+        self.bid = bool(cfg["use_bidirectional"])
+        self.lstm_dim = int(cfg["lstm_dim"])
+        self.lstm_out_dim = self.lstm_dim * (self.bid + 1)
+        self.use_lang = bool(cfg["use_lang"])
+        self.use_img = bool(cfg["use_img"])
+        if not cfg["use_same_atb"]:
+            raise NotImplementedError("use_same_atb=False (separate att/reg heads, mdl.py:223-225) is not lowered yet")
+        if backbone_kind != "retina":
+            raise NotImplementedError("mdl_to_use='ssd_vgg' is not lowered yet (SURVEY.md §8 config 4, next round)")
+        if cfg["do_norm"]:
+            raise NotImplementedError("do_norm=True (mdl.py:118-130) is not lowered yet")
+        self.six_hundred = list(cfg["resize_img"]) == [600, 600]
+        self.cf = 256 if self.use_img else 0
+        self.cw = self.lstm_out_dim if self.use_lang else 0
+        self.use_grid = (self.use_img and self.use_lang) or (not self.use_img and not self.use_lang)
+        self.start_dim_head = self.cf + self.cw + (2 if self.use_grid else 0)       # mdl.py:196-209
+        self.lstm_state = "randn"          # 'randn' (reference) | 'zeros'
+
+        self.store = ParamStore()
+        self.convs: Dict[str, ConvL] = {}
+        self.bns: Dict[str, BnL] = {}
+        self._declare()
+        self.store.allocate(torch.device("cpu"))
+        nb = sum(b.c for b in self.bns.values())
+        self._rm = torch.zeros(nb)
+        self._rv = torch.ones(nb)
+        self._nbt = torch.zeros(len(self.bns), dtype=torch.long)
+        self._register()
+        self.reset_parameters()
+        self._plans: Dict[Tuple, "_Plan"] = {}
+        self.debug = False
+
+    # ------------------------------------------------------------------------------------------------------
+    # declaration (names == reference state_dict keys)
+    # ------------------------------------------------------------------------------------------------------
+    def _conv(self, name, cin, cout, k, stride=1, pad=0, dil=1, bias=False, merge_x=False) -> ConvL:
+        L = ConvL(name, cin, cout, k, stride, pad, dil, bias, merge_x)
+        self.convs[name] = L
+        self.store.add_conv(name + ".weight", cout, cin, k)
+        if bias:
+            self.store.add_vec(name + ".bias", cout)
+        return L
+
+    def _bn(self, name, c) -> BnL:
+        off = sum(b.c for b in self.bns.values())
+        L = BnL(name, c, off)
+        self.bns[name] = L
+        self.store.add_vec(name + ".weight", c)
+        self.store.add_vec(name + ".bias", c)
+        return L
+
+    def _declare(self):
+        kind, nblocks = ARCHS[self.arch]
+        self.block_kind, self.nblocks = kind, nblocks
+        exp = 4 if kind == "bottleneck" else 1
+        e = "backbone.encoder."
+        self._conv(e + "conv1", 3, 64, 7, 2, 3, merge_x=True)
+        self._bn(e + "bn1", 64)
+        inpl = 64
+        self.blocks = []
+        for li, (planes, nb) in enumerate(zip((64, 128, 256, 512), nblocks), start=1):
+            for bi in range(nb):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                q = f"{e}layer{li}.{bi}."
+                blk = dict(prefix=q, stride=stride, layer=li, last=(bi == nb - 1), ds=False)
+                if kind == "bottleneck":       # stride on the 3x3 (torchvision v1.5 == fpn_resnet.py:73-74)
+                    self._conv(q + "conv1", inpl, planes, 1)
+                    self._bn(q + "bn1", planes)
+                    self._conv(q + "conv2", planes, planes, 3, stride, 1)
+                    self._bn(q + "bn2", planes)
+                    self._conv(q + "conv3", planes, planes * 4, 1)
+                    self._bn(q + "bn3", planes * 4)
+                else:
+                    self._conv(q + "conv1", inpl, planes, 3, stride, 1)
+                    self._bn(q + "bn1", planes)
+                    self._conv(q + "conv2", planes, planes, 3, 1, 1)
+                    self._bn(q + "bn2", planes)
+                if bi == 0 and (stride != 1 or inpl != planes * exp):
+                    self._conv(q + "downsample.0", inpl, planes * exp, 1, stride, 0)
+                    self._bn(q + "downsample.1", planes * exp)
+                    blk["ds"] = True
+                inpl = planes * exp
+                self.blocks.append(blk)
+        c3, c4, c5 = 128 * exp, 256 * exp, 512 * exp
+        f = "backbone.fpn."          # registration order of FPN_backbone.__init__, fpn_resnet.py:123-152
+        self._conv(f + "P7_2", 256, 256, 3, 2, 1, bias=True)
+        self._conv(f + "P6", c5, 256, 3, 2, 1, bias=True)
+        self._conv(f + "P5_1", c5, 256, 1, 1, 0, bias=True)
+        self._conv(f + "P5_2", 256, 256, 3, 1, 1, bias=True)
+        self._conv(f + "P4_1", c4, 256, 1, 1, 0, bias=True)
+        self._conv(f + "P4_2", 256, 256, 3, 1, 1, bias=True)
+        self._conv(f + "P3_1", c3, 256, 1, 1, 0, bias=True)
+        self._conv(f + "P3_2", 256, 256, 3, 1, 1, bias=True)
+        self._conv("att_reg_box.0.0", self.start_dim_head, 256, 3, 1, 1, bias=True)
+        for i in range(1, 5):
+            self._conv(f"att_reg_box.{i}.0", 256, 256, 3, 1, 1, bias=True)
+        self._conv("att_reg_box.5", 256, 5 * self.n_anchors, 3, 1, 1, bias=True)
+        H4 = 4 * self.lstm_dim
+        for suf in ([""] + (["_reverse"] if self.bid else [])):       # nn.LSTM parameter order
+            self.store.add_mat("lstm.weight_ih_l0" + suf, H4, self.emb_dim)
+            self.store.add_mat("lstm.weight_hh_l0" + suf, H4, self.lstm_dim)
+            self.store.add_vec("lstm.bias_ih_l0" + suf, H4)
+            self.store.add_vec("lstm.bias_hh_l0" + suf, H4)
+
+    def _register(self):
+        self._param_names = list(self.store.order)
+        for name in self._param_names:
+            register_named(self, name, self.store.view(name))
+        for i, (name, L) in enumerate(self.bns.items()):
+            register_named(self, name + ".running_mean", self._rm[L.index:L.index + L.c], buffer=True)
+            register_named(self, name + ".running_var", self._rv[L.index:L.index + L.c], buffer=True)
+            register_named(self, name + ".num_batches_tracked", self._nbt[i], buffer=True)
+
+    def _rebind(self):
+        """Re-point every Parameter / buffer at the (possibly moved) flat storages."""
+        mods = dict(self.named_modules())
+        for name in self._param_names:
+            path, leaf = name.rsplit(".", 1)
+            p = mods[path]._parameters[leaf]
+            p.data = self.store.view(name)
+            p.grad = None
+        for i, (name, L) in enumerate(self.bns.items()):
+            m = mods[name]
+            m._buffers["running_mean"] = self._rm[L.index:L.index + L.c]
+            m._buffers["running_var"] = self._rv[L.index:L.index + L.c]
+            m._buffers["num_batches_tracked"] = self._nbt[i]
+        self._plans = {}
+
+    def _apply(self, fn, recurse=True):
+        flat = fn(self.store.flat)
+        if flat.dtype != torch.float32:
+            raise TypeError("zsgnet-pytorch_amd computes in fp32 only (fp32 MFMA); dtype conversion is not supported")
+        self.store.flat = flat
+        self.store.grad = torch.zeros_like(flat)
+        self._rm, self._rv = fn(self._rm), fn(self._rv)
+        self._nbt = self._nbt.to(flat.device)
+        self._rebind()
+        return self
+
+    @property
+    def device(self):
+        return self.store.flat.device
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: Optional[int] = None):
+        """Random init (no network access for torchvision's ImageNet weights, mdl.py:411): He-normal encoder convs
+        (fpn_resnet.py:266-272), PyTorch-default FPN/head convs, U(+-1/sqrt(H)) LSTM, head bias [0,0,0,0,-4]*A
+        (mdl.py:214-219)."""
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        for name in self._param_names:
+            p = self.store.view(name)
+            e = self.store.entries[name]
+            if e.kind == "conv":
+                co, ci, k, _ = e.shape
+                if name.startswith("backbone.encoder."):
+                    p.copy_(torch.randn(e.shape, generator=g) * math.sqrt(2.0 / (k * k * co)))
+                else:
+                    bound = 1.0 / math.sqrt(ci * k * k)
+                    p.copy_((torch.rand(e.shape, generator=g) * 2 - 1) * bound)
+            elif name.startswith("lstm."):
+                bound = 1.0 / math.sqrt(self.lstm_dim)
+                p.copy_((torch.rand(e.shape, generator=g) * 2 - 1) * bound)
+            elif name.endswith(".bias") and name[:-5] in self.convs:
+                L = self.convs[name[:-5]]
+                bound = 1.0 / math.sqrt(L.cin * L.k * L.k)
+                p.copy_((torch.rand(e.shape, generator=g) * 2 - 1) * bound)
+            elif name.endswith(".weight"):       # BN gamma
+                p.fill_(1.0)
+            else:                                # BN beta
+                p.zero_()
+        hb = torch.zeros(5 * self.n_anchors)
+        hb[4::5] = -4.0
+        self.store.view("att_reg_box.5.bias").copy_(hb)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts reference checkpoints: strips DDP's 'module.' prefix (utils.py:489) and tolerates torchvision's
+        unused `backbone.encoder.fc.*`."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k[7:] if k.startswith("module.") else k
+            if k.startswith("backbone.encoder.fc.") or k.startswith("backbone.encoder.fpn."):
+                continue
+            sd[k] = v
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    # ------------------------------------------------------------------------------------------------------
+    # forward / backward
+    # ------------------------------------------------------------------------------------------------------
+    def lstm_init_hidden(self, bs: int):
+        """Reference mdl.py:279-294: two CPU draws (hidden_a then hidden_b) per forward, train and eval."""
+        n = 2 if self.bid else 1
+        if self.lstm_state == "zeros":
+            return torch.zeros(n, bs, self.lstm_dim), torch.zeros(n, bs, self.lstm_dim)
+        return torch.randn(n, bs, self.lstm_dim), torch.randn(n, bs, self.lstm_dim)
+
+    def _ordered_params(self) -> List[nn.Parameter]:
+        """Parameters in flat-storage order (== the order run_backward returns gradients in)."""
+        if getattr(self, "_plist", None) is None:
+            mods = dict(self.named_modules())
+            self._plist = [mods[n.rsplit(".", 1)[0]]._parameters[n.rsplit(".", 1)[1]] for n in self._param_names]
+        return self._plist
+
+    def _plan_for(self, B, H, W, T) -> "_Plan":
+        key = (B, H, W, T, self.training)
+        if key not in self._plans:
+            self._plans[key] = _Plan(self, B, H, W, T, self.training)
+        return self._plans[key]
+
+    def forward(self, inp: Dict[str, Any]) -> Dict[str, Any]:
+        require_gpu()
+        img, qvec, qlens = inp["img"], inp["qvec"], inp["qlens"]
+        if img.device.type != "cuda" or self.device.type != "cuda":
+            raise RuntimeError("ZSGNet.forward needs the model and the batch on the MI355X (no CPU fallback)")
+        B, _, H, W = img.shape
+        T = qvec.shape[1]
+        plan = self._plan_for(B, H, W, T)
+        if "h0" in inp:
+            h0, c0 = inp["h0"], inp["c0"]
+        else:
+            h0, c0 = self.lstm_init_hidden(B)
+        params = self._ordered_params()
+        out5 = _NetFn.apply(self, plan, img, qvec, qlens, h0, c0, *params)
+        return dict(att_out=out5[..., 4:5], bbx_out=out5[..., :4], feat_sizes=plan.feat_sizes_t,
+                    num_f_out=plan.num_f_out_t, att_bbx_out=out5)
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, plan, img, qvec, qlens, h0, c0, *params):
+        ctx.net, ctx.plan = net, plan
+        return plan.run_forward(img, qvec, qlens, h0, c0)
+
+    @staticmethod
+    def backward(ctx, g5):
+        grads = ctx.plan.run_backward(g5)
+        return (None,) * 7 + tuple(grads)
+
+
+class _Plan:
+    """Static lowering of ZSGNet for one (B, H, W, T, training) geometry."""
+
+    def __init__(self, net: ZSGNet, B: int, H: int, W: int, T: int, training: bool):
+        self.net, self.B, self.H, self.W, self.T, self.training = net, B, H, W, T, training
+        self.dev = net.device
+        self.fwd = Program("fwd")
+        self.prep = Program("bwd-prep")
+        self.bwd = Program("bwd")
+        self.tape = []
+        self.acts: Dict[str, Act] = {}
+        self.bytes = 0
+        self.wt: Dict[str, torch.Tensor] = {}
+        self._lower()
+
+    # ---- allocation helpers --------------------------------------------------------------------------------
+    def _buf(self, n, dtype=torch.float32):
+        t = torch.zeros(int(n), dtype=dtype, device=self.dev)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def act(self, name, B, H, W, C, ld=None, requires_grad=True) -> Act:
+        ld = ld or C
+        a = Act(self._buf(B * H * W * ld), B, C, ld, [Level(0, H, W, H * W * ld)], name)
+        a.requires_grad = requires_grad
+        self.acts[name] = a
+        return a
+
+    def packed(self, name, B, sizes, C, ld=None) -> Act:
+        """pyramid levels packed level-major in one buffer"""
+        ld = ld or C
+        lv, off = [], 0
+        for (h, w) in sizes:
+            lv.append(Level(off, h, w, h * w * ld))
+            off += B * h * w * ld
+        a = Act(self._buf(off), B, C, ld, lv, name)
+        self.acts[name] = a
+        return a
+
+    def like(self, a: Act, name=None) -> Act:
+        g = Act(self._buf(a.buf.numel()), a.B, a.C, a.ld, a.levels, name or (a.name + ".grad"))
+        return g
+
+    def grad_of(self, a: Act) -> Act:
+        if a.grad is None:
+            a.grad = self.like(a)
+        return a.grad
+
+    @staticmethod
+    def base(a: Act) -> torch.Tensor:
+        """flat tensor starting at the first element of a (single-level or packed) activation"""
+        return a.buf[a.levels[0].off:]
+
+    def P(self, name):      # raw parameter storage
+        return self.net.store.raw(name)
+
+    def G(self, name):
+        return self.net.store.raw(name, self.net.store.grad)
+
+    # ---- op lowering ---------------------------------------------------------------------------------------------
+    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None) -> Act:
+        if out is None:
+            lv = src.levels
+            assert len(lv) == 1
+            out = self.act(name or L.name, src.B, conv_out(lv[0].H, L.k, L.stride, L.pad, L.dil),
+                           conv_out(lv[0].W, L.k, L.stride, L.pad, L.dil), L.cout)
+        d = fwd_desc(src, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
+        bias = self.P(L.name + ".bias") if L.bias else None
+        self.fwd.add(lib.zsg_conv_igemm, d, src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, what=L.name)
+        out.needs_mask = relu
+        self.tape.append(lambda: self._conv_bwd(L, src, out))
+        return out
+
+    def _wt(self, L: ConvL, cred: int) -> torch.Tensor:
+        """transposed weight image [cpad][k*k][cred] for the data gradient, refreshed by the bwd-prep program"""
+        if L.name not in self.wt:
+            t = self._buf(L.cpad * L.k * L.k * cred)
+            self.wt[L.name] = t
+            self.prep.add(lib.zsg_transpose_w, self.P(L.name + ".weight"), t, L.cout, L.k * L.k, L.cpad, cred, what="T:" + L.name)
+        return self.wt[L.name]
+
+    def _conv_bwd(self, L: ConvL, src: Act, out: Act, dy: Optional[Act] = None):
+        dy = dy or out.grad
+        if dy is None:
+            return
+        dw = fwd_desc(src, dy, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad)
+        self.bwd.add(lib.zsg_conv_wgrad, dw, src.buf, dy.buf, self.G(L.name + ".weight"), what="wgrad:" + L.name)
+        if L.bias:
+            base = dy.levels[0].off
+            self.bwd.add(lib.zsg_colsum, dy.buf[base:], 1, 0, dy.rows(), dy.ld, 0, L.cout, self.G(L.name + ".bias"), 1,
+                         what="bgrad:" + L.name)
+        if src.requires_grad:
+            self.dgrad(L, dy, src, n=L.cpad)
+
+    def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None):
+        """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
+        cred = dy.ld
+        assert cred % 4 == 0
+        wt = self._wt(L, cred)
+        dx = dx or self.grad_of(src)
+        d = dgrad_desc(dy, dx, cred, n, L.k, L.stride, L.pad, L.dil)
+        wt_off = row0 * L.k * L.k * cred
+        self.bwd.add(lib.zsg_conv_igemm, d, dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None,
+                     src.buf if src.needs_mask else None, what="dgrad:" + L.name)
+        dx.gfilled = True
+
+    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None) -> Act:
+        net = self.net
+        lv = x.levels[0]
+        out = self.act(name or L.name, x.B, lv.H, lv.W, L.c)
+        rows = x.B * lv.H * lv.W
+        mean, invstd = self._buf(L.c), self._buf(L.c)
+        rm, rv = net._rm[L.index:L.index + L.c], net._rv[L.index:L.index + L.c]
+        self.ws_need = max(getattr(self, "ws_need", 0), lib.zsg_bn_workspace_bytes(rows, L.c))
+        gam, bet = self.P(L.name + ".weight"), self.P(L.name + ".bias")
+        if self.training:
+            self.fwd.add(lib.zsg_bn_stats, x.buf, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, self.ws, self.ws_bytes, what=L.name)
+        else:
+            self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name)
+        self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
+                     int(relu), out.buf, what=L.name)
+
+        def back():
+            if out.grad is None:
+                return
+            dx = self.grad_of(x)
+            g_out = None
+            if residual is not None and residual.requires_grad:
+                rg = self.grad_of(residual)
+                assert not rg.gfilled, "residual gradient must be produced first (tape order)"
+                g_out = rg.buf
+                rg.gfilled = True
+            self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), out.buf if relu else None, x.buf, rows, L.c, mean, invstd, gam,
+                         dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,
+                         what="bnbwd:" + L.name)
+            dx.gfilled = True
+        self.tape.append(back)
+        return out
+
+    # ---- the network ---------------------------------------------------------------------------------------------------
+    def _lower(self):
+        net, B, H, W, T = self.net, self.B, self.H, self.W, self.T
+        C = net.convs
+        BN = net.bns
+        e = "backbone.encoder."
+        # shared BN workspace: sized generously up-front (largest rows*C is the stem's conv output)
+        H1, W1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+        self.ws_bytes = 8 << 20          # >= zsg_bn_workspace_bytes for every layer (chunks*2*C floats <= ~2.2 MB); checked by the library
+        self.ws = self._buf(self.ws_bytes // 4)
+
+        # ---- static inputs ------------------------------------------------------------------------------------------
+        self.in_qvec = self._buf(B * T * net.emb_dim)
+        self.in_qlens = self._buf(B)
+        nd = 2 if net.bid else 1
+        self.in_h0 = self._buf(nd * B * net.lstm_dim)
+        self.in_c0 = self._buf(nd * B * net.lstm_dim)
+        self.img_slot = len(self.fwd.calls)
+        x0 = self.act("img_nhwc4", B, H, W, 4, requires_grad=False)
+        self.fwd.add(lib.zsg_nchw_to_nhwc4, self.in_qvec, B, 3, H, W, x0.buf, what="img")     # src pointer patched per call
+
+        # ---- query encoder ----------------------------------------------------------------------------------------------
+        we = None
+        if net.use_lang:
+            we = self._lower_lstm()
+
+        # ---- encoder ------------------------------------------------------------------------------------------------------
+        feats: List[Act] = []
+        if net.use_img:
+            y = self.conv(C[e + "conv1"], x0, name="stem.y")
+            a = self.bn(BN[e + "bn1"], y, relu=True, name="stem.a")
+            H2, W2 = conv_out(H1, 3, 2, 1), conv_out(W1, 3, 2, 1)
+            x = self.act("pool", B, H2, W2, 64)
+            idx = self._buf((B * H2 * W2 * 64 + 3) // 4)      # uint8 indices, stored in a float-sized buffer
+            self.fwd.add(lib.zsg_maxpool_fwd, a.buf, B, H1, W1, 64, 3, 2, 1, H2, W2, x.buf, idx, what="maxpool")
+            pool_in, pool_out = a, x
+
+            def pool_back():
+                if pool_out.grad is None:
+                    return
+                dx = self.grad_of(pool_in)
+                self.bwd.add(lib.zsg_maxpool_bwd, self.base(pool_out.grad), idx, B, H1, W1, 64, 3, 2, 1, H2, W2, dx.buf, what="maxpool_bwd")
+                dx.gfilled = True
+            self.tape.append(pool_back)
+            taps = {}
+            for blk in net.blocks:
+                x = self._lower_block(blk, x)
+                if blk["last"]:
+                    taps[blk["layer"]] = x
+            feats = self._lower_fpn(taps[2], taps[3], taps[4])
+        else:
+            raise NotImplementedError("use_img=False (image-blind ablation, mdl.py:363-366) is not lowered yet")
+        self.feat_sizes = [(f.levels[0].H, f.levels[0].W) for f in feats]
+        self.feat_sizes_t = torch.tensor(self.feat_sizes, dtype=torch.long, device=self.dev)
+        self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
+        self._lower_head(feats, we)
+
+        # ---- backward program: replay the tape in reverse ----------------------------------------------------------
+        if self.training:
+            for emit in reversed(self.tape):
+                emit()
+        self.tape = []
+
+    def _lower_block(self, blk, x: Act) -> Act:
+        net = self.net
+        C, BN, q = net.convs, net.bns, blk["prefix"]
+        if net.block_kind == "bottleneck":
+            y1 = self.conv(C[q + "conv1"], x, name=q + "y1")
+            a1 = self.bn(BN[q + "bn1"], y1, True, name=q + "a1")
+            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2")
+            a2 = self.bn(BN[q + "bn2"], y2, True, name=q + "a2")
+            y3 = self.conv(C[q + "conv3"], a2, name=q + "y3")
+            last_bn, last_y = BN[q + "bn3"], y3
+        else:
+            y1 = self.conv(C[q + "conv1"], x, name=q + "y1")
+            a1 = self.bn(BN[q + "bn1"], y1, True, name=q + "a1")
+            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2")
+            last_bn, last_y = BN[q + "bn2"], y2
+        res = x
+        if blk["ds"]:
+            yd = self.conv(C[q + "downsample.0"], x, name=q + "yd")
+            res = self.bn(BN[q + "downsample.1"], yd, False, name=q + "rd")
+        return self.bn(last_bn, last_y, True, residual=res, name=q + "out")
+
+    def _lower_fpn(self, c3: Act, c4: Act, c5: Act) -> List[Act]:
+        """fpn_resnet.py:154-178"""
+        net, B = self.net, self.B
+        C = net.convs
+        f = "backbone.fpn."
+        p51 = self.conv(C[f + "P5_1"], c5, name="p51")
+        p5 = self.conv(C[f + "P5_2"], p51, name="p5")
+        t4 = self.conv(C[f + "P4_1"], c4, name="t4")
+        p41 = self._upsample_add(t4, p51, "p41")
+        p4 = self.conv(C[f + "P4_2"], p41, name="p4")
+        t3 = self.conv(C[f + "P3_1"], c3, name="t3")
+        p31 = self._upsample_add(t3, p41, "p31")
+        p3 = self.conv(C[f + "P3_2"], p31, name="p3")
+        p6 = self.conv(C[f + "P6"], c5, name="p6")
+        r6 = self.act("r6", B, p6.levels[0].H, p6.levels[0].W, 256)
+        n6 = r6.buf.numel()
+        self.fwd.add(lib.zsg_relu_fwd, p6.buf, n6, r6.buf, what="relu(p6)")
+
+        def relu_back():
+            if r6.grad is None:
+                return
+            g = self.grad_of(p6)
+            self.bwd.add(lib.zsg_relu_bwd, self.base(r6.grad), p6.buf, n6, self.base(g), int(g.gfilled), what="relu_bwd(p6)")
+            g.gfilled = True
+        self.tape.append(relu_back)
+        p7 = self.conv(C[f + "P7_2"], r6, name="p7")
+        if net.six_hundred:
+            return [p4, p5, p6, p7]           # p3 is computed and dropped, as the reference does (fpn_resnet.py:173-174)
+        l7 = p7.levels[0]
+        p8 = self.act("p8", B, 1, 1, 256)
+        self.fwd.add(lib.zsg_avgpool_fwd, p7.buf, B, l7.H * l7.W, 256, p8.buf, what="avgpool")
+
+        def avg_back():
+            if p8.grad is None:
+                return
+            g = self.grad_of(p7)
+            self.bwd.add(lib.zsg_avgpool_bwd, self.base(p8.grad), B, l7.H * l7.W, 256, self.base(g), int(g.gfilled), what="avgpool_bwd")
+            g.gfilled = True
+        self.tape.append(avg_back)
+        return [p3, p4, p5, p6, p7, p8]
+
+    def _upsample_add(self, a: Act, p: Act, name: str) -> Act:
+        la, lp = a.levels[0], p.levels[0]
+        out = self.act(name, a.B, la.H, la.W, a.C)
+        self.fwd.add(lib.zsg_upsample_add_fwd, a.buf, p.buf, a.B, lp.H, lp.W, la.H, la.W, a.C, out.buf, what=name)
+
+        def back():
+            if out.grad is None:
+                return
+            assert a.grad is None
+            a.grad = out.grad                     # identity branch: share the buffer
+            g = self.grad_of(p)
+            self.bwd.add(lib.zsg_upsample_add_bwd, self.base(out.grad), a.B, lp.H, lp.W, la.H, la.W, a.C, self.base(g), int(g.gfilled),
+                         what=name + "_bwd")
+            g.gfilled = True
+        self.tape.append(back)
+        return out
+
+    def _lower_lstm(self) -> Act:
+        """mdl.py:296-336.  we [B, 2H] = [h_fwd(len-1) | reverse-cell(x[len-1])]"""
+        net, B, T = self.net, self.B, self.T
+        E, Hd = net.emb_dim, net.lstm_dim
+        H4 = 4 * Hd
+        we = self.act("we", B, 1, 1, net.lstm_out_dim)
+        dirs = [("", 0)] + ([("_reverse", 1)] if net.bid else [])
+        x_all = Act(self.in_qvec, B, E, E, [Level(0, 1, T, T * E)], "qvec")
+        x_all.requires_grad = False
+        xlast = self.act("xlast", B, 1, 1, E, requires_grad=False)
+        for suf, di in dirs:
+            Tn = T if di == 0 else 1
+            xin = x_all if di == 0 else xlast
+            if di == 1:
+                self.fwd.add(lib.zsg_lstm_gather_last, self.in_qvec, self.in_qlens, B, T, E, xlast.buf, what="gather_last")
+            gin = self.act("gin" + suf, B, 1, Tn, H4)
+            d = fwd_desc(xin, gin, E, H4, 1, 1, 0, 1, wC=E)
+            self.fwd.add(lib.zsg_conv_igemm, d, xin.buf, self.P("lstm.weight_ih_l0" + suf), gin.buf, self.P("lstm.bias_ih_l0" + suf),
+                         None, None, what="lstm_in" + suf)
+            gates, cst, hprev = self._buf(B * Tn * H4), self._buf(B * Tn * Hd), self._buf(B * Tn * Hd)
+            h0 = self.in_h0[di * B * Hd:(di + 1) * B * Hd]
+            c0 = self.in_c0[di * B * Hd:(di + 1) * B * Hd]
+            lens = self.in_qlens if di == 0 else None
+            self.fwd.add(lib.zsg_lstm_fwd, gin.buf, self.P("lstm.weight_hh_l0" + suf), self.P("lstm.bias_hh_l0" + suf), h0, c0,
+                         self.in_qlens, lens, B, Tn, Hd, gates, cst, hprev, we.buf, net.lstm_out_dim, di * Hd, what="lstm" + suf)
+
+            def back(suf=suf, di=di, Tn=Tn, xin=xin, gates=gates, cst=cst, hprev=hprev, c0=c0, lens=lens):
+                if we.grad is None:
+                    return
+                dg = Act(self._buf(B * Tn * H4), B, H4, H4, [Level(0, 1, Tn, Tn * H4)], "dgates" + suf)
+                self.bwd.add(lib.zsg_lstm_bwd, we.grad.buf, net.lstm_out_dim, di * Hd, self.P("lstm.weight_hh_l0" + suf), gates, cst, c0,
+                             self.in_qlens, lens, B, Tn, Hd, dg.buf, what="lstm_bwd" + suf)
+                d_ih = fwd_desc(xin, dg, E, H4, 1, 1, 0, 1, wC=E)
+                self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), what="wgrad:w_ih" + suf)
+                hp = Act(hprev, B, Hd, Hd, [Level(0, 1, Tn, Tn * Hd)], "hprev" + suf)
+                d_hh = fwd_desc(hp, dg, Hd, H4, 1, 1, 0, 1, wC=Hd)
+                self.bwd.add(lib.zsg_conv_wgrad, d_hh, hp.buf, dg.buf, self.G("lstm.weight_hh_l0" + suf), what="wgrad:w_hh" + suf)
+                for bname in ("lstm.bias_ih_l0", "lstm.bias_hh_l0"):
+                    self.bwd.add(lib.zsg_colsum, dg.buf, 1, 0, B * Tn, H4, 0, H4, self.G(bname + suf), 1, what="bgrad:" + bname + suf)
+            self.tape.append(back)
+        return we
+
+    def _lower_head(self, feats: List[Act], we: Optional[Act]):
+        """concat_we (mdl.py:69-104) + shared head (mdl.py:235-244) over all pyramid levels in grouped launches."""
+        net, B = self.net, self.B
+        C = net.convs
+        sizes = self.feat_sizes
+        Cf, Cw = net.cf, net.cw
+        cin0 = net.start_dim_head
+        ld0 = pad4(cin0)
+        F0 = self.packed("head.in", B, sizes, ld0, ld0)
+        F0.requires_grad = False          # its gradient is routed by hand below (feature / language halves)
+        self.gy, self.gx = [], []
+        for i, (h, w) in enumerate(sizes):
+            g = anchors_mod.create_grid_np(h, w).reshape(h, w, 2)
+            gy = torch.from_numpy(np.ascontiguousarray(g[:, 0, 0])).to(self.dev)
+            gx = torch.from_numpy(np.ascontiguousarray(g[0, :, 1])).to(self.dev)
+            self.gy.append(gy)
+            self.gx.append(gx)
+            l = F0.levels[i]
+            self.fwd.add(lib.zsg_fuse_lang_grid, feats[i].buf[feats[i].levels[0].off:] if Cf else None, we.buf if Cw else None, gy, gx, B, h, w,
+                         Cf, Cw, int(net.use_grid), ld0, F0.buf[l.off:], what=f"fuse{i}")
+        L0 = C["att_reg_box.0.0"]
+        h = self.packed("head.h1", B, sizes, 256)
+        self.conv(L0, F0, relu=True, out=h)
+        self.tape.pop()                     # replaced by the split backward below
+        h1 = h
+        hs = [h1]
+        for i in range(1, 5):
+            nxt = self.packed(f"head.h{i + 1}", B, sizes, 256)
+            self.conv(C[f"att_reg_box.{i}.0"], hs[-1], relu=True, out=nxt)
+            hs.append(nxt)
+        L5 = C["att_reg_box.5"]
+        nout = L5.cout
+        P = sum(hh * ww for hh, ww in sizes)
+        self.A = P * net.n_anchors
+        lv, off = [], 0
+        for (hh, ww) in sizes:
+            lv.append(Level(off * nout, hh, ww, P * nout))
+            off += hh * ww
+        out5 = Act(self._buf(B * P * nout), B, nout, nout, lv, "out5")
+        self.acts["out5"] = out5
+        self.out5 = out5
+        self.conv(L5, hs[-1], relu=False, out=out5)
+        self.tape.pop()
+        if not self.training:
+            return
+        # ---- head backward (emitted first: the tape is replayed in reverse, so push it last) -----------------------
+        npad = pad4(nout)
+        lvp, off = [], 0
+        for (hh, ww) in sizes:
+            lvp.append(Level(off * npad, hh, ww, P * npad))
+            off += hh * ww
+        self.g5_in = self._buf(B * P * nout)
+        g5p = Act(self._buf(B * P * npad), B, npad, npad, lvp, "g5p")
+        h5 = hs[-1]
+
+        def head_back():
+            self.bwd.add(lib.zsg_pad_rows, self.g5_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
+            self.bwd.add(lib.zsg_colsum, self.g5_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:head5")
+            dw = fwd_desc(h5, g5p, L5.cpad, nout, 3, 1, 1, 1, wC=L5.cpad)
+            self.bwd.add(lib.zsg_conv_wgrad, dw, h5.buf, g5p.buf, self.G(L5.name + ".weight"), what="wgrad:head5")
+            self.dgrad(L5, g5p, h5, n=256)
+            for i in range(4, 0, -1):
+                self._conv_bwd(C[f"att_reg_box.{i}.0"], hs[i - 1], hs[i])
+            # conv0: weight/bias gradient over the full 514(+pad) channels; data gradient split into the feature and
+            # the language halves (the grid channels are constants)
+            dy = h1.grad
+            dw0 = fwd_desc(F0, dy, L0.cpad, 256, 3, 1, 1, 1, wC=L0.cpad)
+            self.bwd.add(lib.zsg_conv_wgrad, dw0, F0.buf, dy.buf, self.G(L0.name + ".weight"), what="wgrad:head0")
+            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0")
+            if Cf:
+                dF = self.packed("head.dfeat", B, sizes, Cf)
+                self.dgrad(L0, dy, F0, n=Cf, row0=0, dx=dF)
+                for i, f in enumerate(feats):
+                    assert f.grad is None
+                    f.grad = dF.lvl(i)
+                    f.grad.gfilled = True
+            if Cw:
+                dWe = self.packed("head.dwe", B, sizes, Cw)
+                self.dgrad(L0, dy, F0, n=Cw, row0=Cf, dx=dWe)
+                gwe = self.grad_of(we)
+                for i, (hh, ww) in enumerate(sizes):
+                    l = dWe.levels[i]
+                    self.bwd.add(lib.zsg_colsum, dWe.buf[l.off:], B, hh * ww * Cw, hh * ww, Cw, 0, Cw, gwe.buf, int(i > 0), what=f"dwe{i}")
+                gwe.gfilled = True
+        self.tape.append(head_back)
+
+    # ---- execution -------------------------------------------------------------------------------------------------------
+    def run_forward(self, img, qvec, qlens, h0, c0) -> torch.Tensor:
+        net = self.net
+        B = self.B
+        img = img.contiguous()
+        if img.dtype != torch.float32:
+            img = img.float()
+        self.in_qvec.view(B, self.T, net.emb_dim).copy_(qvec, non_blocking=True)
+        self.in_qlens.copy_(qlens.reshape(B), non_blocking=True)
+        nd = 2 if net.bid else 1
+        self.in_h0.view(nd, B, net.lstm_dim).copy_(h0, non_blocking=True)
+        self.in_c0.view(nd, B, net.lstm_dim).copy_(c0, non_blocking=True)
+        # patch the one dynamic pointer (the caller's image tensor)
+        fn, args, what = self.fwd.calls[self.img_slot]
+        import ctypes as C_
+        self.fwd.calls[self.img_slot] = (fn, (C_.c_void_p(img.data_ptr()),) + args[1:], what)
+        self._img_keepalive = img
+        if self.training:
+            net._nbt.add_(1)
+        self.fwd.run(stream_ptr())
+        return self.out5.buf.view(B, self.A, 5).clone()
+
+    def run_backward(self, g5: torch.Tensor):
+        net = self.net
+        if not self.training:
+            raise RuntimeError("backward through an eval-mode plan")
+        params = net._ordered_params()
+        fresh = all(p.grad is None for p in params)
+        st = stream_ptr()
+        if fresh:
+            lib.zsg_memset_f32(net.store.grad.data_ptr(), net.store.grad.numel(), 0.0, st)
+        self.g5_in.view_as(g5).copy_(g5)
+        self.prep.run(st)
+        self.bwd.run(st)
+        if not fresh:
+            return [None] * len(params)      # gradients were accumulated in place into the tensors p.grad already views
+        return [net.store.view(n, net.store.grad) for n in net._param_names]
+
+
+def get_default_net(num_anchors=1, cfg=None):
+    """Constructs the network based on the config (reference mdl.py:406-422).  'retina' = ResNet + FPN; the encoder
+    depth comes from the optional cfg key `resnet_arch` (default resnet50, the reference's hard-coded choice)."""
+    kind = cfg["mdl_to_use"]
+    arch = cfg["resnet_arch"] if "resnet_arch" in cfg else "resnet50"
+    net = ZSGNet(kind, num_anchors, cfg=cfg, arch=arch)
+    path = cfg["pretrained_path"] if "pretrained_path" in cfg else ""
+    if path:
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("model_state_dict", sd)
+        net.load_state_dict(sd, strict=False)
+    return net

@@ -1,0 +1,42 @@
+"""Fused Adam over the model's flat parameter buffer (reference: torch.optim.Adam(betas=(0.9,0.99)), main_dist.py:50,
+stepped at utils.py:413).  One HIP launch updates all 37.6 M parameters (28 B/param of HBM traffic) instead of ~170
+per-tensor updates; the step counter lives on the device so the launch is hipGraph-capturable."""
+import torch
+
+from ._lib import lib, check, stream_ptr
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        net = model.module if hasattr(model, "module") else model
+        self.net = net
+        params = net._ordered_params()
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        flat = net.store.flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=flat.device)
+        self.grad_scale = grad_scale
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.net._ordered_params():
+            p.grad = None            # gradients live in the flat buffer, which backward re-zeroes
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        st = self.net.store
+        check(lib.zsg_adam_step(st.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), st.flat.numel(),
+                                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                float(g["weight_decay"]), float(self.grad_scale), self.step_count.data_ptr(), stream_ptr()),
+              "zsg_adam_step")
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["zsg"] = dict(m=self.m, v=self.v, step=self.step_count)
+        return d
+
+    def load_state_dict(self, sd):
+        z = sd.get("zsg")
+        if z is not None:
+            self.m.copy_(z["m"]); self.v.copy_(z["v"]); self.step_count.copy_(z["step"])
