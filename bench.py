@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py — ZSGNet training-step throughput on MI355X (BASELINE.json metric: train images/sec).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+
+A "step" is the reference's hot loop body, utils.py:407-414: zero_grad -> ZSGNet.forward -> ZSGLoss -> backward
+(-> bucketed RCCL all-reduce) -> Adam -> Evaluator, on a synthetic batch already resident in HBM (SURVEY.md §8d:
+img ~ U[0,1) 300x300, 20-token queries, per-GPU batch 16 = BASELINE configs[1]).  W warm-up steps, then exactly K timed
+steps between barrier + torch.cuda.synchronize(); MAX over ranks; rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, outside the timed region):
+  roofline     — per-launch HIP-event timing of every kernel class (zsg_prof_*); the dominant class is reported as
+                 achieved TFLOP/s = algorithmic 2*MAC / event time against the 157.3 TFLOP/s fp32-MFMA peak.
+  cpu_baseline — the CPU oracle's same step (torch-CPU fp32, B=4) on the host cores ("port"); N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_GF = {"resnet50": 32.569, "resnet101": None, "resnet18": None}     # BASELINE.md §3 (conv 2*MAC per image @300^2)
+PEAK_TF = 157.3                                                         # fp32-input MFMA, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=16, help="per-GPU batch (configs[1]: 16)")
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--img", type=int, default=300)
+    ap.add_argument("--tokens", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-out", default="")
+    return ap.parse_args()
+
+
+def cpu_baseline(arch, img, tokens):
+    """The oracle's training step on the host cores (kind 'port'): B=4, 1 warm-up + 3 timed steps (~10-20 s)."""
+    import numpy as np
+    from oracle import zsg_oracle as O
+    B = 4
+    sd = O.seeded_state_dict(arch, 0)
+    params = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    buffers = {k: v.clone() for k, v in sd.items() if k not in params}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4, betas=(0.9, 0.99))
+    bt = O.synthetic_batch(B, img, img, T=tokens, seed=1234)
+    r, s = O.default_ratios_scales()
+    anc = torch.from_numpy(O.create_anchors(O.feat_sizes_for(img, img), r, s).astype(np.float32))
+    times = []
+    for it in range(4):
+        h0, c0 = torch.randn(2, B, 128), torch.randn(2, B, 128)
+        t0 = time.perf_counter()
+        O.cpu_train_step(params, buffers, opt, bt, h0, c0, anc, arch=arch)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[1]
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle.cpu_train_step, {arch} {img}x{img}, B={B}, 1 warm-up + 3 timed steps, median {med:.3f} s/step"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    from zsgnet_pytorch_amd import config, dist as zdist, evaluator, loss, mdl, optim
+    from zsgnet_pytorch_amd._lib import ProfEntry, lib
+    if world > 1:
+        zdist.init_process_group_from_env("nccl")
+
+    cfg = config.get_cfg(resnet_arch=a.arch, bs=a.bs, resize_img=[a.img, a.img])
+    torch.manual_seed(1234)                       # identical initial weights on every rank (and C3 broadcasts anyway)
+    net = mdl.get_default_net(9, cfg).to("cuda")
+    net.train()
+    model = zdist.DistributedDataParallel(net, device_ids=[local], broadcast_buffers=True) if world > 1 else net
+    r, s = config.ratios_scales(cfg)
+    lf, ev = loss.get_default_loss(r, s, cfg), evaluator.get_default_eval(r, s, cfg)
+    opt = optim.FusedAdam(net, lr=cfg["lr"], betas=(0.9, 0.99))
+
+    from oracle.zsg_oracle import synthetic_batch     # the synthetic-input generator only (data, not compute)
+    bt = synthetic_batch(a.bs, a.img, a.img, T=a.tokens, seed=1234 + rank)
+    batch = {k: v.cuda() for k, v in bt.items()}
+    torch.manual_seed(99 + rank)                  # LSTM initial states (mdl.py:279-294) are drawn on the host each step
+
+    def step():
+        opt.zero_grad()
+        out = model(batch)
+        ls = lf(out, batch)
+        ls["loss"].mean().backward()
+        opt.step()
+        return ls, ev(out, batch)
+
+    for _ in range(a.warmup):
+        ls, em = step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ls, em = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val, acc = float(ls["loss"]), float(em["Acc"])
+    ips = a.bs * world * a.steps / dt
+
+    roof, prof_rows = None, []
+    if rank == 0 and not a.no_roofline:
+        lib.zsg_prof_enable(1)
+        nprof = 2
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        lib.zsg_prof_enable(0)
+        arr = (ProfEntry * 64)()
+        n = lib.zsg_prof_collect(arr, 64)
+        tot = sum(arr[i].ms for i in range(n))
+        for i in range(n):
+            e = arr[i]
+            prof_rows.append(dict(kernel=e.name.decode(), launches_per_step=e.launches / nprof, ms_per_step=e.ms / nprof,
+                                  tflops=(e.flops / (e.ms * 1e9)) if e.ms > 0 and e.flops > 0 else None,
+                                  gbps=(e.bytes / (e.ms * 1e6)) if e.ms > 0 and e.bytes > 0 else None,
+                                  share=e.ms / tot if tot else 0))
+        prof_rows.sort(key=lambda x: -x["ms_per_step"])
+        dom = prof_rows[0]
+        if dom["tflops"]:
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": None,
+                    "avg_launch_ms": round(dom["ms_per_step"] / dom["launches_per_step"], 5), "launches_per_step": dom["launches_per_step"],
+                    "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(tot / nprof, 3)}
+        else:
+            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": None}
+        if a.prof_out:
+            with open(a.prof_out, "w") as f:
+                json.dump(prof_rows, f, indent=1)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.arch, a.img, a.tokens)
+
+    if rank == 0:
+        fwd_gf = FWD_GF.get(a.arch) if a.img == 300 else None
+        step_frac = (ips / world) * (3 * fwd_gf) * 1e9 / (PEAK_TF * 1e12) if fwd_gf else None
+        out = {
+            "metric": "train images/sec", "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (img~U[0,1), qvec~N(0,.35), random boxes; random-init weights)",
+            "config": {"workload": f"ZSGNet train step, {a.arch}+FPN, {a.img}x{a.img}, per-GPU bs={a.bs}, {a.tokens}-token queries "
+                                   f"(BASELINE configs[{1 if world == 1 else 2}] shape)", "global_batch": a.bs * world,
+                       "parallelism": f"dp{world}", "step": "zero_grad+fwd+loss+bwd(+allreduce)+adam+eval"},
+            "step_mfma_frac": round(step_frac, 4) if step_frac else None,
+            "final_loss": round(loss_val, 4), "final_acc": acc,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

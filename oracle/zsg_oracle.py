@@ -459,7 +459,7 @@ def query_encoder(sd, qvec, qlens, h0, c0, rank: Optional[torch.Tensor] = None):
 def fuse_lang_grid(feat, we):
     """[feat(256) || we(256) || grid(2: y then x)] -> [B,514,h,w].  Reference mdl.py:69-104."""
     B, _, h, w = feat.shape
-    grid = torch.from_numpy(create_grid(h, w)).view(h, w, 2).permute(2, 0, 1)
+    grid = torch.from_numpy(create_grid(h, w)).view(h, w, 2).permute(2, 0, 1).to(feat.dtype)
     return torch.cat([feat, we.view(B, -1, 1, 1).expand(B, we.shape[1], h, w),
                       grid.unsqueeze(0).expand(B, 2, h, w)], dim=1)
 
@@ -491,10 +491,10 @@ def torch_loss(out, annot, anchors_f32: torch.Tensor, alpha=0.25, gamma=2.0, lam
     att = out["att_out"].squeeze(-1)
     reg = out["bbx_out"]
     anc = anchors_f32.numpy()
-    iou = iou_values(annot.numpy(), anc)
+    iou = iou_values(annot.float().numpy(), anc)
     mask, _ = match_mask(iou, thr, True)
-    t = torch.from_numpy(mask.astype(F32))
-    gt = torch.from_numpy(bbox_to_reg_params(anc, annot.numpy()))
+    t = torch.from_numpy(mask.astype(F32)).to(att.dtype)
+    gt = torch.from_numpy(bbox_to_reg_params(anc, annot.float().numpy())).to(att.dtype)
     box = (F.smooth_l1_loss(reg, gt, reduction="none").sum(2) * t).sum(1) / t.sum(1)
     box = box.mean()
     p = torch.sigmoid(att).detach()

@@ -277,7 +277,8 @@ def test_upsample_add(Z, Hs, Ws, Hd, Wd):
     L.check(L.lib.zsg_upsample_add_fwd(ad.data_ptr(), pd.data_ptr(), B, Hs, Ws, Hd, Wd, Cc, out.data_ptr(), st), "upsample")
     assert torch.equal(out.cpu().permute(0, 3, 1, 2), out_ref.detach())
     dp = torch.empty(B, Hs, Ws, Cc, device="cuda")
-    L.check(L.lib.zsg_upsample_add_bwd(dev(gy.permute(0, 2, 3, 1)).data_ptr(), B, Hs, Ws, Hd, Wd, Cc, dp.data_ptr(), 0, st), "upsample_bwd")
+    gyd = dev(gy.permute(0, 2, 3, 1))
+    L.check(L.lib.zsg_upsample_add_bwd(gyd.data_ptr(), B, Hs, Ws, Hd, Wd, Cc, dp.data_ptr(), 0, st), "upsample_bwd")
     assert_close(dp.permute(0, 3, 1, 2), pr.grad, 1e-6, 1e-6, "upsample bwd")
 
 
@@ -292,35 +293,41 @@ def test_small_ops(Z):
     assert torch.equal(o.cpu(), torch.relu(x))
     gy = torch.randn(x.shape, generator=g)
     dx = dev(torch.ones_like(x))
-    L.check(L.lib.zsg_relu_bwd(dev(gy).data_ptr(), xd.data_ptr(), x.numel(), dx.data_ptr(), 1, st), "relu_bwd")
+    gyd_ = dev(gy)
+    L.check(L.lib.zsg_relu_bwd(gyd_.data_ptr(), xd.data_ptr(), x.numel(), dx.data_ptr(), 1, st), "relu_bwd")
     assert_close(dx, 1 + gy * (x > 0), 1e-6, 1e-6)
     avg = torch.empty(2, 256, device="cuda")
     L.check(L.lib.zsg_avgpool_fwd(xd.data_ptr(), 2, 9, 256, avg.data_ptr(), st), "avgpool")
     assert_close(avg, x.reshape(2, 9, 256).mean(1), 1e-6, 1e-6)
     ga = torch.randn(2, 256, generator=g)
     dxa = torch.empty(2, 9, 256, device="cuda")
-    L.check(L.lib.zsg_avgpool_bwd(dev(ga).data_ptr(), 2, 9, 256, dxa.data_ptr(), 0, st), "avgpool_bwd")
+    gad = dev(ga)
+    L.check(L.lib.zsg_avgpool_bwd(gad.data_ptr(), 2, 9, 256, dxa.data_ptr(), 0, st), "avgpool_bwd")
     assert_close(dxa, (ga / 9)[:, None, :].expand(2, 9, 256), 1e-6, 1e-7)
     img = torch.rand(2, 3, 13, 11, generator=g)
     n4 = torch.empty(2, 13, 11, 4, device="cuda")
-    L.check(L.lib.zsg_nchw_to_nhwc4(dev(img).data_ptr(), 2, 3, 13, 11, n4.data_ptr(), st), "nhwc4")
+    imgd = dev(img)
+    L.check(L.lib.zsg_nchw_to_nhwc4(imgd.data_ptr(), 2, 3, 13, 11, n4.data_ptr(), st), "nhwc4")
     assert torch.equal(n4.cpu()[..., :3], img.permute(0, 2, 3, 1)) and float(n4[..., 3].abs().max()) == 0
     # fuse_lang_grid == oracle.fuse_lang_grid (channel order feat | we | y | x)
     feat, we = torch.randn(2, 256, 5, 3, generator=g), torch.randn(2, 256, generator=g)
     ref = O.fuse_lang_grid(feat, we).permute(0, 2, 3, 1)
     grid = O.create_grid(5, 3).reshape(5, 3, 2)
     out = torch.full((2, 5, 3, 516), float("nan"), device="cuda")
-    L.check(L.lib.zsg_fuse_lang_grid(dev(feat.permute(0, 2, 3, 1)).data_ptr(), dev(we).data_ptr(), dev(torch.from_numpy(grid[:, 0, 0].copy())).data_ptr(),
-                                     dev(torch.from_numpy(grid[0, :, 1].copy())).data_ptr(), 2, 5, 3, 256, 256, 1, 516, out.data_ptr(), st), "fuse")
+    fd, wed = dev(feat.permute(0, 2, 3, 1)), dev(we)
+    gyd, gxd = dev(torch.from_numpy(grid[:, 0, 0].copy())), dev(torch.from_numpy(grid[0, :, 1].copy()))
+    L.check(L.lib.zsg_fuse_lang_grid(fd.data_ptr(), wed.data_ptr(), gyd.data_ptr(), gxd.data_ptr(), 2, 5, 3, 256, 256, 1, 516, out.data_ptr(), st), "fuse")
     assert torch.equal(out.cpu()[..., :514], ref) and float(out[..., 514:].abs().max()) == 0
     # pad_rows / colsum per group
     src = torch.randn(7, 45, generator=g)
     dst = torch.full((7, 48), float("nan"), device="cuda")
-    L.check(L.lib.zsg_pad_rows(dev(src).data_ptr(), 7, 45, 45, dst.data_ptr(), 48, st), "pad_rows")
+    srcd = dev(src)
+    L.check(L.lib.zsg_pad_rows(srcd.data_ptr(), 7, 45, 45, dst.data_ptr(), 48, st), "pad_rows")
     assert torch.equal(dst.cpu()[:, :45], src) and float(dst[:, 45:].abs().max()) == 0
     big = torch.randn(3, 700, 40, generator=g)
     cs = torch.zeros(3, 16, device="cuda")
-    L.check(L.lib.zsg_colsum(dev(big).data_ptr(), 3, 700 * 40, 700, 40, 8, 16, cs.data_ptr(), 0, st), "colsum")
+    bigd = dev(big)
+    L.check(L.lib.zsg_colsum(bigd.data_ptr(), 3, 700 * 40, 700, 40, 8, 16, cs.data_ptr(), 0, st), "colsum")
     assert_close(cs, big[:, :, 8:24].sum(1), 1e-4, 1e-4)
 
 
@@ -337,7 +344,8 @@ def test_l2norm(Z):
     st = L.stream_ptr()
     L.check(L.lib.zsg_l2norm_fwd(xd.data_ptr(), 50, 512, out.data_ptr(), nrm.data_ptr(), st), "l2norm")
     assert_close(out, y, 1e-5, 1e-6)
-    L.check(L.lib.zsg_l2norm_bwd(dev(gy).data_ptr(), out.data_ptr(), nrm.data_ptr(), 50, 512, dx.data_ptr(), st), "l2norm_bwd")
+    gyd = dev(gy)
+    L.check(L.lib.zsg_l2norm_bwd(gyd.data_ptr(), out.data_ptr(), nrm.data_ptr(), 50, 512, dx.data_ptr(), st), "l2norm_bwd")
     assert_close(dx, xr.grad, 1e-4, 1e-5)
 
 
@@ -354,7 +362,8 @@ def test_adam_matches_torch(Z):
         gr = torch.randn(n, generator=g)
         pr.grad = gr.clone()
         opt.step()
-        L.check(L.lib.zsg_adam_step(pd.data_ptr(), dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.99, 1e-8, 0.0, 1.0,
+        grd = dev(gr)
+        L.check(L.lib.zsg_adam_step(pd.data_ptr(), grd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.99, 1e-8, 0.0, 1.0,
                                     step.data_ptr(), L.stream_ptr()), "adam")
     assert int(step.item()) == 5
     assert_close(pd, pr.detach(), 1e-5, 1e-6, "adam params")

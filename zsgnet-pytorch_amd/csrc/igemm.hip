@@ -157,8 +157,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tile();
-    store_tile(0);
+    if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
+        load_tile();
+        store_tile(0);
+    }
     __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;

@@ -1,0 +1,147 @@
+"""Data parallelism for the MI355X ZSGNet step: one process per GPU, gradients all-reduced with RCCL over xGMI.
+
+Reference: main_dist.py:36-40 wraps the model in torch DistributedDataParallel (NCCL, broadcast_buffers=True); the
+collectives are C1-C3 of SURVEY.md §2.2.  Here the gradients already live in ONE flat buffer in parameter order, so the
+reducer is a handful of large in-place all-reduces on contiguous slices ("buckets", a few tens of MB each: xGMI is
+point-to-point, ring collectives are per-link bound, so few large messages beat many small ones).  A bucket is launched
+as soon as the last backward launch that writes into it has been enqueued, on RCCL's own stream (torch.distributed
+fences it against the compute stream with events), so communication overlaps the rest of backward; the optimizer waits
+on all of them.  The same code runs on CPU tensors over gloo, which is how it is tested without GPUs.
+"""
+import os
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_main_process() -> bool:
+    return get_rank() == 0
+
+
+def synchronize():
+    """utils.py:47-59"""
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def init_process_group_from_env(backend: Optional[str] = None):
+    """env:// rendezvous (torchrun / torch.distributed.launch): RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT, LOCAL_RANK."""
+    if dist.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, init_method="env://")
+
+
+@dataclass
+class Bucket:
+    start: int          # element range [start, end) of the flat gradient buffer
+    end: int
+    ready: int          # index of the last backward launch that writes into the range (-1: nothing writes)
+
+
+def plan_buckets(spans: Sequence[Tuple[int, int, int]], target_elems: int) -> List[Bucket]:
+    """spans: (offset, size, ready_index) per parameter in flat order.  Adjacent parameters are merged while they
+    become ready together (their ready indices are within the same backward phase) up to ~target_elems; the result
+    covers the flat buffer exactly once and is sorted by readiness so buckets are launched in completion order."""
+    buckets: List[Bucket] = []
+    cur: Optional[Bucket] = None
+    for off, size, ready in sorted(spans):
+        if cur is not None and cur.end == off and (cur.end - cur.start) < target_elems:
+            cur.end = off + size
+            cur.ready = max(cur.ready, ready)
+        else:
+            if cur is not None:
+                buckets.append(cur)
+            cur = Bucket(off, off + size, ready)
+    if cur is not None:
+        buckets.append(cur)
+    return sorted(buckets, key=lambda b: b.ready)
+
+
+class BucketReducer:
+    """Sum-all-reduce of a flat buffer in buckets, interleaved with a list of launches."""
+
+    def __init__(self, flat: torch.Tensor, buckets: List[Bucket], group=None):
+        self.flat, self.buckets, self.group = flat, buckets, group
+        self.pending = []
+
+    def run(self, n_launches: int, launch_range: Callable[[int, int], None]):
+        """launch_range(i, j) enqueues launches [i, j).  After the launch with index b.ready, bucket b is reduced."""
+        done = 0
+        for b in self.buckets:
+            upto = min(max(b.ready + 1, done), n_launches)
+            if upto > done:
+                launch_range(done, upto)
+                done = upto
+            self.pending.append(dist.all_reduce(self.flat[b.start:b.end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if done < n_launches:
+            launch_range(done, n_launches)
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+class DistributedDataParallel(nn.Module):
+    """Drop-in for torch.nn.parallel.DistributedDataParallel(mdl, device_ids=[local_rank], broadcast_buffers=True) at
+    main_dist.py:36-40, specialised to the flat-buffer ZSGNet: parameters are broadcast from rank 0 at construction
+    (C3), BatchNorm running statistics before every training forward (C2), gradients are averaged by the bucketed
+    reducer during backward (C1)."""
+
+    def __init__(self, module: nn.Module, device_ids=None, output_device=None, broadcast_buffers: bool = True,
+                 find_unused_parameters: bool = False, bucket_mb: float = 32.0, process_group=None):
+        super().__init__()
+        self.module = module
+        self.broadcast_buffers = broadcast_buffers
+        self.group = process_group
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.world = get_world_size()
+        module._ddp = self
+        if self.world > 1:
+            dist.broadcast(module.store.flat, src=0, group=self.group)
+            self._sync_buffers()
+
+    def _sync_buffers(self):
+        m = self.module
+        dist.broadcast(m._rm, src=0, group=self.group)
+        dist.broadcast(m._rv, src=0, group=self.group)
+        dist.broadcast(m._nbt, src=0, group=self.group)
+
+    def forward(self, inp):
+        if self.world > 1 and self.broadcast_buffers and self.module.training:
+            self._sync_buffers()
+        return self.module(inp)
+
+    def make_reducer(self, spans) -> BucketReducer:
+        return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems), self.group)
+
+
+def reduce_dict(input_dict, average=False):
+    """utils.py:62-91: stack the scalar values and reduce them to rank 0 (C4)."""
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k].detach().float().reshape(()) for k in names], dim=0)
+        dist.reduce(values, dst=0)
+        if dist.get_rank() == 0 and average:
+            values /= world
+        return {k: v for k, v in zip(names, values)}

@@ -339,6 +339,8 @@ class _Plan:
         self.acts: Dict[str, Act] = {}
         self.bytes = 0
         self.wt: Dict[str, torch.Tensor] = {}
+        self.grad_ready: Dict[str, int] = {}
+        self.reducer = None
         self._lower()
 
     # ---- allocation helpers --------------------------------------------------------------------------------
@@ -383,6 +385,8 @@ class _Plan:
         return self.net.store.raw(name)
 
     def G(self, name):
+        """gradient storage of a parameter; remembers the last backward launch that writes it (bucket readiness)"""
+        self.grad_ready[name] = len(self.bwd.calls)
         return self.net.store.raw(name, self.net.store.grad)
 
     # ---- op lowering ---------------------------------------------------------------------------------------------
@@ -670,14 +674,37 @@ class _Plan:
             self.fwd.add(lib.zsg_fuse_lang_grid, feats[i].buf[feats[i].levels[0].off:] if Cf else None, we.buf if Cw else None, gy, gx, B, h, w,
                          Cf, Cw, int(net.use_grid), ld0, F0.buf[l.off:], what=f"fuse{i}")
         L0 = C["att_reg_box.0.0"]
-        h = self.packed("head.h1", B, sizes, 256)
-        self.conv(L0, F0, relu=True, out=h)
-        self.tape.pop()                     # replaced by the split backward below
-        h1 = h
+        h1 = self.packed("head.h1", B, sizes, 256)
+        self.conv(L0, F0, relu=True, out=h1)
+        self.tape.pop()                     # conv0's backward is split by hand (feature / language halves)
+
+        def head0_back():
+            dy = h1.grad
+            if dy is None:
+                return
+            dw0 = fwd_desc(F0, dy, L0.cpad, 256, 3, 1, 1, 1, wC=L0.cpad)
+            self.bwd.add(lib.zsg_conv_wgrad, dw0, F0.buf, dy.buf, self.G(L0.name + ".weight"), what="wgrad:head0")
+            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0")
+            if Cf:                          # the grid channels are constants: no data gradient for them
+                dF = self.packed("head.dfeat", B, sizes, Cf)
+                self.dgrad(L0, dy, F0, n=Cf, row0=0, dx=dF)
+                for i, f in enumerate(feats):
+                    assert f.grad is None
+                    f.grad = dF.lvl(i)
+                    f.grad.gfilled = True
+            if Cw:
+                dWe = self.packed("head.dwe", B, sizes, Cw)
+                self.dgrad(L0, dy, F0, n=Cw, row0=Cf, dx=dWe)
+                gwe = self.grad_of(we)
+                for i, (hh, ww) in enumerate(sizes):
+                    l = dWe.levels[i]
+                    self.bwd.add(lib.zsg_colsum, dWe.buf[l.off:], B, hh * ww * Cw, hh * ww, Cw, 0, Cw, gwe.buf, int(i > 0), what=f"dwe{i}")
+                gwe.gfilled = True
+        self.tape.append(head0_back)
         hs = [h1]
         for i in range(1, 5):
             nxt = self.packed(f"head.h{i + 1}", B, sizes, 256)
-            self.conv(C[f"att_reg_box.{i}.0"], hs[-1], relu=True, out=nxt)
+            self.conv(C[f"att_reg_box.{i}.0"], hs[-1], relu=True, out=nxt)      # backward via the tape
             hs.append(nxt)
         L5 = C["att_reg_box.5"]
         nout = L5.cout
@@ -694,7 +721,7 @@ class _Plan:
         self.tape.pop()
         if not self.training:
             return
-        # ---- head backward (emitted first: the tape is replayed in reverse, so push it last) -----------------------
+        # ---- last conv backward: the incoming [B,A,5] gradient is re-packed to 48 channels (16-byte GEMM rows) ------
         npad = pad4(nout)
         lvp, off = [], 0
         for (hh, ww) in sizes:
@@ -704,36 +731,13 @@ class _Plan:
         g5p = Act(self._buf(B * P * npad), B, npad, npad, lvp, "g5p")
         h5 = hs[-1]
 
-        def head_back():
+        def head5_back():
             self.bwd.add(lib.zsg_pad_rows, self.g5_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
             self.bwd.add(lib.zsg_colsum, self.g5_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:head5")
             dw = fwd_desc(h5, g5p, L5.cpad, nout, 3, 1, 1, 1, wC=L5.cpad)
             self.bwd.add(lib.zsg_conv_wgrad, dw, h5.buf, g5p.buf, self.G(L5.name + ".weight"), what="wgrad:head5")
             self.dgrad(L5, g5p, h5, n=256)
-            for i in range(4, 0, -1):
-                self._conv_bwd(C[f"att_reg_box.{i}.0"], hs[i - 1], hs[i])
-            # conv0: weight/bias gradient over the full 514(+pad) channels; data gradient split into the feature and
-            # the language halves (the grid channels are constants)
-            dy = h1.grad
-            dw0 = fwd_desc(F0, dy, L0.cpad, 256, 3, 1, 1, 1, wC=L0.cpad)
-            self.bwd.add(lib.zsg_conv_wgrad, dw0, F0.buf, dy.buf, self.G(L0.name + ".weight"), what="wgrad:head0")
-            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0")
-            if Cf:
-                dF = self.packed("head.dfeat", B, sizes, Cf)
-                self.dgrad(L0, dy, F0, n=Cf, row0=0, dx=dF)
-                for i, f in enumerate(feats):
-                    assert f.grad is None
-                    f.grad = dF.lvl(i)
-                    f.grad.gfilled = True
-            if Cw:
-                dWe = self.packed("head.dwe", B, sizes, Cw)
-                self.dgrad(L0, dy, F0, n=Cw, row0=Cf, dx=dWe)
-                gwe = self.grad_of(we)
-                for i, (hh, ww) in enumerate(sizes):
-                    l = dWe.levels[i]
-                    self.bwd.add(lib.zsg_colsum, dWe.buf[l.off:], B, hh * ww * Cw, hh * ww, Cw, 0, Cw, gwe.buf, int(i > 0), what=f"dwe{i}")
-                gwe.gfilled = True
-        self.tape.append(head_back)
+        self.tape.append(head5_back)
 
     # ---- execution -------------------------------------------------------------------------------------------------------
     def run_forward(self, img, qvec, qlens, h0, c0) -> torch.Tensor:
@@ -767,8 +771,20 @@ class _Plan:
         if fresh:
             lib.zsg_memset_f32(net.store.grad.data_ptr(), net.store.grad.numel(), 0.0, st)
         self.g5_in.view_as(g5).copy_(g5)
+        ddp = getattr(net, "_ddp", None)
         self.prep.run(st)
-        self.bwd.run(st)
+        if ddp is not None and ddp.world > 1:
+            # average over ranks: pre-scale the incoming gradient (backward is linear), then SUM-all-reduce buckets as
+            # soon as the launches that fill them are enqueued; the optimizer waits through wait_gradients().
+            self.g5_in.mul_(1.0 / ddp.world)
+            if self.reducer is None:
+                ents = net.store.entries
+                spans = [(ents[n].offset, (ents[n].size + 3) // 4 * 4, self.grad_ready.get(n, -1)) for n in net._param_names]
+                self.reducer = ddp.make_reducer(spans)
+            self.reducer.run(len(self.bwd.calls), lambda i, j: self.bwd.run(st, i, j))
+            self.reducer.wait()
+        else:
+            self.bwd.run(st)
         if not fresh:
             return [None] * len(params)      # gradients were accumulated in place into the tensors p.grad already views
         return [net.store.view(n, net.store.grad) for n in net._param_names]

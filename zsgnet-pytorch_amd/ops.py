@@ -5,6 +5,7 @@ geometry, so one training step is just a loop of foreign calls on torch's curren
 host<->device synchronisation — and the whole list can be captured into a hipGraph.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -162,9 +163,18 @@ class Program:
         assert len(args) == len(fn.argtypes) - 1, f"{fn.__name__}: {len(args)} args for {len(fn.argtypes) - 1}"
         self.calls.append((fn, tuple(conv), what or fn.__name__))
 
-    def run(self, stream: int):
+    def run(self, stream: int, start: int = 0, stop: Optional[int] = None):
         st = C.c_void_p(stream)
-        for fn, args, what in self.calls:
+        calls = self.calls if (start == 0 and stop is None) else self.calls[start:stop]
+        if os.environ.get("ZSG_DEBUG_SYNC"):          # locate a faulting launch: name it, run it, synchronise
+            for fn, args, what in calls:
+                print(f"[zsg] {self.name}/{what}", flush=True)
+                rc = fn(*args, st)
+                if rc:
+                    raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
+                torch.cuda.synchronize()
+            return
+        for fn, args, what in calls:
             rc = fn(*args, st)
             if rc:
                 raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
