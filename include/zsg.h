@@ -77,12 +77,13 @@ typedef struct {
     int32_t relu;         /* epilogue: max(.,0)                                                             */
     int32_t merge_x;      /* 1: C==4 and all x-taps of a row are one contiguous run (stem / RGB input)       */
     int32_t nseg;
-    int32_t tile_hint;    /* 0 auto, else (BM<<16)|BN                                                       */
+    int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16); chosen by the host autotuner     */
     zsg_seg seg[ZSG_MAX_SEG];
 } zsg_conv_desc;
 
 /* out = epilogue( sum_taps src * wt ) ;  epilogue: + bias[n] ; + add_src[same index as out] ; relu ;
- * * (mask_src[same index] > 0).   bias / add_src / mask_src may be NULL.  add_src may alias out (accumulate). */
+ * * (mask_src[same index] > 0).   bias / add_src / mask_src may be NULL.  add_src may alias out (accumulate).
+ * split_k > 1 (single dense segment, no ReLU): K slices are combined with fp32 atomics (output zeroed by the call). */
 int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
                    const float* add_src, const float* mask_src, void* stream);
 

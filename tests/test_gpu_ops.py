@@ -73,9 +73,11 @@ CONV_CASES = [
     (2, 256, 45, 10, 10, 3, 1, 1, 1, True, False, False, 0),
     (1, 64, 96, 12, 12, 3, 1, 6, 6, True, False, False, 0),
     (2, 128, 256, 5, 5, 3, 1, 0, 1, True, True, False, 0),
-    (2, 64, 256, 16, 16, 1, 1, 0, 1, False, False, False, (128 << 16) | 128),
-    (2, 64, 256, 16, 16, 3, 1, 1, 1, False, False, False, (128 << 16) | 64),
-    (2, 64, 256, 16, 16, 3, 1, 1, 1, False, False, False, (64 << 16) | 64),
+    (2, 64, 256, 16, 16, 1, 1, 0, 1, False, False, False, 128 | (128 << 8)),
+    (2, 64, 256, 16, 16, 3, 1, 1, 1, False, False, False, 128 | (64 << 8)),
+    (2, 64, 256, 16, 16, 3, 1, 1, 1, False, False, False, 64 | (64 << 8)),
+    (2, 64, 256, 16, 16, 3, 1, 1, 1, True, True, False, 128 | (128 << 8) | (1 << 24)),
+    (2, 96, 64, 16, 16, 3, 1, 1, 1, True, False, False, 128 | (64 << 8) | (1 << 24)),
     (16, 300, 512, 1, 20, 1, 1, 0, 1, True, False, False, 0),
 ]
 
@@ -133,6 +135,8 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
         dx = torch.full((B, H, W, cp), float("nan"), device="cuda")
         dxv = view_of(ops, dx, B, H, W, cp)
         ddesc = ops.dgrad_desc(dyv, dxv, Cop, cp, k, s, p, d)
+        if ddesc.zero_fill:              # parity classes without any tap are not launched: the caller clears dx
+            dx.zero_()
         L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, st), "dgrad")
         assert_close(dx[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), "conv dgrad")
         # accumulate + relu-mask epilogue: out = (prev + acc) * (mask > 0)
@@ -141,7 +145,21 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
         dx2, maskd = dev(prev), dev(mask)
         L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx2.data_ptr(), None, dx2.data_ptr(), maskd.data_ptr(), st), "dgrad+")
         ref2 = (prev[..., :Ci] + xr.grad.permute(0, 2, 3, 1)) * (mask[..., :Ci] > 0)
-        assert_close(dx2[..., :Ci], ref2, 5e-4, 5e-4 * float(ref2.abs().max()), "dgrad accumulate+mask")
+        if not ddesc.zero_fill:          # (dropped parity classes are neither accumulated nor masked: never needed)
+            assert_close(dx2[..., :Ci], ref2, 5e-4, 5e-4 * float(ref2.abs().max()), "dgrad accumulate+mask")
+        # split-K variants (fp32 atomics) of the same data gradient
+        for sp in (2, 5):
+            dx3 = torch.full((B, H, W, cp), float("nan"), device="cuda")
+            if ddesc.nseg == 1 and s == 1:
+                d3 = ops.dgrad_desc(dyv, view_of(ops, dx3, B, H, W, cp), Cop, cp, k, s, p, d, tile_hint=ops.tile_hint(64, 64, sp))
+                L.check(L.lib.zsg_conv_igemm(C.byref(d3), dyd.data_ptr(), wt.data_ptr(), dx3.data_ptr(), None, None, None, st), "dgrad split-K")
+                assert_close(dx3[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), f"conv dgrad split-K {sp}")
+    if not relu:
+        for sp in (3, 8):
+            out3 = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+            d3 = ops.fwd_desc(src, view_of(ops, out3, B, Ho, Wo, Co), cp, Co, k, s, p, d, wC=cp, merge_x=mx, tile_hint=ops.tile_hint(64, 64, sp))
+            L.check(L.lib.zsg_conv_igemm(C.byref(d3), xd.data_ptr(), wd.data_ptr(), out3.data_ptr(), bd.data_ptr() if bias else None, None, None, st), "fwd split-K")
+            assert_close(out3.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, f"conv fwd split-K {sp}")
     torch.cuda.synchronize()
 
 

@@ -80,15 +80,45 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows, float* mean,
-                                         float* invstd, float* rmean, float* rvar, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int k = 0; k < chunks; ++k) {
-        s += (double)part[(size_t)k * 2 * C + c];
-        ss += (double)part[(size_t)k * 2 * C + C + c];
+// Finalize: 8 channels x 32 chunk-lanes per block; each thread strides over the chunk partials (independent loads in
+// flight instead of one serial latency chain per channel), fp64 LDS tree across the 32 lanes.
+#define BN_FC 8
+#define BN_FK 32
+__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int chunks, int C, int c, int kl, double& s, double& ss,
+                                                   double (*sm)[BN_FK][BN_FC]) {
+    s = 0;
+    ss = 0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = kl; k < chunks; k += BN_FK) {
+            s += (double)part[(size_t)k * 2 * C + c];
+            ss += (double)part[(size_t)k * 2 * C + C + c];
+        }
     }
+    const int cl = threadIdx.x % BN_FC;
+    sm[0][kl][cl] = s;
+    sm[1][kl][cl] = ss;
+    __syncthreads();
+    for (int o = BN_FK / 2; o > 0; o >>= 1) {
+        if (kl < o) {
+            sm[0][kl][cl] += sm[0][kl + o][cl];
+            sm[1][kl][cl] += sm[1][kl + o][cl];
+        }
+        __syncthreads();
+    }
+    s = sm[0][0][cl];
+    ss = sm[1][0][cl];
+}
+
+__global__ __launch_bounds__(BN_FC * BN_FK) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
+                                                                          float* mean, float* invstd, float* rmean, float* rvar,
+                                                                          float momentum, float eps) {
+    __shared__ double sm[2][BN_FK][BN_FC];
+    const int c = blockIdx.x * BN_FC + threadIdx.x % BN_FC;
+    const int kl = threadIdx.x / BN_FC;
+    double s, ss;
+    bn_reduce_partials(part, chunks, C, c, kl, s, ss, sm);
+    if (kl != 0 || c >= C) return;
     const double n = (double)rows;
     const double m = s / n;
     double var = ss / n - m * m;
@@ -131,15 +161,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // coef[0][c] = sum g / n ; coef[1][c] = sum g*xhat / n ; dgamma/dbeta written or accumulated.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows, float* coef,
-                                       float* dgamma, float* dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int k = 0; k < chunks; ++k) {
-        s += (double)part[(size_t)k * 2 * C + c];
-        ss += (double)part[(size_t)k * 2 * C + C + c];
-    }
+__global__ __launch_bounds__(BN_FC * BN_FK) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
+                                                                        float* coef, float* dgamma, float* dbeta, int accumulate) {
+    __shared__ double sm[2][BN_FK][BN_FC];
+    const int c = blockIdx.x * BN_FC + threadIdx.x % BN_FC;
+    const int kl = threadIdx.x / BN_FC;
+    double s, ss;
+    bn_reduce_partials(part, chunks, C, c, kl, s, ss, sm);
+    if (kl != 0 || c >= C) return;
     coef[c] = (float)(s / (double)rows);
     coef[C + c] = (float)(ss / (double)rows);
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
@@ -185,7 +214,7 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     float* part = (float*)ws;
     hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, g.chunks, C, rows, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -224,7 +253,7 @@ extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const f
     float* coef = part + (size_t)g.chunks * 2 * C;
     hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, mean, invstd, rows, C,
                        g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, x, rows, C, mean, invstd, gamma,
                        coef, dx, g_out, g.lanes, g.rpb);

@@ -33,15 +33,22 @@ struct IgParams {
     const float* mask_src;
     int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, relu, nseg;
     int m_tiles, n_tiles;
+    int splits;       // split-K factor (1: plain stores; >1: fp32 atomic accumulation into a zeroed / pre-filled output)
+    int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
+    int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     IgSegDev seg[ZSG_MAX_SEG];
 };
 
-template <int BM, int BN, bool MERGE_X>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
-    constexpr int RA = BM / 32;          // A rows staged per thread
-    constexpr int RB = BN / 32;          // B rows staged per thread
-    constexpr int TM = BM / 64;          // 32x32 MFMA tiles per wave along M (waves 2x2)
-    constexpr int TN = BN / 64;
+// BM x BN block tile computed by WM x WN waves (each wave: TM x TN MFMA tiles of 32x32).
+template <int BM, int BN, int WM, int WN, bool MERGE_X>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
+    constexpr int NT = 64 * WM * WN;     // threads
+    constexpr int RP = NT / 8;           // tile rows staged per pass (8 threads x 16 B cover one 32-float row)
+    constexpr int RA = BM / RP;          // A rows staged per thread
+    constexpr int RB = BN / RP;          // B rows staged per thread
+    constexpr int TM = BM / WM / 32;     // 32x32 MFMA tiles per wave along M
+    constexpr int TN = BN / WN / 32;
+    static_assert(RA >= 1 && RB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [2][BM][IG_LDK]
     float* Bs = smem + 2 * BM * IG_LDK;                // [2][BN][IG_LDK]
@@ -49,11 +56,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int g = tid & 7;               // 16-byte k-group staged by this thread
     const int r0 = tid >> 3;             // first staged row
 
-    const int bid = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+    const int n_tiles_mn = p.m_tiles * p.n_tiles;
+    const int split = blockIdx.x / n_tiles_mn;
+    const int bid0 = blockIdx.x - split * n_tiles_mn;
+    const int bid = p.remap ? xcd_remap(bid0, n_tiles_mn) : bid0;
     const int mt = bid / p.n_tiles, nt = bid % p.n_tiles;
     int si = 0;
 #pragma unroll
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     int a_by[RA], a_bx[RA], a_off[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        const int m = m0 + r0 + 32 * j;
+        const int m = m0 + r0 + RP * j;
         const bool ok = m < sg.rows;
         const int mm = ok ? m : 0;
         const int per = sg.rows_y * sg.rows_x;
@@ -80,25 +90,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         a_bx[j] = x * sg.sx + sg.tx.d0;
         a_off[j] = sg.src_off + b * sg.src_bstride;
         if (g == 0)
-            rowout[r0 + 32 * j] =
+            rowout[r0 + RP * j] =
                 ok ? sg.out_off + b * sg.out_bstride + ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld
                    : -1;
     }
     int b_off[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int n = n0 + r0 + 32 * j;
+        const int n = n0 + r0 + RP * j;
         b_off[j] = (n < p.N) ? n * p.wt_ld + p.wc0 : -1;
     }
 
     const int n_cc = MERGE_X ? 1 : (p.C + IG_BK - 1) / IG_BK;
     const int n_jx = MERGE_X ? 1 : sg.tx.n;
-    const int n_it = sg.ty.n * n_jx * n_cc;
+    const int n_it_all = sg.ty.n * n_jx * n_cc;
+    int it0 = 0, n_it = n_it_all;
+    if (p.splits > 1) {                  // this block's slice of the K iterations
+        const int per = (n_it_all + p.splits - 1) / p.splits;
+        it0 = min(split * per, n_it_all);
+        n_it = min(per, n_it_all - it0);
+    }
 
     f32x4 ra[RA], rb[RB];
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.wt);
-    int jy = 0, jx = 0, cc = 0;          // K-iteration counters of the NEXT tile to load (wave-uniform)
+    // K-iteration counters of the NEXT tile to load (wave-uniform)
+    int cc = it0 % n_cc;
+    int jx = (it0 / n_cc) % n_jx;
+    int jy = it0 / (n_cc * n_jx);
 
     auto load_tile = [&]() {
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
@@ -144,9 +163,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         float* a = As + buf * BM * IG_LDK;
         float* b = Bs + buf * BN * IG_LDK;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *(f32x4*)(a + (r0 + 32 * j) * IG_LDK + 4 * g) = ra[j];
+        for (int j = 0; j < RA; ++j) *(f32x4*)(a + (r0 + RP * j) * IG_LDK + 4 * g) = ra[j];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) *(f32x4*)(b + (r0 + 32 * j) * IG_LDK + 4 * g) = rb[j];
+        for (int j = 0; j < RB; ++j) *(f32x4*)(b + (r0 + RP * j) * IG_LDK + 4 * g) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -164,8 +183,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;
-    const int a_row = wm * (BM / 2) + li;
-    const int b_row = wn * (BN / 2) + li;
+    const int a_row = wm * (BM / WM) + li;
+    const int b_row = wn * (BN / WN) + li;
 
     for (int it = 0; it < n_it; ++it) {
         const bool more = (it + 1) < n_it;
@@ -194,22 +213,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     // ---- epilogue: bias, residual add, relu, relu-mask ---------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + li;
+        const int n = n0 + wn * (BN / WN) + j * 32 + li;
         const bool nok = n < p.N;
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int ro = rowout[row];
                 if (ro >= 0 && nok) {
-                    float v = acc[i][j][e] + bv;
                     const size_t o = (size_t)ro + n;
-                    if (p.add_src) v += p.add_src[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
-                    p.out[o] = v;
+                    if (p.splits > 1) {          // split-K: every term of the epilogue is linear (no ReLU here)
+                        float v = acc[i][j][e];
+                        if (split == 0) {
+                            v += bv;
+                            if (p.add_src && !p.add_is_out) v += p.add_src[o];
+                        }
+                        if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
+                        unsafeAtomicAdd(p.out + o, v);
+                    } else {
+                        float v = acc[i][j][e] + bv;
+                        if (p.add_src) v += p.add_src[o];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
+                        p.out[o] = v;
+                    }
                 }
             }
         }
@@ -251,33 +280,43 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
     }
     p.m_tiles = tiles;
     p.n_tiles = cdiv(d->N, BN);
+    p.remap = 1;
+    for (int s = 1; s < d->nseg; ++s)
+        if (d->seg[s].ty.n * d->seg[s].tx.n != d->seg[0].ty.n * d->seg[0].tx.n) p.remap = 0;   // unequal K work: keep round-robin
     if (flops) *flops = fl;
     return 0;
 }
 
-template <int BM, int BN, bool MX>
+template <int BM, int BN, int WM, int WN, bool MX>
 static int launch_cfg(const IgParams& p, hipStream_t st) {
     const size_t lds = (size_t)2 * (BM + BN) * IG_LDK * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;      // idempotent; a benign race sets it twice
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, MX>), dim3(p.m_tiles * p.n_tiles), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
 
-// cost model: blocks are issued in rounds of one per CU; small tiles pay more operand traffic per MFMA.
-static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN) {
+// tile_hint = BM | (BN << 8) | (splits << 16); 0 = heuristic.  The Python lowering autotunes the hint per layer on
+// the device (measure, don't guess); the heuristic below is the fallback: blocks go out in rounds of one per CU and the
+// 64x64 tile (4 resident blocks per CU) hides latency best.
+static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int* w8) {
+    *splits = 1;
+    *w8 = 0;
     if (d->tile_hint) {
-        *BM = d->tile_hint >> 16;
-        *BN = d->tile_hint & 0xffff;
+        *BM = d->tile_hint & 0xff;
+        *BN = (d->tile_hint >> 8) & 0xff;
+        *splits = (d->tile_hint >> 16) & 0xff;
+        *w8 = (d->tile_hint >> 24) & 1;          // 8-wave workgroup variant
+        if (*splits < 1) *splits = 1;
         return;
     }
-    static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    static const double eff[3] = {1.0, 0.93, 0.86};
+    static const int cand[3][2] = {{64, 64}, {128, 64}, {128, 128}};
+    static const double eff[3] = {1.0, 0.85, 0.82};
     double best = 1e300;
     for (int c = 0; c < 3; ++c) {
         const int bm = cand[c][0], bn = cand[c][1];
@@ -297,25 +336,39 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN) {
 extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
                               const float* add_src, const float* mask_src, void* stream) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
-    int BM = 128, BN = 128;
-    pick_tile(d, &BM, &BN);
+    int BM = 64, BN = 64, splits = 1, w8 = 0;
+    pick_tile(d, &BM, &BN, &splits, &w8);
+    if (d->merge_x && BN == 128) BN = 64;
     IgParams p;
     memset(&p, 0, sizeof(p));
     double flops = 0;
     int rc = fill_params(d, p, BM, BN, &flops);
     if (rc) return rc;
     p.src = src; p.wt = wt; p.out = out; p.bias = bias; p.add_src = add_src; p.mask_src = mask_src;
+    p.splits = splits;
+    p.add_is_out = (add_src == out) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    if (splits > 1) {
+        ZSG_REQUIRE(!d->relu && d->nseg == 1 && d->out_ld == d->N && d->seg[0].osy == 1 && d->seg[0].osx == 1 &&
+                        d->seg[0].out_W == d->seg[0].rows_x && d->seg[0].out_bstride == (int64_t)d->seg[0].rows_y * d->seg[0].rows_x * d->N,
+                    "conv_igemm: split-K needs a single dense segment without ReLU");
+        if (!p.add_is_out) {
+            hipError_t e = hipMemsetAsync(out + d->seg[0].out_off, 0, (size_t)d->B * d->seg[0].out_bstride * sizeof(float), st);
+            if (e != hipSuccess) ZSG_FAIL(-3, "conv_igemm: memset: %s", hipGetErrorString(e));
+        }
+    }
     ZSG_PROF("conv_igemm", st, flops, 0);
     if (d->merge_x) {
-        if (BM == 128 && BN == 64) return launch_cfg<128, 64, true>(p, st);
-        if (BM == 64 && BN == 64) return launch_cfg<64, 64, true>(p, st);
-        // merge_x layers have N <= 64 in every supported model; fall back to the narrow tile
-        fill_params(d, p, 128, 64, nullptr);
-        return launch_cfg<128, 64, true>(p, st);
+        if (BM == 128) return launch_cfg<128, 64, 2, 2, true>(p, st);
+        return launch_cfg<64, 64, 2, 2, true>(p, st);
     }
-    if (BM == 128 && BN == 128) return launch_cfg<128, 128, false>(p, st);
-    if (BM == 128 && BN == 64) return launch_cfg<128, 64, false>(p, st);
-    if (BM == 64 && BN == 64) return launch_cfg<64, 64, false>(p, st);
+    if (w8) {
+        if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 4, false>(p, st);
+        if (BM == 128 && BN == 64) return launch_cfg<128, 64, 4, 2, false>(p, st);
+        ZSG_FAIL(-1, "conv_igemm: no 8-wave variant for tile %dx%d", BM, BN);
+    }
+    if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 2, false>(p, st);
+    if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2, false>(p, st);
+    if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2, false>(p, st);
     ZSG_FAIL(-1, "conv_igemm: unsupported tile %dx%d", BM, BN);
 }

@@ -249,12 +249,19 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
         rows_all += (double)rows;
     }
     p.kt_total = kt;
-    const int TM = (d->N > 64) ? 2 : 1;
-    const int TN = (p.ncols > 64) ? 2 : 1;
+    // tile_hint = BM | (BN << 8) | (splits << 16) (BM over output channels, BN over weight columns); 0 = heuristic
+    int TM = (d->N > 64) ? 2 : 1;
+    int TN = (p.ncols > 64) ? 2 : 1;
+    int want_splits = 0;
+    if (d->tile_hint) {
+        TM = ((d->tile_hint & 0xff) >= 128) ? 2 : 1;
+        TN = (((d->tile_hint >> 8) & 0xff) >= 128) ? 2 : 1;
+        want_splits = (d->tile_hint >> 16) & 0xffff;
+    }
     p.m_tiles = cdiv(d->N, 64 * TM);
     p.n_tiles = cdiv(p.ncols, 64 * TN);
     const int nmn = p.m_tiles * p.n_tiles;
-    int splits = (2 * ZSG_NUM_CU + nmn - 1) / nmn;
+    int splits = want_splits > 0 ? want_splits : (2 * ZSG_NUM_CU + nmn - 1) / nmn;
     if (splits > kt / 2) splits = kt / 2;
     if (splits < 1) splits = 1;
     p.kt_chunk = cdiv(kt, splits);

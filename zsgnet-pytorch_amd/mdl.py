@@ -25,7 +25,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import lib, require_gpu, stream_ptr
-from .ops import Level, Program, TView, conv_out, dgrad_desc, fwd_desc
+from .ops import Level, Program, TView, autotune_conv, conv_out, dgrad_desc, fwd_desc
 from .params import ParamStore, pad4, register_named
 
 ARCHS = {
@@ -398,6 +398,7 @@ class _Plan:
                            conv_out(lv[0].W, L.k, L.stride, L.pad, L.dil), L.cout)
         d = fwd_desc(src, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
         bias = self.P(L.name + ".bias") if L.bias else None
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None), stream_ptr())
         self.fwd.add(lib.zsg_conv_igemm, d, src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, what=L.name)
         out.needs_mask = relu
         self.tape.append(lambda: self._conv_bwd(L, src, out))
@@ -416,13 +417,18 @@ class _Plan:
         if dy is None:
             return
         dw = fwd_desc(src, dy, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad)
-        self.bwd.add(lib.zsg_conv_wgrad, dw, src.buf, dy.buf, self.G(L.name + ".weight"), what="wgrad:" + L.name)
+        self.wgrad(dw, src, dy, L.name + ".weight", "wgrad:" + L.name)
         if L.bias:
             base = dy.levels[0].off
             self.bwd.add(lib.zsg_colsum, dy.buf[base:], 1, 0, dy.rows(), dy.ld, 0, L.cout, self.G(L.name + ".bias"), 1,
                          what="bgrad:" + L.name)
         if src.requires_grad:
             self.dgrad(L, dy, src, n=L.cpad)
+
+    def wgrad(self, d, src: Act, dy: Act, pname: str, what: str):
+        gw = self.G(pname)
+        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, (src.buf, dy.buf, gw), stream_ptr())
+        self.bwd.add(lib.zsg_conv_wgrad, d, src.buf, dy.buf, gw, what=what)
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
@@ -432,8 +438,12 @@ class _Plan:
         dx = dx or self.grad_of(src)
         d = dgrad_desc(dy, dx, cred, n, L.k, L.stride, L.pad, L.dil)
         wt_off = row0 * L.k * L.k * cred
-        self.bwd.add(lib.zsg_conv_igemm, d, dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None,
-                     src.buf if src.needs_mask else None, what="dgrad:" + L.name)
+        if d.zero_fill and not dx.gfilled:      # stride-parity classes without taps get no launch: clear them
+            self.bwd.add(lib.zsg_memset_f32, self.base(dx), sum(dx.B * l.H * l.W * dx.ld for l in dx.levels), 0.0, what="zero:" + L.name)
+            dx.gfilled = True
+        args = (dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None, src.buf if src.needs_mask else None)
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr())
+        self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
         dx.gfilled = True
 
     def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None) -> Act:
@@ -683,7 +693,7 @@ class _Plan:
             if dy is None:
                 return
             dw0 = fwd_desc(F0, dy, L0.cpad, 256, 3, 1, 1, 1, wC=L0.cpad)
-            self.bwd.add(lib.zsg_conv_wgrad, dw0, F0.buf, dy.buf, self.G(L0.name + ".weight"), what="wgrad:head0")
+            self.wgrad(dw0, F0, dy, L0.name + ".weight", "wgrad:head0")
             self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0")
             if Cf:                          # the grid channels are constants: no data gradient for them
                 dF = self.packed("head.dfeat", B, sizes, Cf)
@@ -735,7 +745,7 @@ class _Plan:
             self.bwd.add(lib.zsg_pad_rows, self.g5_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
             self.bwd.add(lib.zsg_colsum, self.g5_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:head5")
             dw = fwd_desc(h5, g5p, L5.cpad, nout, 3, 1, 1, 1, wC=L5.cpad)
-            self.bwd.add(lib.zsg_conv_wgrad, dw, h5.buf, g5p.buf, self.G(L5.name + ".weight"), what="wgrad:head5")
+            self.wgrad(dw, h5, g5p, L5.name + ".weight", "wgrad:head5")
             self.dgrad(L5, g5p, h5, n=256)
         self.tape.append(head5_back)
 

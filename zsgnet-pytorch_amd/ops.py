@@ -92,7 +92,8 @@ def dgrad_desc(dy: TView, dx: TView, C_red: int, N: int, k: int, stride: int, pa
     """Data gradient as an implicit GEMM over the transposed weight image WT[cin][k][k][C_red]:
     rows = dx pixels, reduction = dy channels (C_red = dy.ld incl. zero padding), N = forward input channels.
     Strided convolutions are split into stride^2 parity classes (one segment each) so that every K tile carries only
-    taps that really contribute (no multiply-by-zero work)."""
+    taps that really contribute (no multiply-by-zero work).  Classes without any contributing tap (e.g. three of the
+    four classes of a 1x1 stride-2 convolution) are dropped: `desc.zero_fill` tells the caller to clear dx first."""
     d = ConvDesc()
     d.B, d.C, d.N = dy.B, C_red, N
     d.src_ld, d.out_ld = dy.ld, dx.ld
@@ -102,6 +103,7 @@ def dgrad_desc(dy: TView, dx: TView, C_red: int, N: int, k: int, stride: int, pa
     d.relu, d.merge_x, d.tile_hint = 0, 0, tile_hint
     assert len(dy.levels) == len(dx.levels)
     segs = []
+    zero_fill = False
     for ly, lx in zip(dy.levels, dx.levels):
         assert ly.H == conv_out(lx.H, k, stride, pad, dil) and ly.W == conv_out(lx.W, k, stride, pad, dil)
         if stride == 1:
@@ -122,6 +124,9 @@ def dgrad_desc(dy: TView, dx: TView, C_red: int, N: int, k: int, stride: int, pa
                 c0 = (px + pad) % stride
                 nx = len(range(c0, k, stride))
                 tx = _taps(nx, c0, stride, (px + pad - c0) // stride, -1)
+                if ny == 0 or nx == 0:
+                    zero_fill = True
+                    continue
                 segs.append((ry, rx, ly, lx, stride, py, px, ty, tx))
     assert len(segs) <= ZSG_MAX_SEG, "too many dgrad segments"
     d.nseg = len(segs)
@@ -136,7 +141,12 @@ def dgrad_desc(dy: TView, dx: TView, C_red: int, N: int, k: int, stride: int, pa
         s.src_off, s.src_bstride = ly.off, ly.bstride
         s.out_off, s.out_bstride = lx.off, lx.bstride
         s.ty, s.tx = ty, tx
+    d.zero_fill = zero_fill
     return d
+
+
+def tile_hint(bm: int, bn: int, splits: int = 0, w8: int = 0) -> int:
+    return bm | (bn << 8) | (splits << 16) | (w8 << 24)
 
 
 class Program:
@@ -179,5 +189,99 @@ class Program:
             if rc:
                 raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
 
+    def profile(self, stream: int):
+        """[(what, ms)] per launch, timed with HIP events on the launch stream (developer tool, bench --per-op)."""
+        st = C.c_void_p(stream)
+        evs = []
+        for fn, args, what in self.calls:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args, st)
+            b.record()
+            if rc:
+                raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
+            evs.append((what, fn.__name__, a, b))
+        torch.cuda.synchronize()
+        return [(w, f, a.elapsed_time(b)) for w, f, a, b in evs]
+
     def __len__(self):
         return len(self.calls)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# On-device autotuning of the tile shape / split-K factor of a convolution launch ("measure, don't guess").
+# ---------------------------------------------------------------------------------------------------------------------
+_TUNE_CACHE = {}
+
+
+def _sig(kind, d: ConvDesc, extra) -> tuple:
+    segs = tuple((d.seg[i].rows_y, d.seg[i].rows_x, d.seg[i].src_H, d.seg[i].src_W, d.seg[i].sy, d.seg[i].osy,
+                  d.seg[i].ty.n, d.seg[i].tx.n) for i in range(d.nseg))
+    return (kind, d.B, d.C, d.N, d.src_ld, d.out_ld, d.wR, d.wC, d.wt_ld, d.relu, d.merge_x, segs, extra)
+
+
+def _time_launch(fn, args, stream, reps=5):
+    st = C.c_void_p(stream)
+    for _ in range(2):
+        rc = fn(*args, st)
+        if rc:
+            return float("inf")
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn(*args, st)
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def autotune_conv(kind: str, fn, d: ConvDesc, ptr_args: Sequence, stream: int) -> int:
+    """Pick desc.tile_hint for `fn(desc, *ptr_args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the
+    real buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic."""
+    if os.environ.get("ZSG_AUTOTUNE", "1") == "0" or not torch.cuda.is_available():
+        return 0
+    add_src, mask = (ptr_args[4], ptr_args[5]) if kind == "igemm" else (None, None)
+    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is ptr_args[2]))
+    if key in _TUNE_CACHE:
+        d.tile_hint = _TUNE_CACHE[key]
+        return d.tile_hint
+    rows = sum(d.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
+    cands = []
+    if kind == "igemm":
+        tiles = [(64, 64), (128, 64)] + ([(128, 128)] if d.N > 64 else [])
+        s0 = d.seg[0]
+        dense = (d.nseg == 1 and not d.relu and d.out_ld == d.N and s0.osy == 1 and s0.osx == 1 and s0.out_W == s0.rows_x
+                 and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
+        for bm, bn in tiles:
+            cands.append(tile_hint(bm, bn, 1))
+            if bm == 128 and not d.merge_x:
+                cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup
+        blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
+        n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
+        if dense and blocks64 < 1024:
+            for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
+                if sp <= n_it and blocks64 * sp <= 3072:
+                    cands.append(tile_hint(64, 64, sp))
+                    if blocks64 * sp < 256:
+                        cands.append(tile_hint(128, 64, sp))
+    else:
+        ncols = d.seg[0].ty.n * d.seg[0].tx.n * d.C
+        for bm in ((64, 128) if d.N > 64 else (64,)):
+            for bn in ((64, 128) if ncols > 64 else (64,)):
+                nmn = ((d.N + bm - 1) // bm) * ((ncols + bn - 1) // bn)
+                seen = set()
+                for target in (256, 512, 1024, 2048):
+                    sp = max(1, min(target // nmn, rows // 64))
+                    if sp not in seen:
+                        seen.add(sp)
+                        cands.append(tile_hint(bm, bn, sp))
+    conv = [C.byref(d)] + [C.c_void_p(a.data_ptr()) if isinstance(a, torch.Tensor) else None for a in ptr_args]
+    best, best_t = 0, float("inf")
+    for h in cands:
+        d.tile_hint = h
+        t = _time_launch(fn, conv, stream)
+        if t < best_t:
+            best, best_t = h, t
+    d.tile_hint = best
+    _TUNE_CACHE[key] = best
+    return best
