@@ -87,10 +87,13 @@ typedef struct {
 int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
                    const float* add_src, const float* mask_src, void* stream);
 
-/* Weight gradient.  dw[n][(r*wS+s)*wC + wc0 + c] += sum_rows dy[row][n] * src[gather(row, r, s)][c]
- * (atomic fp32 accumulation: the caller zeroes dw once per step; shared-weight levels simply accumulate).
- * The descriptor is the FORWARD descriptor of the convolution (src = forward input, "out" geometry = dy). */
-int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, void* stream);
+/* Weight gradient.  dw[n][(r*wS+s)*wC + wc0 + c] (+)= sum_rows dy[row][n] * src[gather(row, r, s)][c]
+ * The descriptor is the FORWARD descriptor of the convolution (src = forward input, "out" geometry = dy); all
+ * segments (pyramid levels of the shared head) are reduced in the one launch.  The pixel dimension is split over
+ * tile_hint's split_k blocks whose partial tiles go to the workspace and are summed in a fixed order (deterministic). */
+size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d);
+int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                   size_t ws_bytes, void* stream);
 
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */

@@ -25,6 +25,25 @@ def dev(t):
     return t.cuda().contiguous()
 
 
+class _LazyWS:
+    """split-K workspace of zsg_conv_wgrad (allocated on first use)"""
+    t = None
+
+    def _get(self):
+        if _LazyWS.t is None:
+            _LazyWS.t = torch.empty(64 << 20, device="cuda")
+        return _LazyWS.t
+
+    def data_ptr(self):
+        return self._get().data_ptr()
+
+    def numel(self):
+        return self._get().numel()
+
+
+WS = _LazyWS()
+
+
 def pad4(n):
     return (n + 3) // 4 * 4
 
@@ -119,8 +138,13 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
     # wgrad
     dw = torch.zeros(Co, k, k, cp, device="cuda")
     wdesc = ops.fwd_desc(src, dyv, cp, Co, k, s, p, d, wC=cp)
-    L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), st), "wgrad")
+    L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgrad")
     assert_close(dw[..., :Ci].permute(0, 3, 1, 2), wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), "conv wgrad")
+    for hint, acc in ((ops.tile_hint(64, 64, 1), 1), (ops.tile_hint(128, 64, 3), 1), (ops.tile_hint(64, 128, 7), 0)):
+        dw2 = torch.full((Co, k, k, cp), 1.0, device="cuda")
+        wd2 = ops.fwd_desc(src, dyv, cp, Co, k, s, p, d, wC=cp, tile_hint=hint)
+        L.check(L.lib.zsg_conv_wgrad(C.byref(wd2), xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, st), "wgrad hint")
+        assert_close(dw2[..., :Ci].permute(0, 3, 1, 2) - acc, wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), f"conv wgrad hint {hint:x} acc={acc}")
     if cp > Ci:
         assert float(dw[..., Ci:].abs().max()) == 0.0
     if bias:
@@ -203,7 +227,7 @@ def test_conv_multilevel_shared_weights(Z):
     dyv = ops.TView(gyd.view(-1), B, Cop, Cop, lv_dy)
     dw = torch.zeros(Co, k, k, Ci, device="cuda")
     wdesc = ops.fwd_desc(src, dyv, Ci, Co, k, 1, 1, 1, wC=Ci)
-    L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), packed.data_ptr(), gyd.data_ptr(), dw.data_ptr(), L.stream_ptr()), "wgrad")
+    L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), packed.data_ptr(), gyd.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad")
     wr = w.clone().requires_grad_()
     tot = sum((F.conv2d(x, wr, None, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Co) * gy[:, o:o + x.shape[2] * x.shape[3]]).sum()
               for x, o in zip(xs, np.cumsum([0] + [h * ww for h, ww in sizes])[:-1]))
@@ -428,10 +452,10 @@ def test_lstm_against_golden_and_oracle(Z, gold):
                                    ld.data_ptr() if di == 0 else None, B, Tn, H, dg.data_ptr(), st), "lstm_bwd")
         dgv = ops.TView(dg.view(-1), B, 4 * H, 4 * H, [ops.Level(0, 1, Tn, Tn * 4 * H)])
         dwih = torch.zeros(4 * H, E, device="cuda")
-        L.check(L.lib.zsg_conv_wgrad(C.byref(ops.fwd_desc(src, dgv, E, 4 * H, 1, 1, 0, 1, wC=E)), xin.data_ptr(), dg.data_ptr(), dwih.data_ptr(), st), "w_ih")
+        L.check(L.lib.zsg_conv_wgrad(C.byref(ops.fwd_desc(src, dgv, E, 4 * H, 1, 1, 0, 1, wC=E)), xin.data_ptr(), dg.data_ptr(), dwih.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "w_ih")
         hp = ops.TView(hprev.view(-1), B, H, H, [ops.Level(0, 1, Tn, Tn * H)])
         dwhh = torch.zeros(4 * H, H, device="cuda")
-        L.check(L.lib.zsg_conv_wgrad(C.byref(ops.fwd_desc(hp, dgv, H, 4 * H, 1, 1, 0, 1, wC=H)), hprev.data_ptr(), dg.data_ptr(), dwhh.data_ptr(), st), "w_hh")
+        L.check(L.lib.zsg_conv_wgrad(C.byref(ops.fwd_desc(hp, dgv, H, 4 * H, 1, 1, 0, 1, wC=H)), hprev.data_ptr(), dg.data_ptr(), dwhh.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "w_hh")
         db = torch.zeros(4 * H, device="cuda")
         L.check(L.lib.zsg_colsum(dg.data_ptr(), 1, 0, B * Tn, 4 * H, 0, 4 * H, db.data_ptr(), 0, st), "bias")
         tag = "l0" + suf

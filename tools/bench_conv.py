@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zsgnet_pytorch_amd import ops
 from zsgnet_pytorch_amd._lib import lib, check, stream_ptr
 
+WS = torch.empty(64 << 20, device="cuda")
+
 # name, B, Cin, Cout, H, W, k, s, p
 SHAPES = [
     ("head3x3_38", 16, 256, 256, 38, 38, 3, 1, 1),
@@ -73,10 +75,10 @@ def main():
             ms = timeit(lambda: check(lib.zsg_conv_igemm(C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, st)))
             line += f" d[{t & 0xff}x{(t >> 8) & 0xff}{chr(119) if t >> 24 else chr(32)}] {gf / ms:5.1f}"
         line += " | wgrad"
-        for t in TILES:
+        for t in TILES + [128 | (128 << 8) | (1 << 25), 64 | (64 << 8) | (1 << 25), 64 | (128 << 8) | (1 << 25)]:
             d = ops.fwd_desc(xv, dyv, Ci, Co, k, s, p, 1, wC=Ci, tile_hint=t)
-            ms = timeit(lambda: check(lib.zsg_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), st)))
-            line += f" [{t & 0xff}x{(t >> 8) & 0xff}] {gf / ms:6.1f}"
+            ms = timeit(lambda: check(lib.zsg_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st)))
+            line += f" [{t & 0xff}x{(t >> 8) & 0xff}{'k32' if (t >> 25) & 1 else ''}] {gf / ms:6.1f}"
         if B * Ho * Wo <= 2048:
             line += " | fwd split-K"
             for sp in (2, 4, 8, 16):

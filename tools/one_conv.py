@@ -11,6 +11,8 @@ from tools.bench_conv import SHAPES
 from zsgnet_pytorch_amd import ops
 from zsgnet_pytorch_amd._lib import lib, check, stream_ptr
 
+WS = torch.empty(64 << 20, device="cuda")
+
 name, mode, bm, bn = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 w8 = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 sp = int(sys.argv[6]) if len(sys.argv) > 6 else 0
@@ -38,5 +40,5 @@ for _ in range(8):
         check(lib.zsg_conv_igemm(C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, st))
     else:
         d = ops.fwd_desc(xv, dyv, Ci, Co, k, s, p, 1, wC=Ci, tile_hint=hint)
-        check(lib.zsg_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), st))
+        check(lib.zsg_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st))
 torch.cuda.synchronize()

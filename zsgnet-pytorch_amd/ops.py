@@ -145,8 +145,27 @@ def dgrad_desc(dy: TView, dx: TView, C_red: int, N: int, k: int, stride: int, pa
     return d
 
 
-def tile_hint(bm: int, bn: int, splits: int = 0, w8: int = 0) -> int:
-    return bm | (bn << 8) | (splits << 16) | (w8 << 24)
+def tile_hint(bm: int, bn: int, splits: int = 0, w8: int = 0, k32: int = 0) -> int:
+    """BM | BN<<8 | split_k<<16 | (8-wave workgroup)<<24 | (32-pixel K tiles, wgrad only)<<25"""
+    return bm | (bn << 8) | (min(splits, 255) << 16) | (w8 << 24) | (k32 << 25)
+
+
+def marshal(fn, args, keep: Optional[list] = None) -> tuple:
+    """Convert (ctypes struct | tensor | None | scalar) arguments to the C types of fn (all but the trailing stream)."""
+    assert len(args) == len(fn.argtypes) - 1, f"{fn.__name__}: {len(args)} args for {len(fn.argtypes) - 1}"
+    conv = []
+    for a, t in zip(args, fn.argtypes[:-1]):
+        if isinstance(a, C.Structure):
+            conv.append(C.byref(a))
+        elif isinstance(a, torch.Tensor):
+            conv.append(t(a.data_ptr()))
+        elif a is None:
+            conv.append(None)
+        else:
+            conv.append(t(a))
+        if keep is not None and isinstance(a, (C.Structure, torch.Tensor)):
+            keep.append(a)
+    return tuple(conv)
 
 
 class Program:
@@ -158,20 +177,7 @@ class Program:
         self.keep = []          # ctypes structs / tensors that must outlive the program
 
     def add(self, fn, *args, what: str = ""):
-        conv = []
-        for a, t in zip(args, fn.argtypes[:-1]):
-            if isinstance(a, C.Structure):
-                self.keep.append(a)
-                conv.append(C.byref(a))
-            elif isinstance(a, torch.Tensor):
-                self.keep.append(a)
-                conv.append(t(a.data_ptr()))
-            elif a is None:
-                conv.append(None)
-            else:
-                conv.append(t(a))
-        assert len(args) == len(fn.argtypes) - 1, f"{fn.__name__}: {len(args)} args for {len(fn.argtypes) - 1}"
-        self.calls.append((fn, tuple(conv), what or fn.__name__))
+        self.calls.append((fn, marshal(fn, args, self.keep), what or fn.__name__))
 
     def run(self, stream: int, start: int = 0, stop: Optional[int] = None):
         st = C.c_void_p(stream)
@@ -235,13 +241,13 @@ def _time_launch(fn, args, stream, reps=5):
     return a.elapsed_time(b) / reps
 
 
-def autotune_conv(kind: str, fn, d: ConvDesc, ptr_args: Sequence, stream: int) -> int:
-    """Pick desc.tile_hint for `fn(desc, *ptr_args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the
-    real buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic."""
+def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0) -> int:
+    """Pick d.tile_hint for `fn(d, *args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the real
+    buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic."""
     if os.environ.get("ZSG_AUTOTUNE", "1") == "0" or not torch.cuda.is_available():
         return 0
-    add_src, mask = (ptr_args[4], ptr_args[5]) if kind == "igemm" else (None, None)
-    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is ptr_args[2]))
+    add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
+    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2]))
     if key in _TUNE_CACHE:
         d.tile_hint = _TUNE_CACHE[key]
         return d.tile_hint
@@ -270,12 +276,14 @@ def autotune_conv(kind: str, fn, d: ConvDesc, ptr_args: Sequence, stream: int) -
             for bn in ((64, 128) if ncols > 64 else (64,)):
                 nmn = ((d.N + bm - 1) // bm) * ((ncols + bn - 1) // bn)
                 seen = set()
-                for target in (256, 512, 1024, 2048):
-                    sp = max(1, min(target // nmn, rows // 64))
-                    if sp not in seen:
+                for target in (256, 384, 512, 768, 1024, 2048):
+                    sp = max(1, min(target // nmn, rows // 64, 255))
+                    if sp not in seen and sp * d.N * ncols * 4 <= ws_bytes:
                         seen.add(sp)
                         cands.append(tile_hint(bm, bn, sp))
-    conv = [C.byref(d)] + [C.c_void_p(a.data_ptr()) if isinstance(a, torch.Tensor) else None for a in ptr_args]
+                        if bm == 128 and bn == 128:
+                            cands.append(tile_hint(bm, bn, sp, 0, 1))
+    conv = marshal(fn, (d,) + tuple(args))
     best, best_t = 0, float("inf")
     for h in cands:
         d.tile_hint = h
