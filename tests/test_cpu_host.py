@@ -1,0 +1,187 @@
+"""CPU-only checks of the host side: config rules, reference parameter names / layouts, the C-ABI library exports,
+the bucketed gradient reducer over gloo (world_size 2), CLI plumbing, and the fail-loudly rule (no CPU fallback)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import zsg_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    import ctypes
+    from zsgnet_pytorch_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "zsg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(zsg_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 35
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/zsg.h but not exported by libzsg.so"
+        assert name in _lib.SIGNATURES, f"{name} has no Python binding"
+    assert sorted(_lib.SIGNATURES) == declared
+    assert _lib.lib.zsg_version() == 100 and _lib.lib.zsg_last_error() is not None
+
+
+def test_config_rules():
+    from zsgnet_pytorch_amd.config import get_cfg, ratios_scales, update_from_dict
+    cfg = get_cfg()
+    assert cfg.bs == cfg["bs"] == 16 and cfg.mdl_to_use == "retina" and cfg.resize_img == [300, 300]
+    update_from_dict(cfg, {"bs": "4", "lr": "1e-3", "use_focal": "False", "resize_img": "[600, 600]", "ds_to_use": "flickr30k_c0"})
+    assert cfg.bs == 4 and cfg.lr == 1e-3 and cfg.use_focal is False and cfg.resize_img == [600, 600] and cfg.ds_to_use == "flickr30k_c0"
+    with pytest.raises(AssertionError):
+        update_from_dict(cfg, {"no_such_key": 1})           # extended_config.py:78-85
+    with pytest.raises(AssertionError):
+        update_from_dict(cfg, {"bs": "abc"})                # type must be kept (extended_config.py:87)
+    r, s = ratios_scales(get_cfg())
+    ro, so = O.default_ratios_scales()
+    assert r == ro and np.array_equal(s, so)
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.bs = 3
+
+
+@pytest.mark.parametrize("arch,nparams", [("resnet18", None), ("resnet50", 35594349), ("resnet101", None)])
+def test_module_names_shapes_and_storage_layout(arch, nparams):
+    from zsgnet_pytorch_amd.config import get_cfg
+    from zsgnet_pytorch_amd.mdl import get_default_net
+    net = get_default_net(9, get_cfg(resnet_arch=arch))
+    ref = O.seeded_state_dict(arch, 0)
+    sd = net.state_dict()
+    assert list(sd.keys()) and set(sd.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    if nparams:
+        assert sum(p.numel() for p in net.parameters()) == nparams      # 37 643 349 minus torchvision's unused fc
+    net.load_state_dict(ref)
+    for k, v in ref.items():
+        assert torch.equal(net.state_dict()[k], v), k
+    # OHWI storage, input channels padded to a multiple of 4 with zeros; the Parameter is a strided OIHW view of it
+    raw = net.store.raw("backbone.encoder.conv1.weight").view(64, 7, 7, 4)
+    assert torch.equal(raw[..., :3].permute(0, 3, 1, 2), ref["backbone.encoder.conv1.weight"]) and raw[..., 3].abs().max() == 0
+    raw = net.store.raw("att_reg_box.0.0.weight").view(256, 3, 3, 516)
+    assert torch.equal(raw[..., :514].permute(0, 3, 1, 2), ref["att_reg_box.0.0.weight"]) and raw[..., 514:].abs().max() == 0
+    assert torch.equal(net.state_dict()["att_reg_box.5.bias"], torch.tensor([0, 0, 0, 0, -4.0] * 9))
+    assert [n for n, _ in net.named_parameters()] == net._param_names
+    # DDP-style / torchvision-style checkpoints load (utils.py:489)
+    dd = {"module." + k: v for k, v in ref.items()}
+    dd["module.backbone.encoder.fc.weight"] = torch.zeros(10, 10)
+    net.load_state_dict(dd)
+    # parameters stay views of ONE flat buffer after .to()
+    net.to("cpu")
+    p = dict(net.named_parameters())["backbone.fpn.P6.weight"]
+    assert p.data_ptr() >= net.store.flat.data_ptr() and p.data_ptr() < net.store.flat.data_ptr() + net.store.flat.numel() * 4
+
+
+def test_no_cpu_fallback():
+    """The hot path must fail loudly without the MI355X (task rule ③)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from zsgnet_pytorch_amd.config import get_cfg
+    from zsgnet_pytorch_amd.mdl import get_default_net
+    net = get_default_net(9, get_cfg(resnet_arch="resnet18"))
+    bt = O.synthetic_batch(2, 64, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(bt)
+    with pytest.raises(NotImplementedError):
+        get_default_net(9, get_cfg(mdl_to_use="ssd_vgg"))
+
+
+def test_host_anchor_tables_match_oracle():
+    from zsgnet_pytorch_amd import anchors
+    r, s = O.default_ratios_scales()
+    for fs in (O.feat_sizes_for(300, 300), O.feat_sizes_for(600, 600, True), [(7, 3), (1, 5)]):
+        assert np.array_equal(anchors.create_anchors_np(fs, r, s), O.create_anchors(fs, r, s))
+    assert np.array_equal(anchors.create_grid((19, 19)).numpy(), O.create_grid(19, 19))
+
+
+def test_cli_argument_parsing_and_config_1_plumbing():
+    """BASELINE configs[0]: refclef, ResNet-18 FPN, bs=2, CPU-only world_size=1 — CLI -> cfg -> modules (no GPU compute)."""
+    from zsgnet_pytorch_amd.config import get_cfg, update_from_dict
+    from zsgnet_pytorch_amd.main_dist import parse_argv
+    from zsgnet_pytorch_amd.mdl import get_default_net
+    from zsgnet_pytorch_amd.synth import get_data
+    uid, kw = parse_argv(["exp", "--ds_to_use=refclef", "--bs=2", "--resnet_arch", "resnet18", "--only_val"])
+    cfg = update_from_dict(get_cfg(), kw)
+    assert uid == "exp" and cfg.bs == 2 and cfg.resnet_arch == "resnet18" and cfg.only_val is True
+    net = get_default_net(9, cfg)
+    assert net.block_kind == "basic" and "backbone.encoder.layer4.1.conv2.weight" in net.state_dict()
+    data = get_data(cfg)
+    b = next(iter(data.train_dl))
+    assert b["img"].shape == (2, 3, 300, 300) and b["qvec"].shape == (2, 20, 300) and b["annot"].shape == (2, 4)
+    assert all(v.dtype == torch.float32 for v in b.values())          # collater casts every field to float (dat_loader.py:193)
+
+
+def test_plan_buckets_cover_flat_buffer_in_readiness_order():
+    from zsgnet_pytorch_amd.dist import plan_buckets
+    spans = [(0, 100, 90), (100, 60, 80), (160, 400, 70), (560, 40, 10), (600, 8, 95)]
+    b = plan_buckets(spans, 150)
+    assert sorted((x.start, x.end) for x in b) == [(0, 160), (160, 560), (560, 608)]
+    assert [x.ready for x in b] == sorted(x.ready for x in b)
+    assert {(x.start, x.end): x.ready for x in b}[(0, 160)] == 90
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _reducer_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zsgnet_pytorch_amd.dist import BucketReducer, DistributedDataParallel, plan_buckets, reduce_dict
+    torch.manual_seed(rank)
+    n = 1000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    launched = []
+    spans = [(0, 300, 7), (300, 300, 4), (600, 400, 1)]
+    red = BucketReducer(flat, plan_buckets(spans, 100))
+    red.run(10, lambda i, j: launched.append((i, j)))
+    red.wait()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(flat, expect) and launched == [(0, 2), (2, 5), (5, 8), (8, 10)]
+
+    class Store:
+        pass
+
+    class Fake(torch.nn.Module):          # the slice of ZSGNet the wrapper touches
+        def __init__(self):
+            super().__init__()
+            self.store = Store()
+            self.store.flat = torch.full((16,), float(rank))
+            self.store.grad = torch.zeros(16)
+            self._rm, self._rv = torch.full((4,), float(rank)), torch.full((4,), float(rank) + 1)
+            self._nbt = torch.tensor([rank])
+
+        def forward(self, x):
+            return x
+    m = Fake()
+    ddp = DistributedDataParallel(m)
+    ok = ok and float(m.store.flat.sum()) == 0.0 and float(m._rv.sum()) == 4.0 and int(m._nbt) == 0     # rank 0's values everywhere
+    m._rm.fill_(float(rank + 5))
+    m.train()
+    ddp(torch.zeros(1))
+    ok = ok and float(m._rm[0]) == 5.0                                                                   # C2: buffers re-broadcast per forward
+    rd = reduce_dict({"a": torch.tensor(float(rank + 1)), "b": torch.tensor(2.0)}, average=True)
+    if rank == 0:
+        ok = ok and abs(float(rd["a"]) - 1.5) < 1e-6 and abs(float(rd["b"]) - 2.0) < 1e-6
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_and_ddp_wrapper_gloo_world2():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reducer_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]

@@ -113,7 +113,7 @@ class DistributedDataParallel(nn.Module):
         self.group = process_group
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.world = get_world_size()
-        module._ddp = self
+        object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a cycle
         if self.world > 1:
             dist.broadcast(module.store.flat, src=0, group=self.group)
             self._sync_buffers()
