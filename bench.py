@@ -147,9 +147,16 @@ def main():
                                   share=e.ms / tot if tot else 0))
         prof_rows.sort(key=lambda x: -x["ms_per_step"])
         dom = prof_rows[0]
+        traffic = None                 # HBM bytes per launch of the dominant kernel class from the separate rocprofv3 --pmc passes
+        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")       # (FETCH_SIZE x2 + WRITE_SIZE, tools/rocprof_round.sh)
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         if dom["tflops"]:
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": None,
+                    "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom["ms_per_step"] / dom["launches_per_step"], 5), "launches_per_step": dom["launches_per_step"],
                     "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(tot / nprof, 3)}
         else:

@@ -1,0 +1,51 @@
+"""Condense a tools/rocprof_round.sh output directory into the small files committed under profiles/:
+<tag>_kernel_stats.csv (rocprofv3 --stats per-kernel summary) and <tag>_hbm_traffic.json (per-launch HBM bytes per
+kernel class from the FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
+wide coalesced reads on gfx950)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "gpurun_out", "profiles_" + tag)
+os.makedirs(dst, exist_ok=True)
+ks = glob.glob(out + "/stats/*/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+
+def klass(name):
+    if name.startswith("void igemm_kernel"):
+        return "conv_igemm"
+    if name.startswith("void wgrad_kernel"):
+        return "conv_wgrad"
+    if "wgrad_reduce" in name:
+        return "conv_wgrad_reduce"
+    return name.split("(")[0].replace("void ", "")[:40]
+
+
+res = {}
+for pass_, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(out + f"/{pass_}/*/*counter_collection.csv")
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            a = agg[klass(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    for k, (n, v) in agg.items():
+        res.setdefault(k, {})[key + "_KB_per_launch"] = v / n
+        res[k]["launches_in_pass"] = n
+for k, d in res.items():
+    d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
+json.dump(res, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+for k in ("conv_igemm", "conv_wgrad"):
+    if k in res:
+        print(k, {a: round(b) for a, b in res[k].items()})
+if ks:
+    print(open(ks[0]).read()[:3000])

@@ -218,6 +218,34 @@ class Program:
 # On-device autotuning of the tile shape / split-K factor of a convolution launch ("measure, don't guess").
 # ---------------------------------------------------------------------------------------------------------------------
 _TUNE_CACHE = {}
+_TUNE_DIRTY = False
+
+
+def load_tune_cache(path: str) -> int:
+    """Optional persistence of the autotuner's choices (ZSG_TUNE_CACHE=<file>): profiling runs then contain no tuning
+    launches.  Keys are geometry signatures, values tile hints."""
+    import ast
+    import json
+    if not path or not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        for k, v in json.load(f).items():
+            _TUNE_CACHE[ast.literal_eval(k)] = int(v)
+    return len(_TUNE_CACHE)
+
+
+def save_tune_cache(path: str):
+    import json
+    if path and _TUNE_DIRTY:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({repr(k): v for k, v in _TUNE_CACHE.items()}, f)
+
+
+if os.environ.get("ZSG_TUNE_CACHE"):
+    import atexit
+    load_tune_cache(os.environ["ZSG_TUNE_CACHE"])
+    atexit.register(lambda: save_tune_cache(os.environ.get("ZSG_TUNE_CACHE", "")))
 
 
 def _sig(kind, d: ConvDesc, extra) -> tuple:
@@ -292,4 +320,6 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             best, best_t = h, t
     d.tile_hint = best
     _TUNE_CACHE[key] = best
+    global _TUNE_DIRTY
+    _TUNE_DIRTY = True
     return best
