@@ -281,6 +281,94 @@ def resnet_conv_specs(arch: str):
     return specs
 
 
+VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]   # ssd_vgg.py:174-177
+SSD_EXTRAS = [256, "S", 512, 128, "S", 256, 128, 256, 128, 256]                                        # ssd_vgg.py:179-182
+SSD_MBOX = [4, 6, 6, 6, 4, 4]
+
+
+def ssd_layer_specs():
+    """VGG trunk + extras of build_ssd('train', 300) (ssd_vgg.py:117-155): returns (vgg, extras) where vgg is a list of
+    ('conv', idx, cin, cout, k, pad, dil) | ('relu', idx) | ('pool', idx, k, s, p, ceil) and extras a list of
+    (idx, cin, cout, k, stride, pad)."""
+    vgg, cin, idx = [], 3, 0
+    for v in VGG_BASE:
+        if v == "M":
+            vgg.append(("pool", idx, 2, 2, 0, False)); idx += 1
+        elif v == "C":
+            vgg.append(("pool", idx, 2, 2, 0, True)); idx += 1
+        else:
+            vgg.append(("conv", idx, cin, v, 3, 1, 1)); vgg.append(("relu", idx + 1)); idx += 2
+            cin = v
+    vgg.append(("pool", idx, 3, 1, 1, False)); idx += 1                       # pool5
+    vgg.append(("conv", idx, 512, 1024, 3, 6, 6)); vgg.append(("relu", idx + 1)); idx += 2     # conv6 (dilated)
+    vgg.append(("conv", idx, 1024, 1024, 1, 0, 1)); vgg.append(("relu", idx + 1)); idx += 2    # conv7
+    extras, cin, flag, k = [], 1024, False, 0
+    for i, v in enumerate(SSD_EXTRAS):
+        if cin != "S":
+            if v == "S":
+                extras.append((k, cin, SSD_EXTRAS[i + 1], (1, 3)[flag], 2, 1)); k += 1
+            else:
+                extras.append((k, cin, v, (1, 3)[flag], 1, 0)); k += 1
+            flag = not flag
+        cin = v
+    return vgg, extras
+
+
+def ssd_forward(sd, img, six_hundred=False, prefix="backbone.encoder."):
+    """SSD.forward, ssd_vgg.py:54-102: conv4_3 (channel-L2-normalised, no eps), conv7, four extras -> 256-ch maps."""
+    vgg, extras = ssd_layer_specs()
+    x = img
+    sources = []
+    for layer in vgg:
+        if layer[0] == "conv":
+            _, idx, ci, co, k, pad, dil = layer
+            x = F.conv2d(x, sd[f"{prefix}vgg.{idx}.weight"], sd[f"{prefix}vgg.{idx}.bias"], 1, pad, dil)
+        elif layer[0] == "relu":
+            x = F.relu(x)
+            if layer[1] == 22:                                  # vgg[0:23] ends with conv4_3's ReLU (ssd_vgg.py:75-80)
+                sources.append(x / x.norm(dim=1, keepdim=True))
+        else:
+            _, idx, k, s_, p_, ceil = layer
+            x = F.max_pool2d(x, k, s_, p_, ceil_mode=ceil)
+    sources.append(x)
+    for (k, ci, co, ks, st, pd) in extras:
+        x = F.relu(F.conv2d(x, sd[f"{prefix}extras.{k}.weight"], sd[f"{prefix}extras.{k}.bias"], st, pd))
+        if k % 2 == 1:
+            sources.append(x)
+    outs = [F.conv2d(sources[i], sd[f"{prefix}fproj{i + 1}.weight"], sd[f"{prefix}fproj{i + 1}.bias"]) for i in range(3)] + sources[3:]
+    return outs[1:] if six_hundred else outs
+
+
+def seeded_ssd_state_dict(seed: int = 0, n_anchors: int = 9, emb_dim: int = 300, lstm_dim: int = 128, head_in: int = 514):
+    """Seed-only weights with the reference's SSD key names (incl. the never-used loc/conf heads, ssd_vgg.py:157-171)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (ci * k * k))
+        sd[name + ".bias"] = (torch.rand(co, generator=g) - 0.5) * 0.2
+    p = "backbone.encoder."
+    vgg, extras = ssd_layer_specs()
+    for layer in vgg:
+        if layer[0] == "conv":
+            conv(f"{p}vgg.{layer[1]}", layer[3], layer[2], layer[4])
+    conv(p + "fproj1", 256, 512, 1)
+    conv(p + "fproj2", 256, 1024, 1)
+    conv(p + "fproj3", 256, 512, 1)
+    for (k, ci, co, ks, st, pd) in extras:
+        conv(f"{p}extras.{k}", co, ci, ks)
+    src_ch = [512, 1024, 512, 256, 256, 256]
+    for i, (c, nb) in enumerate(zip(src_ch, SSD_MBOX)):
+        conv(f"{p}loc.{i}", nb * 4, c, 3)
+    for i, (c, nb) in enumerate(zip(src_ch, SSD_MBOX)):
+        conv(f"{p}conf.{i}", nb * 21, c, 3)
+    base = seeded_state_dict("resnet18", seed + 1, n_anchors, emb_dim, lstm_dim, head_in)
+    for k_, v in base.items():
+        if k_.startswith("att_reg_box.") or k_.startswith("lstm."):
+            sd[k_] = v
+    return sd
+
+
 def fpn_in_channels(arch: str):
     kind, _ = ARCHS[arch]
     e = 4 if kind == "bottleneck" else 1
@@ -476,8 +564,11 @@ def zsgnet_forward(sd, batch, h0, c0, arch="resnet50", training=True, six_hundre
     """Reference mdl.py:338-403.  Returns dict(att_out [B,A,1], bbx_out [B,A,4], feat_sizes [L,2], num_f_out [1])."""
     bn = BNState(sd, training)
     we = query_encoder(sd, batch["qvec"], batch["qlens"], h0, c0, rank)
-    c3, c4, c5 = encoder_forward(sd, batch["img"], arch, bn)
-    feats = fpn_forward(sd, c3, c4, c5, six_hundred)
+    if arch == "ssd_vgg":
+        feats = ssd_forward(sd, batch["img"], six_hundred)
+    else:
+        c3, c4, c5 = encoder_forward(sd, batch["img"], arch, bn)
+        feats = fpn_forward(sd, c3, c4, c5, six_hundred)
     outs = [head_forward(sd, fuse_lang_grid(f, we)) for f in feats]
     ab = torch.cat(outs, dim=1)
     return dict(att_out=ab[..., 4:5], bbx_out=ab[..., :4],

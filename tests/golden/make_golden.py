@@ -70,10 +70,11 @@ def import_reference():
     import evaluator
     import loss
     import mdl
+    import ssd_vgg
     from extended_config import cfg
     os.chdir(REPO)
     cfg.device = "cpu"
-    return dict(anchors=anchors, evaluator=evaluator, loss=loss, mdl=mdl, fpn_resnet=fpn_resnet, cfg=cfg)
+    return dict(anchors=anchors, evaluator=evaluator, loss=loss, mdl=mdl, fpn_resnet=fpn_resnet, ssd_vgg=ssd_vgg, cfg=cfg)
 
 
 def save(name, **arrs):
@@ -331,6 +332,40 @@ def main():
         for k in keep:
             d["grad__" + k] = grads[k].numpy()
         save("g10_" + tag, **d)
+    # ---- G11 SSD-VGG16 backbone (config 4): SSD.forward + ZSGNet head/loss, B=1, seeded weights -------------------
+    S = R["ssd_vgg"]
+    sd = O.seeded_ssd_state_dict(seed=5)
+    enc = S.build_ssd("train", cfg=cfg)
+    net = M.ZSGNet(M.SSDBackBone(enc, cfg), 9, cfg=cfg)
+    res = net.load_state_dict(sd, strict=True)
+    net.train()
+    bt = O.synthetic_batch(1, 300, 300, seed=31)
+    gq = torch.Generator().manual_seed(77)
+    h0 = torch.randn(2, 1, 128, generator=gq)
+    c0 = torch.randn(2, 1, 128, generator=gq)
+    net.lstm_init_hidden = lambda bs: (h0, c0)
+    with torch.no_grad():
+        feats = enc(bt["img"])
+    out = net(bt)
+    fs = [tuple(int(v) for v in r) for r in out["feat_sizes"].tolist()]
+    anc = A.create_anchors(fs, ratios, scales, device=cpu).float()
+    lf = L.get_default_loss(ratios, scales, cfg)
+    lf.anchs = anc
+    ls = lf(out, bt)
+    net.zero_grad()
+    ls["loss"].backward()
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    names = sorted(grads)
+    unused = sorted(k for k, p in net.named_parameters() if p.grad is None)
+    d = dict(seed=np.array([5]), batch_seed=np.array([31]), h0=h0.numpy(), c0=c0.numpy(), feat_sizes=np.array(fs),
+             loss=np.float64(ls["loss"].item()), att_out_s=out["att_out"].detach().numpy()[:, ::7], bbx_out_s=out["bbx_out"].detach().numpy()[:, ::7],
+             grad_names=np.array(names), grad_norms=np.array([grads[k].double().norm().item() for k in names]), unused=np.array(unused),
+             keys=np.array(sorted(net.state_dict().keys())))
+    for i, f in enumerate(feats):
+        d[f"feat{i}_s"] = f.numpy()[:, ::8, ::3, ::3] if f.shape[2] > 5 else f.numpy()
+    for k in ("backbone.encoder.vgg.0.bias", "backbone.encoder.vgg.21.bias", "backbone.encoder.fproj1.bias", "backbone.encoder.extras.7.bias"):
+        d["grad__" + k] = grads[k].numpy()
+    save("g11_ssd", **d)
     print("done")
 
 

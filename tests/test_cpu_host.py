@@ -92,7 +92,9 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(bt)
     with pytest.raises(NotImplementedError):
-        get_default_net(9, get_cfg(mdl_to_use="ssd_vgg"))
+        get_default_net(9, get_cfg(do_norm=True))
+    ssd = get_default_net(9, get_cfg(mdl_to_use="ssd_vgg"))
+    assert set(ssd.state_dict().keys()) == set(O.seeded_ssd_state_dict(0).keys())
 
 
 def test_host_anchor_tables_match_oracle():

@@ -221,3 +221,34 @@ def test_end_to_end(gold, tag, hw):
     e = O.zsg_eval(att[..., 0], bbx, bt["annot"].numpy(), bt["img_size"].numpy(), anc.numpy())
     assert e["Acc"] == g["Acc"] and e["MaxPos"] == g["MaxPos"]
     np.testing.assert_allclose(e["pred_scores"], g["pred_scores"], rtol=1e-4)
+
+
+def test_ssd_vgg_backbone(gold):
+    """config 4 backbone (ssd_vgg.py): oracle vs the reference's SSD.forward + ZSGNet head/loss on seeded weights"""
+    g = gold("g11_ssd")
+    sd = O.seeded_ssd_state_dict(int(g["seed"][0]))
+    assert sorted(sd.keys()) == list(g["keys"])
+    for k, v in sd.items():
+        v.requires_grad_(True)
+    bt = O.synthetic_batch(1, 300, 300, seed=int(g["batch_seed"][0]))
+    feats = O.ssd_forward(sd, bt["img"])
+    for i, f in enumerate(feats):
+        f = f.detach().numpy()
+        ref = g[f"feat{i}_s"]
+        np.testing.assert_allclose(f[:, ::8, ::3, ::3] if f.shape[2] > 5 else f, ref, rtol=1e-4, atol=1e-5)
+    out = O.zsgnet_forward(sd, bt, torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"]), arch="ssd_vgg")
+    assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist()
+    np.testing.assert_allclose(out["att_out"].detach().numpy()[:, ::7], g["att_out_s"], rtol=1e-3, atol=1e-4)
+    anc = torch.from_numpy(O.create_anchors([tuple(r) for r in g["feat_sizes"].tolist()], RATIOS, SCALES).astype(np.float32))
+    ls = O.torch_loss(out, bt["annot"], anc)
+    np.testing.assert_allclose(ls["loss"].item(), g["loss"], rtol=1e-4)
+    ls["loss"].backward()
+    norms = dict(zip(g["grad_names"], g["grad_norms"]))
+    for k, v in sd.items():
+        if k in norms:
+            np.testing.assert_allclose(v.grad.double().norm().item(), norms[k], rtol=2e-3, atol=1e-7, err_msg=k)
+        else:
+            assert k in set(g["unused"]) and (v.grad is None or float(v.grad.abs().max()) == 0), k
+    for k in g.files:
+        if k.startswith("grad__"):
+            np.testing.assert_allclose(sd[k[6:]].grad.numpy(), g[k], rtol=2e-3, atol=1e-6)

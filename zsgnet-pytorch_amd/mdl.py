@@ -28,6 +28,9 @@ from ._lib import lib, require_gpu, stream_ptr
 from .ops import Level, Program, TView, autotune_conv, conv_out, dgrad_desc, fwd_desc
 from .params import ParamStore, pad4, register_named
 
+VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
+SSD_EXTRAS = [256, "S", 512, 128, "S", 256, 128, 256, 128, 256]                                          # ssd_vgg.py:179-182
+
 ARCHS = {
     "resnet18": ("basic", (2, 2, 2, 2)),
     "resnet34": ("basic", (3, 4, 6, 3)),
@@ -95,11 +98,12 @@ class ZSGNet(nn.Module):
         self.use_img = bool(cfg["use_img"])
         if not cfg["use_same_atb"]:
             raise NotImplementedError("use_same_atb=False (separate att/reg heads, mdl.py:223-225) is not lowered yet")
-        if backbone_kind != "retina":
-            raise NotImplementedError("mdl_to_use='ssd_vgg' is not lowered yet (SURVEY.md §8 config 4, next round)")
+        if backbone_kind not in ("retina", "ssd_vgg"):
+            raise ValueError(f"mdl_to_use={backbone_kind!r}: expected 'retina' or 'ssd_vgg' (mdl.py:410-414)")
         if cfg["do_norm"]:
             raise NotImplementedError("do_norm=True (mdl.py:118-130) is not lowered yet")
-        self.six_hundred = list(cfg["resize_img"]) == [600, 600]
+        # fpn_resnet.py:173 tests resize_img == [600,600]; ssd_vgg.py:98 tests resize_img[0] >= 600
+        self.six_hundred = (list(cfg["resize_img"]) == [600, 600]) if backbone_kind == "retina" else (cfg["resize_img"][0] >= 600)
         self.cf = 256 if self.use_img else 0
         self.cw = self.lstm_out_dim if self.use_lang else 0
         self.use_grid = (self.use_img and self.use_lang) or (not self.use_img and not self.use_lang)
@@ -140,6 +144,54 @@ class ZSGNet(nn.Module):
         return L
 
     def _declare(self):
+        if self.backbone_kind == "ssd_vgg":
+            self._declare_ssd()
+        else:
+            self._declare_resnet_fpn()
+        self._declare_head_lstm()
+
+    def _declare_ssd(self):
+        """SSD300-VGG16 trunk (ssd_vgg.py:117-171): registration order vgg, fproj1-3, extras, loc, conf.  The loc/conf
+        multibox heads are created but never used by SSD.forward; they are kept so reference checkpoints load."""
+        e = "backbone.encoder."
+        self.block_kind, self.nblocks, self.blocks = "vgg", (), []
+        self.vgg_layers = []
+        cin, idx = 3, 0
+        for v in VGG_BASE:
+            if v in ("M", "C"):
+                self.vgg_layers.append(("pool", idx, 2, 2, 0, v == "C"))
+                idx += 1
+            else:
+                self._conv(f"{e}vgg.{idx}", cin, v, 3, 1, 1, bias=True, merge_x=(cin == 3))
+                self.vgg_layers.append(("conv", idx))
+                idx += 2
+                cin = v
+        self.vgg_layers.append(("pool", idx, 3, 1, 1, False))
+        idx += 1
+        self._conv(f"{e}vgg.{idx}", 512, 1024, 3, 1, 6, 6, bias=True)
+        self.vgg_layers.append(("conv", idx))
+        idx += 2
+        self._conv(f"{e}vgg.{idx}", 1024, 1024, 1, 1, 0, bias=True)
+        self.vgg_layers.append(("conv", idx))
+        self._conv(e + "fproj1", 512, 256, 1, bias=True)
+        self._conv(e + "fproj2", 1024, 256, 1, bias=True)
+        self._conv(e + "fproj3", 512, 256, 1, bias=True)
+        cin, flag, k = 1024, False, 0
+        for i, v in enumerate(SSD_EXTRAS):
+            if cin != "S":
+                if v == "S":
+                    self._conv(f"{e}extras.{k}", cin, SSD_EXTRAS[i + 1], (1, 3)[flag], 2, 1, bias=True)
+                else:
+                    self._conv(f"{e}extras.{k}", cin, v, (1, 3)[flag], 1, 0, bias=True)
+                k += 1
+                flag = not flag
+            cin = v
+        self.n_extras = k
+        for nm, mult in (("loc", 4), ("conf", 21)):
+            for i, (c, nb) in enumerate(zip((512, 1024, 512, 256, 256, 256), (4, 6, 6, 6, 4, 4))):
+                self._conv(f"{e}{nm}.{i}", c, nb * mult, 3, 1, 1, bias=True)
+
+    def _declare_resnet_fpn(self):
         kind, nblocks = ARCHS[self.arch]
         self.block_kind, self.nblocks = kind, nblocks
         exp = 4 if kind == "bottleneck" else 1
@@ -181,6 +233,8 @@ class ZSGNet(nn.Module):
         self._conv(f + "P4_2", 256, 256, 3, 1, 1, bias=True)
         self._conv(f + "P3_1", c3, 256, 1, 1, 0, bias=True)
         self._conv(f + "P3_2", 256, 256, 3, 1, 1, bias=True)
+
+    def _declare_head_lstm(self):
         self._conv("att_reg_box.0.0", self.start_dim_head, 256, 3, 1, 1, bias=True)
         for i in range(1, 5):
             self._conv(f"att_reg_box.{i}.0", 256, 256, 3, 1, 1, bias=True)
@@ -446,7 +500,15 @@ class _Plan:
         if d.zero_fill and not dx.gfilled:      # stride-parity classes without taps get no launch: clear them
             self.bwd.add(lib.zsg_memset_f32, self.base(dx), sum(dx.B * l.H * l.W * dx.ld for l in dx.levels), 0.0, what="zero:" + L.name)
             dx.gfilled = True
-        args = (dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None, src.buf if src.needs_mask else None)
+        mask = None
+        if src.needs_mask:
+            # the epilogue indexes the mask with the OUTPUT offsets; dx may be a level of a packed buffer while src has
+            # its own: rebase the pointer so that mask[o] == src[o - (dx_off - src_off)]
+            deltas = {sl.off - dl.off for sl, dl in zip(src.levels, dx.levels)}
+            assert len(deltas) == 1 and src.ld == dx.ld, "ReLU mask needs one common offset between src and its gradient"
+            mask = src.buf.data_ptr() + 4 * deltas.pop()
+            self.bwd.keep.append(src.buf)
+        args = (dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None, mask)
         autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr())
         self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
         dx.gfilled = True
@@ -514,7 +576,9 @@ class _Plan:
 
         # ---- encoder ------------------------------------------------------------------------------------------------------
         feats: List[Act] = []
-        if net.use_img:
+        if net.use_img and net.backbone_kind == "ssd_vgg":
+            feats = self._lower_ssd(x0)
+        elif net.use_img:
             y = self.conv(C[e + "conv1"], x0, name="stem.y")
             a = self.bn(BN[e + "bn1"], y, relu=True, name="stem.a")
             H2, W2 = conv_out(H1, 3, 2, 1), conv_out(W1, 3, 2, 1)
@@ -548,6 +612,86 @@ class _Plan:
             for emit in reversed(self.tape):
                 emit()
         self.tape = []
+
+    # ---- generic pooling / normalisation lowering (SSD-VGG trunk) -------------------------------------------------
+    def _grad_sink(self, a: Act):
+        """Where a non-conv producer may write d(a): straight into a.grad when nothing is there yet and no ReLU mask is
+        due, else a scratch buffer that `_grad_commit` folds in with the mask (dx (+)= scratch * (a > 0))."""
+        g = self.grad_of(a)
+        if not g.gfilled and not a.needs_mask:
+            return g, None
+        return g, self.like(a, a.name + ".gtmp")
+
+    def _grad_commit(self, a: Act, g: Act, tmp: Optional[Act]):
+        if tmp is not None:
+            n = a.buf.numel()
+            if a.needs_mask:
+                self.bwd.add(lib.zsg_relu_bwd, tmp.buf, a.buf, n, g.buf, int(g.gfilled), what="mask+acc:" + a.name)
+            else:
+                raise AssertionError("accumulation without mask is not needed by any lowered model")
+        g.gfilled = True
+
+    def maxpool(self, x: Act, k: int, s: int, p: int, ceil: bool, name: str) -> Act:
+        l = x.levels[0]
+
+        def osz(n):
+            o = (n + 2 * p - k + (s - 1 if ceil else 0)) // s + 1
+            if ceil and (o - 1) * s >= n + p:
+                o -= 1
+            return o
+        Ho, Wo = osz(l.H), osz(l.W)
+        out = self.act(name, x.B, Ho, Wo, x.C)
+        idx = self._buf((x.B * Ho * Wo * x.C + 3) // 4)
+        self.fwd.add(lib.zsg_maxpool_fwd, x.buf, x.B, l.H, l.W, x.C, k, s, p, Ho, Wo, out.buf, idx, what=name)
+
+        def back():
+            if out.grad is None:
+                return
+            g, tmp = self._grad_sink(x)
+            self.bwd.add(lib.zsg_maxpool_bwd, self.base(out.grad), idx, x.B, l.H, l.W, x.C, k, s, p, Ho, Wo, (tmp or g).buf, what=name + "_bwd")
+            self._grad_commit(x, g, tmp)
+        self.tape.append(back)
+        return out
+
+    def l2norm(self, x: Act, name: str) -> Act:
+        """x / ||x||_2 over channels, no epsilon (ssd_vgg.py:80)"""
+        l = x.levels[0]
+        rows = x.B * l.H * l.W
+        out = self.act(name, x.B, l.H, l.W, x.C)
+        nrm = self._buf(rows)
+        self.fwd.add(lib.zsg_l2norm_fwd, x.buf, rows, x.C, out.buf, nrm, what=name)
+
+        def back():
+            if out.grad is None:
+                return
+            g, tmp = self._grad_sink(x)
+            self.bwd.add(lib.zsg_l2norm_bwd, self.base(out.grad), out.buf, nrm, rows, x.C, (tmp or g).buf, what=name + "_bwd")
+            self._grad_commit(x, g, tmp)
+        self.tape.append(back)
+        return out
+
+    def _lower_ssd(self, x0: Act) -> List[Act]:
+        """SSD.forward, ssd_vgg.py:54-102 (ReLU fused into every conv epilogue)."""
+        net = self.net
+        C = net.convs
+        e = "backbone.encoder."
+        x = x0
+        sources = []
+        for layer in net.vgg_layers:
+            if layer[0] == "conv":
+                x = self.conv(C[f"{e}vgg.{layer[1]}"], x, relu=True, name=f"vgg.{layer[1]}")
+                if layer[1] == 21:                      # conv4_3 + ReLU == vgg[0:23]
+                    sources.append(self.l2norm(x, "conv4_3.norm"))
+            else:
+                _, idx, k, s, p, ceil = layer
+                x = self.maxpool(x, k, s, p, ceil, f"vgg.{idx}")
+        sources.append(x)
+        for k in range(net.n_extras):
+            x = self.conv(C[f"{e}extras.{k}"], x, relu=True, name=f"extras.{k}")
+            if k % 2 == 1:
+                sources.append(x)
+        outs = [self.conv(C[f"{e}fproj{i + 1}"], sources[i], name=f"fproj{i + 1}") for i in range(3)] + sources[3:]
+        return outs[1:] if net.six_hundred else outs
 
     def _lower_block(self, blk, x: Act) -> Act:
         net = self.net
@@ -711,6 +855,9 @@ class _Plan:
                     assert f.grad is None
                     f.grad = dF.lvl(i)
                     f.grad.gfilled = True
+                    if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
+                        n = f.B * f.levels[0].H * f.levels[0].W * f.ld
+                        self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
             if Cw:
                 dWe = self.packed("head.dwe", B, sizes, Cw)
                 self.dgrad(L0, dy, F0, n=Cw, row0=Cf, dx=dWe)
