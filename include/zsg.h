@@ -85,7 +85,10 @@ typedef struct {
  * * (mask_src[same index] > 0).   bias / add_src / mask_src may be NULL.  add_src may alias out (accumulate).
  * split_k > 1 (single dense segment, no ReLU): K slices are combined with fp32 atomics (output zeroed by the call). */
 int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                   const float* add_src, const float* mask_src, void* stream);
+                   const float* add_src, const float* mask_src, float* bn_partials, void* stream);
+/* bn_partials (optional, may be NULL): [m_tiles][2][N] per-tile column (sum, sum of squares) of the output, written
+ * by the epilogue so the following train-mode BatchNorm needs no extra pass over the activation
+ * (m_tiles = sum over segments of ceil(rows / BM), BM = tile_hint & 0xff); finalize with zsg_bn_stats_from_partials. */
 
 /* Weight gradient.  dw[n][(r*wS+s)*wC + wc0 + c] (+)= sum_rows dy[row][n] * src[gather(row, r, s)][c]
  * The descriptor is the FORWARD descriptor of the convolution (src = forward input, "out" geometry = dy); all
@@ -98,6 +101,11 @@ int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, fl
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */
 int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t dst_ld, void* stream);
+/* All dgrad weight images of a step in ONE launch.  jobs: device array of
+ * {int64 src_off, dst_off; int32 N, T, C, dst_ld, tile0, tiles_c, tiles_n, pad} (offsets in elements from the bases;
+ * tiles_c = ceil(C/32), tiles_n = ceil(dst_ld/32), tile0 = running sum of T*tiles_c*tiles_n). */
+int zsg_transpose_w_batched(const float* src_base, float* dst_base, const void* jobs, int32_t njobs, int32_t total_tiles,
+                            void* stream);
 /* dst[r][0:dst_ld] = [ src[r*src_ld + 0:C] | 0 ... ] */
 int zsg_pad_rows(const float* src, int64_t rows, int32_t C, int32_t src_ld, float* dst, int32_t dst_ld, void* stream);
 
@@ -114,6 +122,8 @@ size_t zsg_bn_workspace_bytes(int64_t rows, int32_t C);
 /* mean/invstd out; running_mean/var updated in place (unbiased var), NULL to skip. */
 int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* invstd, float* running_mean,
                  float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
+int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
+                               float* running_mean, float* running_var, float momentum, float eps, void* stream);
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
 int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                       float* invstd, void* stream);

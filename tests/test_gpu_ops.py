@@ -127,8 +127,25 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
     desc = ops.fwd_desc(src, ov, cp, Co, k, s, p, d, wC=cp, relu=relu, merge_x=mx, tile_hint=tile)
     bd = dev(b) if bias else None
     L.check(L.lib.zsg_conv_igemm(C.byref(desc), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr() if bias else None, None,
-                                 None, st), "igemm")
+                                 None, None, st), "igemm")
     assert_close(out.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, "conv fwd")
+    if not bias and not relu:
+        # fused BatchNorm statistics: per-tile (sum, sum^2) partials from the epilogue -> mean / invstd
+        for bm, bn_, w8 in ((64, 64, 0), (128, 64, 0), (128, 128, 1)):
+            if bn_ == 128 and (Co <= 64 or mx):
+                continue
+            d4 = ops.fwd_desc(src, ov, cp, Co, k, s, p, d, wC=cp, merge_x=mx, tile_hint=ops.tile_hint(bm, bn_, 1, w8))
+            chunks = (B * Ho * Wo + bm - 1) // bm
+            part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
+            L.check(L.lib.zsg_conv_igemm(C.byref(d4), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "igemm+stats")
+            yf = y_ref.detach().permute(0, 2, 3, 1).reshape(-1, Co).double()
+            assert_close(part[:, 0].double().sum(0), yf.sum(0), 1e-4, 1e-4 * float(yf.abs().sum(0).max()), "bn partial sums")
+            assert_close(part[:, 1].double().sum(0), (yf * yf).sum(0), 1e-4, 1e-6, "bn partial sums of squares")
+            mean, invstd = torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+            L.check(L.lib.zsg_bn_stats_from_partials(part.data_ptr(), chunks, B * Ho * Wo, Co, mean.data_ptr(), invstd.data_ptr(), None, None,
+                                                     0.1, 1e-5, st), "bn_from_partials")
+            assert_close(mean, yf.mean(0), 1e-4, 1e-5, "fused bn mean")
+            assert_close(invstd, 1 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5), 2e-4, 0, "fused bn invstd")
 
     # backward: dy is the gradient w.r.t. the pre-ReLU output
     gpre = gy * (y_ref > 0) if relu else gy
@@ -140,7 +157,8 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
     wdesc = ops.fwd_desc(src, dyv, cp, Co, k, s, p, d, wC=cp)
     L.check(L.lib.zsg_conv_wgrad(C.byref(wdesc), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgrad")
     assert_close(dw[..., :Ci].permute(0, 3, 1, 2), wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), "conv wgrad")
-    for hint, acc in ((ops.tile_hint(64, 64, 1), 1), (ops.tile_hint(128, 64, 3), 1), (ops.tile_hint(64, 128, 7), 0)):
+    for hint, acc in ((ops.tile_hint(64, 64, 1), 1), (ops.tile_hint(128, 64, 3), 1), (ops.tile_hint(64, 128, 7), 0),
+                      (ops.tile_hint(128, 128, 2, 1, 0), 0), (ops.tile_hint(128, 128, 3, 1, 1), 1), (ops.tile_hint(128, 128, 1, 0, 1), 0)):
         dw2 = torch.full((Co, k, k, cp), 1.0, device="cuda")
         wd2 = ops.fwd_desc(src, dyv, cp, Co, k, s, p, d, wC=cp, tile_hint=hint)
         L.check(L.lib.zsg_conv_wgrad(C.byref(wd2), xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, st), "wgrad hint")
@@ -161,13 +179,13 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
         ddesc = ops.dgrad_desc(dyv, dxv, Cop, cp, k, s, p, d)
         if ddesc.zero_fill:              # parity classes without any tap are not launched: the caller clears dx
             dx.zero_()
-        L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, st), "dgrad")
+        L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, None, st), "dgrad")
         assert_close(dx[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), "conv dgrad")
         # accumulate + relu-mask epilogue: out = (prev + acc) * (mask > 0)
         prev = torch.randn(B, H, W, cp, generator=g)
         mask = torch.randn(B, H, W, cp, generator=g)
         dx2, maskd = dev(prev), dev(mask)
-        L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx2.data_ptr(), None, dx2.data_ptr(), maskd.data_ptr(), st), "dgrad+")
+        L.check(L.lib.zsg_conv_igemm(C.byref(ddesc), dyd.data_ptr(), wt.data_ptr(), dx2.data_ptr(), None, dx2.data_ptr(), maskd.data_ptr(), None, st), "dgrad+")
         ref2 = (prev[..., :Ci] + xr.grad.permute(0, 2, 3, 1)) * (mask[..., :Ci] > 0)
         if not ddesc.zero_fill:          # (dropped parity classes are neither accumulated nor masked: never needed)
             assert_close(dx2[..., :Ci], ref2, 5e-4, 5e-4 * float(ref2.abs().max()), "dgrad accumulate+mask")
@@ -176,13 +194,13 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
             dx3 = torch.full((B, H, W, cp), float("nan"), device="cuda")
             if ddesc.nseg == 1 and s == 1:
                 d3 = ops.dgrad_desc(dyv, view_of(ops, dx3, B, H, W, cp), Cop, cp, k, s, p, d, tile_hint=ops.tile_hint(64, 64, sp))
-                L.check(L.lib.zsg_conv_igemm(C.byref(d3), dyd.data_ptr(), wt.data_ptr(), dx3.data_ptr(), None, None, None, st), "dgrad split-K")
+                L.check(L.lib.zsg_conv_igemm(C.byref(d3), dyd.data_ptr(), wt.data_ptr(), dx3.data_ptr(), None, None, None, None, st), "dgrad split-K")
                 assert_close(dx3[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), f"conv dgrad split-K {sp}")
     if not relu:
         for sp in (3, 8):
             out3 = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
             d3 = ops.fwd_desc(src, view_of(ops, out3, B, Ho, Wo, Co), cp, Co, k, s, p, d, wC=cp, merge_x=mx, tile_hint=ops.tile_hint(64, 64, sp))
-            L.check(L.lib.zsg_conv_igemm(C.byref(d3), xd.data_ptr(), wd.data_ptr(), out3.data_ptr(), bd.data_ptr() if bias else None, None, None, st), "fwd split-K")
+            L.check(L.lib.zsg_conv_igemm(C.byref(d3), xd.data_ptr(), wd.data_ptr(), out3.data_ptr(), bd.data_ptr() if bias else None, None, None, None, st), "fwd split-K")
             assert_close(out3.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, f"conv fwd split-K {sp}")
     torch.cuda.synchronize()
 
@@ -211,7 +229,7 @@ def test_conv_multilevel_shared_weights(Z):
     ov = ops.TView(out.view(-1), B, Co, Co, lv_out)
     desc = ops.fwd_desc(src, ov, Ci, Co, k, 1, 1, 1, wC=Ci)
     wd, bd = dev(ohwi(w)), dev(b)
-    L.check(L.lib.zsg_conv_igemm(C.byref(desc), packed.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr(), None, None, L.stream_ptr()), "igemm")
+    L.check(L.lib.zsg_conv_igemm(C.byref(desc), packed.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr(), None, None, None, L.stream_ptr()), "igemm")
     assert_close(out, ref, 2e-4, 2e-4, "multi-level conv")
     # wgrad accumulates over the levels
     gy = torch.randn(B, P, Co, generator=g)
@@ -436,7 +454,7 @@ def test_lstm_against_golden_and_oracle(Z, gold):
         d = ops.fwd_desc(src, gv, E, 4 * H, 1, 1, 0, 1, wC=E)
         wih, bih = dev(sd["lstm.weight_ih_l0" + suf]), dev(sd["lstm.bias_ih_l0" + suf])
         whh, bhh = dev(sd["lstm.weight_hh_l0" + suf]), dev(sd["lstm.bias_hh_l0" + suf])
-        L.check(L.lib.zsg_conv_igemm(C.byref(d), xin.data_ptr(), wih.data_ptr(), gin.data_ptr(), bih.data_ptr(), None, None, st), "lstm_in")
+        L.check(L.lib.zsg_conv_igemm(C.byref(d), xin.data_ptr(), wih.data_ptr(), gin.data_ptr(), bih.data_ptr(), None, None, None, st), "lstm_in")
         gates, cst, hprev = (torch.zeros(B, Tn, 4 * H, device="cuda"), torch.zeros(B, Tn, H, device="cuda"), torch.zeros(B, Tn, H, device="cuda"))
         h0d, c0d = dev(h0[di]), dev(c0[di])
         L.check(L.lib.zsg_lstm_fwd(gin.data_ptr(), whh.data_ptr(), bhh.data_ptr(), h0d.data_ptr(), c0d.data_ptr(), ld.data_ptr(),

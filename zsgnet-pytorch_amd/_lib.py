@@ -46,14 +46,16 @@ DP = C.POINTER(ConvDesc)
 SIGNATURES = {
     "zsg_version": (I32, []),
     "zsg_last_error": (C.c_char_p, []),
-    "zsg_conv_igemm": (I32, [DP, P, P, P, P, P, P, P]),
+    "zsg_conv_igemm": (I32, [DP, P, P, P, P, P, P, P, P]),
     "zsg_conv_wgrad_workspace_bytes": (SZ, [DP]),
     "zsg_conv_wgrad": (I32, [DP, P, P, P, I32, P, SZ, P]),
     "zsg_transpose_w": (I32, [P, P, I32, I32, I32, I32, P]),
+    "zsg_transpose_w_batched": (I32, [P, P, P, I32, I32, P]),
     "zsg_pad_rows": (I32, [P, I64, I32, I32, P, I32, P]),
     "zsg_colsum": (I32, [P, I32, I64, I32, I32, I32, I32, P, I32, P]),
     "zsg_bn_workspace_bytes": (SZ, [I64, I32]),
     "zsg_bn_stats": (I32, [P, I64, I32, P, P, P, P, F32, F32, P, SZ, P]),
+    "zsg_bn_stats_from_partials": (I32, [P, I32, I64, I32, P, P, P, P, F32, F32, P]),
     "zsg_bn_eval_stats": (I32, [P, P, I32, F32, P, P, P]),
     "zsg_bn_apply": (I32, [P, I64, I32, P, P, P, P, P, I32, P, P]),
     "zsg_bn_backward": (I32, [P, P, P, I64, I32, P, P, P, P, P, P, P, I32, P, SZ, P]),

@@ -220,6 +220,18 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     return 0;
 }
 
+// Finalize only: the (sum, sum^2) partials were produced by the convolution's epilogue (zsg_conv_igemm bn_partials).
+extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
+                                          float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+    ZSG_REQUIRE(partials && mean && invstd && chunks > 0 && rows > 0 && C > 0, "bn_stats_from_partials: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, partials, chunks, C, rows, mean, invstd,
+                       running_mean, running_var, momentum, eps);
+    ZSG_CHECK_LAUNCH("bn_stats_from_partials");
+    return 0;
+}
+
 extern "C" int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                                  float* invstd, void* stream) {
     ZSG_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "bn_eval_stats: bad argument");

@@ -31,6 +31,7 @@ struct IgParams {
     const float* bias;
     const float* add_src;
     const float* mask_src;
+    float* stats;     // optional BatchNorm partials [m_tiles][2][N]: per-tile column sums / sums of squares of the output
     int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, relu, nseg;
     int m_tiles, n_tiles;
     int splits;       // split-K factor (1: plain stores; >1: fp32 atomic accumulation into a zeroed / pre-filled output)
@@ -210,6 +211,42 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
+    // ---- fused BatchNorm statistics: per-column (sum, sum^2) over this tile's rows (dead rows hold exact zeros) -----
+    if (p.stats) {
+        float* red = smem;                            // [2][WM][BN] — the K-loop tiles are no longer needed
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][j][e];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                const int cl = wn * (BN / WN) + j * 32 + li;
+                red[wm * BN + cl] = s1;
+                red[(WM + wm) * BN + cl] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s1 += red[w * BN + tid];
+                s2 += red[(WM + w) * BN + tid];
+            }
+            float* o = p.stats + (size_t)mt * 2 * p.N;
+            o[n0 + tid] = s1;
+            o[p.N + n0 + tid] = s2;
+        }
+    }
+
     // ---- epilogue: bias, residual add, relu, relu-mask ---------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -334,7 +371,7 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int
 }
 
 extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                              const float* add_src, const float* mask_src, void* stream) {
+                              const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
     int BM = 64, BN = 64, splits = 1, w8 = 0;
     pick_tile(d, &BM, &BN, &splits, &w8);
@@ -347,6 +384,8 @@ extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const fl
     p.src = src; p.wt = wt; p.out = out; p.bias = bias; p.add_src = add_src; p.mask_src = mask_src;
     p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
+    p.stats = bn_partials;
+    if (bn_partials) ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu, "conv_igemm: BN-statistics fusion needs a plain (bias-free, unsplit) convolution");
     hipStream_t st = (hipStream_t)stream;
     if (splits > 1) {
         ZSG_REQUIRE(!d->relu && d->nseg == 1 && d->out_ld == d->N && d->seg[0].osy == 1 && d->seg[0].osx == 1 &&

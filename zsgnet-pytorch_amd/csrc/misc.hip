@@ -357,6 +357,50 @@ extern "C" int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t 
     return 0;
 }
 
+// Batched form: ONE launch refreshes every dgrad weight image of the step.  jobs[j] = {src_off, dst_off, N, T, C,
+// dst_ld, tile0, tiles_c} (element offsets from src_base / dst_base; tile0 = first flat tile index of job j).
+struct ZsgTransposeJob {
+    int64_t src_off, dst_off;
+    int32_t N, T, C, dst_ld, tile0, tiles_c, tiles_n, pad;
+};
+__global__ void transpose_w_batched_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                           const ZsgTransposeJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = njobs - 1;                      // last job whose tile0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ZsgTransposeJob jb = jobs[lo];
+    int t = blockIdx.x - jb.tile0;
+    const int tc = t % jb.tiles_c;
+    t /= jb.tiles_c;
+    const int tn = t % jb.tiles_n;
+    const int tap = t / jb.tiles_n;
+    const float* src = src_base + jb.src_off;
+    float* dst = dst_base + jb.dst_off;
+    const int n0 = tn * 32, c0 = tc * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int n = n0 + j, c = c0 + tx;
+        tile[j][tx] = (n < jb.N && c < jb.C) ? src[((int64_t)n * jb.T + tap) * jb.C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, n = n0 + tx;
+        if (c < jb.C && n < jb.dst_ld) dst[((int64_t)c * jb.T + tap) * jb.dst_ld + n] = tile[tx][j];
+    }
+}
+extern "C" int zsg_transpose_w_batched(const float* src_base, float* dst_base, const void* jobs, int32_t njobs, int32_t total_tiles,
+                                       void* stream) {
+    ZSG_REQUIRE(src_base && dst_base && jobs && njobs > 0 && total_tiles > 0, "transpose_w_batched: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("transpose_w", st, 0, 0);
+    hipLaunchKernelGGL(transpose_w_batched_kernel, dim3(total_tiles), dim3(256), 0, st, src_base, dst_base, (const ZsgTransposeJob*)jobs, njobs);
+    ZSG_CHECK_LAUNCH("transpose_w_batched");
+    return 0;
+}
+
 // ---- column sums ---------------------------------------------------------------------------------------------------------
 // grid (col blocks of 64, row splits, groups); block 256 = 64 columns x 4 row lanes; atomics merge the row splits.
 __global__ void colsum_kernel(const float* __restrict__ x, int64_t gstride, int rows, int ld, int c0, int C, float* __restrict__ out,

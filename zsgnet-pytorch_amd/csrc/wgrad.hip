@@ -47,12 +47,15 @@ __device__ __forceinline__ int fdiv(int a, int d, float rcp) {   // a < 2^24, ex
     return q;
 }
 
-template <int TM, int TN, int WG_BK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+// Block tile (32*TM*WM) x (32*TN*WN) computed by WM x WN waves, each TM x TN MFMA tiles of 32x32.
+template <int TM, int TN, int WG_BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDA = BM + WG_PAD, LDB = BN + WG_PAD;
-    constexpr int GA = BM / 4, PA = 256 / GA, NA = WG_BK / PA;      // A staging: groups/row, rows/pass, passes
-    constexpr int GB = BN / 4, PB = 256 / GB, NB = WG_BK / PB;
+    constexpr int GA = BM / 4, PA = NT / GA, NA = WG_BK / PA;       // A staging: groups/row, rows/pass, passes
+    constexpr int GB = BN / 4, PB = NT / GB, NB = WG_BK / PB;
+    static_assert(NA >= 1 && NB >= 1, "K tile too short for this thread count");
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];
     typedef float (*TileA)[WG_BK][LDA];
     typedef float (*TileB)[WG_BK][LDB];
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     const int nmn = p.m_tiles * p.n_tiles;
@@ -315,11 +318,12 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
     // tile_hint = BM | (BN << 8) | (splits << 16) (BM over output channels, BN over weight columns); 0 = heuristic
     int TM = (d->N > 64) ? 2 : 1;
     int TN = (p.ncols > 64) ? 2 : 1;
-    int want_splits = 0;
+    int want_splits = 0, w8 = 0;
     if (d->tile_hint) {
         TM = ((d->tile_hint & 0xff) >= 128) ? 2 : 1;
         TN = (((d->tile_hint >> 8) & 0xff) >= 128) ? 2 : 1;
         want_splits = (d->tile_hint >> 16) & 0xff;
+        w8 = ((d->tile_hint >> 24) & 1) && TM == 2 && TN == 2;      // 8-wave workgroup: 128x128 tile only
     }
     p.m_tiles = cdiv(d->N, 64 * TM);
     p.n_tiles = cdiv(p.ncols, 64 * TN);
@@ -337,28 +341,32 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
     }
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("conv_wgrad", st, 2.0 * rows_all * d->N * p.ncols, 0);
-    dim3 grid(nmn * p.splits), block(256);
-#define WG_LAUNCH(TM_, TN_, BK_)                                                                                           \
+    dim3 grid(nmn * p.splits);
+#define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_)                                                                                 \
     do {                                                                                                                   \
-        const size_t lds = (size_t)2 * BK_ * ((64 * TM_ + WG_PAD) + (64 * TN_ + WG_PAD)) * sizeof(float);                   \
+        const size_t lds = (size_t)2 * BK_ * ((32 * TM_ * WM_ + WG_PAD) + (32 * TN_ * WN_ + WG_PAD)) * sizeof(float);       \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_>,                          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
-        hipLaunchKernelGGL((wgrad_kernel<TM_, TN_, BK_>), grid, block, lds, st, p);                                         \
+        hipLaunchKernelGGL((wgrad_kernel<TM_, TN_, BK_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), lds, st, p);                \
     } while (0)
-    if (BKsel == 32) {
-        if (TM == 2 && TN == 2) WG_LAUNCH(2, 2, 32);
-        else if (TM == 2 && TN == 1) WG_LAUNCH(2, 1, 32);
-        else if (TM == 1 && TN == 2) WG_LAUNCH(1, 2, 32);
-        else WG_LAUNCH(1, 1, 32);
+    if (w8) {
+        if (BKsel == 32) WG_LAUNCH(2, 1, 32, 2, 4);
+        else WG_LAUNCH(2, 1, 16, 2, 4);
+    } else if (BKsel == 32) {
+        if (TM == 2 && TN == 2) WG_LAUNCH(2, 2, 32, 2, 2);
+        else if (TM == 2 && TN == 1) WG_LAUNCH(2, 1, 32, 2, 2);
+        else if (TM == 1 && TN == 2) WG_LAUNCH(1, 2, 32, 2, 2);
+        else WG_LAUNCH(1, 1, 32, 2, 2);
     } else {
-        if (TM == 2 && TN == 2) WG_LAUNCH(2, 2, 16);
-        else if (TM == 2 && TN == 1) WG_LAUNCH(2, 1, 16);
-        else if (TM == 1 && TN == 2) WG_LAUNCH(1, 2, 16);
-        else WG_LAUNCH(1, 1, 16);
+        if (TM == 2 && TN == 2) WG_LAUNCH(2, 2, 16, 2, 2);
+        else if (TM == 2 && TN == 1) WG_LAUNCH(2, 1, 16, 2, 2);
+        else if (TM == 1 && TN == 2) WG_LAUNCH(1, 2, 16, 2, 2);
+        else WG_LAUNCH(1, 1, 16, 2, 2);
     }
 #undef WG_LAUNCH
     if (p.splits > 1) {

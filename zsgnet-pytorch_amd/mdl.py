@@ -395,7 +395,11 @@ class _Plan:
         self.wt: Dict[str, torch.Tensor] = {}
         self.grad_ready: Dict[str, int] = {}
         self.reducer = None
+        self.wt_jobs, self.wt_arena_used = [], 0
+        self.wt_arena = self._buf(net.store.total + 4096 * len(net.convs)) if training else None
         self._lower()
+        if training:
+            self._finish_prep()
 
     # ---- allocation helpers --------------------------------------------------------------------------------
     def _buf(self, n, dtype=torch.float32):
@@ -444,7 +448,9 @@ class _Plan:
         return self.net.store.raw(name, self.net.store.grad)
 
     # ---- op lowering ---------------------------------------------------------------------------------------------
-    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None) -> Act:
+    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None, bn_fuse: Optional[BnL] = None) -> Act:
+        """bn_fuse: the output feeds a train-mode BatchNorm — let the epilogue emit the per-tile (sum, sum^2) partials
+        (no extra pass over the activation) unless the autotuner chose split-K for this layer."""
         if out is None:
             lv = src.levels
             assert len(lv) == 1
@@ -452,19 +458,51 @@ class _Plan:
                            conv_out(lv[0].W, L.k, L.stride, L.pad, L.dil), L.cout)
         d = fwd_desc(src, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
         bias = self.P(L.name + ".bias") if L.bias else None
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None), stream_ptr())
-        self.fwd.add(lib.zsg_conv_igemm, d, src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, what=L.name)
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, None), stream_ptr())
+        partials = None
+        out.bn_chunks = 0
+        if bn_fuse is not None and self.training and d.tile_hint and ((d.tile_hint >> 16) & 0xff) <= 1 and not L.bias and not relu:
+            bm = d.tile_hint & 0xff
+            chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
+            if chunks * 2 * L.cout * 4 <= self.ws_bytes:
+                partials, out.bn_chunks = self.ws, chunks
+        self.fwd.add(lib.zsg_conv_igemm, d, src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, partials, what=L.name)
+        if partials is not None:         # finalize at once: the shared workspace is reused by the next launch
+            Lb = bn_fuse
+            rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
+            out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
+            rm, rv = self.net._rm[Lb.index:Lb.index + Lb.c], self.net._rv[Lb.index:Lb.index + Lb.c]
+            self.fwd.add(lib.zsg_bn_stats_from_partials, self.ws, out.bn_chunks, rows, Lb.c, out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5,
+                         what="stats:" + Lb.name)
         out.needs_mask = relu
         self.tape.append(lambda: self._conv_bwd(L, src, out))
         return out
 
     def _wt(self, L: ConvL, cred: int) -> torch.Tensor:
-        """transposed weight image [cpad][k*k][cred] for the data gradient, refreshed by the bwd-prep program"""
+        """transposed weight image [cpad][k*k][cred] for the data gradient (a slice of one arena); all images are
+        refreshed by ONE batched transpose launch at the start of backward (built in _finish_prep)"""
         if L.name not in self.wt:
-            t = self._buf(L.cpad * L.k * L.k * cred)
-            self.wt[L.name] = t
-            self.prep.add(lib.zsg_transpose_w, self.P(L.name + ".weight"), t, L.cout, L.k * L.k, L.cpad, cred, what="T:" + L.name)
+            n = L.cpad * L.k * L.k * cred
+            off = self.wt_arena_used
+            self.wt_arena_used += (n + 3) // 4 * 4
+            assert self.wt_arena_used <= self.wt_arena.numel(), "dgrad weight arena too small"
+            self.wt[L.name] = self.wt_arena[off:off + n]
+            e = self.net.store.entries[L.name + ".weight"]
+            self.wt_jobs.append((e.offset, off, L.cout, L.k * L.k, L.cpad, cred))
         return self.wt[L.name]
+
+    def _finish_prep(self):
+        import struct
+        if not self.wt_jobs:
+            return
+        blob, tile0 = b"", 0
+        for (so, do, N, T, Cc, ld) in self.wt_jobs:
+            tc, tn = (Cc + 31) // 32, (ld + 31) // 32
+            blob += struct.pack("<qqiiiiiiii", so, do, N, T, Cc, ld, tile0, tc, tn, 0)
+            tile0 += T * tc * tn
+        self.wt_jobs_dev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.dev)
+        self.prep.add(lib.zsg_transpose_w_batched, self.net.store.flat, self.wt_arena, self.wt_jobs_dev, len(self.wt_jobs), tile0,
+                      what="transpose all dgrad weight images")
 
     def _conv_bwd(self, L: ConvL, src: Act, out: Act, dy: Optional[Act] = None):
         dy = dy or out.grad
@@ -508,7 +546,7 @@ class _Plan:
             assert len(deltas) == 1 and src.ld == dx.ld, "ReLU mask needs one common offset between src and its gradient"
             mask = src.buf.data_ptr() + 4 * deltas.pop()
             self.bwd.keep.append(src.buf)
-        args = (dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None, mask)
+        args = (dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None, mask, None)
         autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr())
         self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
         dx.gfilled = True
@@ -518,11 +556,14 @@ class _Plan:
         lv = x.levels[0]
         out = self.act(name or L.name, x.B, lv.H, lv.W, L.c)
         rows = x.B * lv.H * lv.W
-        mean, invstd = self._buf(L.c), self._buf(L.c)
+        fused = self.training and getattr(x, "bn_chunks", 0) > 0
+        mean, invstd = (x.bn_mean, x.bn_invstd) if fused else (self._buf(L.c), self._buf(L.c))
         rm, rv = net._rm[L.index:L.index + L.c], net._rv[L.index:L.index + L.c]
         self.ws_need = max(getattr(self, "ws_need", 0), lib.zsg_bn_workspace_bytes(rows, L.c))
         gam, bet = self.P(L.name + ".weight"), self.P(L.name + ".bias")
-        if self.training:
+        if fused:
+            pass                          # statistics were finalized right after the producing convolution
+        elif self.training:
             self.fwd.add(lib.zsg_bn_stats, x.buf, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, self.ws, self.ws_bytes, what=L.name)
         else:
             self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name)
@@ -554,7 +595,7 @@ class _Plan:
         e = "backbone.encoder."
         # shared BN workspace: sized generously up-front (largest rows*C is the stem's conv output)
         H1, W1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
-        self.ws_bytes = 8 << 20          # >= zsg_bn_workspace_bytes for every layer (chunks*2*C floats <= ~2.2 MB); checked by the library
+        self.ws_bytes = 32 << 20         # BN partials: >= zsg_bn_workspace_bytes for every layer, and the conv-epilogue partials
         self.ws = self._buf(self.ws_bytes // 4)
         self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
@@ -579,7 +620,7 @@ class _Plan:
         if net.use_img and net.backbone_kind == "ssd_vgg":
             feats = self._lower_ssd(x0)
         elif net.use_img:
-            y = self.conv(C[e + "conv1"], x0, name="stem.y")
+            y = self.conv(C[e + "conv1"], x0, name="stem.y", bn_fuse=BN[e + "bn1"])
             a = self.bn(BN[e + "bn1"], y, relu=True, name="stem.a")
             H2, W2 = conv_out(H1, 3, 2, 1), conv_out(W1, 3, 2, 1)
             x = self.act("pool", B, H2, W2, 64)
@@ -697,20 +738,20 @@ class _Plan:
         net = self.net
         C, BN, q = net.convs, net.bns, blk["prefix"]
         if net.block_kind == "bottleneck":
-            y1 = self.conv(C[q + "conv1"], x, name=q + "y1")
+            y1 = self.conv(C[q + "conv1"], x, name=q + "y1", bn_fuse=BN[q + "bn1"])
             a1 = self.bn(BN[q + "bn1"], y1, True, name=q + "a1")
-            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2")
+            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
             a2 = self.bn(BN[q + "bn2"], y2, True, name=q + "a2")
-            y3 = self.conv(C[q + "conv3"], a2, name=q + "y3")
+            y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
             last_bn, last_y = BN[q + "bn3"], y3
         else:
-            y1 = self.conv(C[q + "conv1"], x, name=q + "y1")
+            y1 = self.conv(C[q + "conv1"], x, name=q + "y1", bn_fuse=BN[q + "bn1"])
             a1 = self.bn(BN[q + "bn1"], y1, True, name=q + "a1")
-            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2")
+            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
             last_bn, last_y = BN[q + "bn2"], y2
         res = x
         if blk["ds"]:
-            yd = self.conv(C[q + "downsample.0"], x, name=q + "yd")
+            yd = self.conv(C[q + "downsample.0"], x, name=q + "yd", bn_fuse=BN[q + "downsample.1"])
             res = self.bn(BN[q + "downsample.1"], yd, False, name=q + "rd")
         return self.bn(last_bn, last_y, True, residual=res, name=q + "out")
 
@@ -790,7 +831,7 @@ class _Plan:
             gin = self.act("gin" + suf, B, 1, Tn, H4)
             d = fwd_desc(xin, gin, E, H4, 1, 1, 0, 1, wC=E)
             self.fwd.add(lib.zsg_conv_igemm, d, xin.buf, self.P("lstm.weight_ih_l0" + suf), gin.buf, self.P("lstm.bias_ih_l0" + suf),
-                         None, None, what="lstm_in" + suf)
+                         None, None, None, what="lstm_in" + suf)
             gates, cst, hprev = self._buf(B * Tn * H4), self._buf(B * Tn * Hd), self._buf(B * Tn * Hd)
             h0 = self.in_h0[di * B * Hd:(di + 1) * B * Hd]
             c0 = self.in_c0[di * B * Hd:(di + 1) * B * Hd]

@@ -311,6 +311,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                         cands.append(tile_hint(bm, bn, sp))
                         if bm == 128 and bn == 128:
                             cands.append(tile_hint(bm, bn, sp, 0, 1))
+                            cands.append(tile_hint(bm, bn, sp, 1, 0))          # 8-wave workgroup
+                            cands.append(tile_hint(bm, bn, sp, 1, 1))
     conv = marshal(fn, (d,) + tuple(args))
     best, best_t = 0, float("inf")
     for h in cands:
