@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-out", default="")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in the RCCL data-parallel reducer even at world size 1 (smoke test)")
     return ap.parse_args()
 
 
@@ -84,12 +85,19 @@ def main():
     from zsgnet_pytorch_amd._lib import ProfEntry, lib
     if world > 1:
         zdist.init_process_group_from_env("nccl")
+    elif a.force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1)
 
     cfg = config.get_cfg(resnet_arch=a.arch, bs=a.bs, resize_img=[a.img, a.img])
     torch.manual_seed(1234)                       # identical initial weights on every rank (and C3 broadcasts anyway)
     net = mdl.get_default_net(9, cfg).to("cuda")
     net.train()
-    model = zdist.DistributedDataParallel(net, device_ids=[local], broadcast_buffers=True) if world > 1 else net
+    model = zdist.DistributedDataParallel(net, device_ids=[local], broadcast_buffers=True) if (world > 1 or a.force_ddp) else net
+    if a.force_ddp and world == 1:
+        model.world = 2                  # exercise broadcast / bucketed all-reduce code paths (a 1-rank group: values unchanged)
+
     r, s = config.ratios_scales(cfg)
     lf, ev = loss.get_default_loss(r, s, cfg), evaluator.get_default_eval(r, s, cfg)
     opt = optim.FusedAdam(net, lr=cfg["lr"], betas=(0.9, 0.99))
