@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
         n_it = min(per, n_it_all - it0);
     }
 
-    f32x4 ra[RA], rb[RB];
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];      // two register stages: global loads run TWO K tiles ahead
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.wt);
     // K-iteration counters of the NEXT tile to load (wave-uniform)
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
     int jx = (it0 / n_cc) % n_jx;
     int jy = it0 / (n_cc * n_jx);
 
-    auto load_tile = [&]() {
+    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
         int ws_, dxx, koff;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
         float* a = As + buf * BM * IG_LDK;
         float* b = Bs + buf * BN * IG_LDK;
 #pragma unroll
@@ -179,8 +179,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
-        load_tile();
-        store_tile(0);
+        load_tile(ra0, rb0);
+        store_tile(0, ra0, rb0);
+        if (n_it > 1) load_tile(ra0, rb0);           // tile 1 stays in flight across the first compute phase
     }
     __syncthreads();
 
@@ -188,9 +189,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
     const int a_row = wm * (BM / WM) + li;
     const int b_row = wn * (BN / WN) + li;
 
-    for (int it = 0; it < n_it; ++it) {
-        const bool more = (it + 1) < n_it;
-        if (more) load_tile();
+    // one K tile: prefetch tile it+2 into `nxt`, MFMA on LDS[it&1], then park tile it+1 (already in `cur`) in the other
+    // LDS buffer.  The global->register latency is covered by two compute phases instead of one.
+    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB]) {
+        if (it + 2 < n_it) load_tile(nxt_a, nxt_b);
         const float* a = As + (it & 1) * BM * IG_LDK + a_row * IG_LDK + 4 * lh;
         const float* b = Bs + (it & 1) * BN * IG_LDK + b_row * IG_LDK + 4 * lh;
 #pragma unroll
@@ -208,8 +210,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile((it + 1) & 1);
+        if (it + 1 < n_it) store_tile((it + 1) & 1, cur_a, cur_b);
         __syncthreads();
+    };
+    for (int it = 0; it < n_it; it += 2) {
+        k_step(it, ra0, rb0, ra1, rb1);
+        if (it + 1 < n_it) k_step(it + 1, ra1, rb1, ra0, rb0);
     }
 
     // ---- fused BatchNorm statistics: per-column (sum, sum^2) over this tile's rows (dead rows hold exact zeros) -----
