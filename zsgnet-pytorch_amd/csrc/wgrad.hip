@@ -102,8 +102,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     WgSegDev sg = p.seg[si];
     int kt_next = kt_begin;
 
-    f32x4 ra[NA], rb[NB];
-    auto load_tile = [&]() {
+    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];      // two register stages: global loads run two K tiles ahead
+    auto load_tile = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
         if (si + 1 < p.nseg && kt_next >= p.seg[si + 1].kt0) {     // wave-uniform segment switch
             ++si;
             sg = p.seg[si];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
         }
         ++kt_next;
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) *(f32x4*)&As[buf][ka + PA * j][4 * ga] = ra[j];
 #pragma unroll
@@ -163,9 +163,11 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (kt_begin < kt_end) {
-        load_tile();
-        store_tile(0);
+    const int n_kt = kt_end - kt_begin;
+    if (n_kt > 0) {
+        load_tile(ra0, rb0);
+        store_tile(0, ra0, rb0);
+        if (n_kt > 1) load_tile(ra0, rb0);
     }
     __syncthreads();
 
@@ -173,10 +175,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     // so the epilogue's stores are 128-byte coalesced.
     const int am = wm * (32 * TM) + li;
     const int bn = wn * (32 * TN) + li;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        const bool more = (kt + 1) < kt_end;
-        if (more) load_tile();
+    auto k_step = [&](int it, f32x4 (&cur_a)[NA], f32x4 (&cur_b)[NB], f32x4 (&nxt_a)[NA], f32x4 (&nxt_b)[NB]) {
+        const int buf = it & 1;
+        if (it + 2 < n_kt) load_tile(nxt_a, nxt_b);
 #pragma unroll
         for (int kk = 0; kk < WG_BK / 2; ++kk) {
             const int k = 2 * kk + lh;
@@ -191,8 +192,12 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+        if (it + 1 < n_kt) store_tile(buf ^ 1, cur_a, cur_b);
         __syncthreads();
+    };
+    for (int it = 0; it < n_kt; it += 2) {
+        k_step(it, ra0, rb0, ra1, rb1);
+        if (it + 1 < n_kt) k_step(it + 1, ra1, rb1, ra0, rb0);
     }
     if (kt_begin >= kt_end || (p.dbg & 2)) return;
 
