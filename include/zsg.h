@@ -168,6 +168,16 @@ int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t
 int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, const float* gx, int32_t B, int32_t h,
                        int32_t w, int32_t Cf, int32_t Cw, int32_t use_grid, int32_t ld, float* out, void* stream);
 
+/* Head conv0 (mdl.py:216, 514 -> 256, 3x3 pad 1) without its spatially-constant input channels: the language vector
+ * is constant over the image and the grid channels do not depend on the batch index, so only the 256 feature channels
+ * go through the implicit GEMM (half the MACs of the reference's dense conv); their contribution is an additive map
+ *   out[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9 + tap],   V = W[:, :, lang] * we[b]  (tiny GEMM),
+ * and the backward needs the validity-masked sums  S1[b][n*9+tap] += sum_{p: tap valid at p} dy[b][p][n]  (S2 = the
+ * [n*9+tap][b] transpose) plus the batch sum of dy for the grid weights.  dy / out: one pyramid level [B][h*w][N]. */
+int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int32_t w, int32_t N, float* out, void* stream);
+int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* S1, float* S2, void* stream);
+int zsg_batch_sum(const float* x, int32_t B, int64_t stride, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * BiLSTM query encoder — nn.LSTM(300,128,bidirectional) on a PackedSequence + last-token gather, mdl.py:296-336.
  * gin: input projections x_t W_ih^T + b_ih  [B][T][4H] (made with zsg_conv_igemm);  one launch per direction.

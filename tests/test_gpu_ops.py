@@ -253,6 +253,92 @@ def test_conv_multilevel_shared_weights(Z):
     assert_close(dw.permute(0, 3, 1, 2), wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), "multi-level wgrad")
 
 
+@pytest.mark.parametrize("B,h,w", [(2, 5, 7), (3, 1, 1), (16, 2, 2)])
+def test_head_conv0_decomposition(Z, B, h, w):
+    """mdl.py:69-104 + :379 — conv0 over [feat | lang (constant over pixels) | grid (constant over batch)] equals the
+    feature-window conv plus the additive map of zsg_head_lang_map; backward: the validity-masked sums of
+    zsg_head_border_sums / zsg_batch_sum give the lang / grid columns of dW and d(we).  fp32 sums: rel 5e-4."""
+    L, ops = Z
+    g = torch.Generator().manual_seed(h * 10 + w)
+    Cf, Cw, N, k = 32, 24, 64, 3
+    Ct = Cf + Cw + 2
+    cp = pad4(Ct)
+    feat = torch.randn(B, Cf, h, w, generator=g)
+    we = torch.randn(B, Cw, generator=g)
+    grid = torch.from_numpy(O.create_grid(h, w).reshape(h, w, 2).astype(np.float32)).permute(2, 0, 1)
+    x = torch.cat([feat, we[:, :, None, None].expand(B, Cw, h, w), grid[None].expand(B, 2, h, w)], 1).requires_grad_()
+    wt = (torch.randn(N, Ct, k, k, generator=g) / 10).requires_grad_()
+    bias = torch.randn(N, generator=g)
+    y = F.relu(F.conv2d(x, wt, bias, 1, 1))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dy_ref = (gy * (y > 0)).permute(0, 2, 3, 1).contiguous()            # gradient w.r.t. the pre-ReLU output, NHWC
+
+    W0 = dev(ohwi(wt.detach(), cp))                                        # [N][3][3][cp]
+    wed, featd, biasd = dev(we), dev(nhwc(feat)), dev(bias)
+    st = L.stream_ptr()
+    # V = W0[..., lang] . we  -> [B][N*9]
+    V = torch.empty(B, N * 9, device="cuda")
+    dv = ops.fwd_desc(view_of(ops, wed, B, 1, 1, Cw), view_of(ops, V, B, 1, 1, N * 9), Cw, N * 9, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
+    L.check(L.lib.zsg_conv_igemm(C.byref(dv), wed.data_ptr(), W0.data_ptr(), V.data_ptr(), None, None, None, None, st), "V")
+    Vref = torch.einsum("ntc,bc->bnt", ohwi(wt.detach(), cp).reshape(N, 9, cp)[:, :, Cf:Cf + Cw], we).reshape(B, N * 9)
+    assert_close(V, Vref, 2e-4, 2e-4, "V")
+    # G = conv(grid, W0[..., grid])
+    gm = torch.zeros(h, w, 4)
+    gm[..., :2] = grid.permute(1, 2, 0)
+    gmd = dev(gm)
+    G = torch.empty(h * w, N, device="cuda")
+    dg = ops.fwd_desc(view_of(ops, gmd, 1, h, w, 4), view_of(ops, G, 1, h, w, N), 4, N, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
+    L.check(L.lib.zsg_conv_igemm(C.byref(dg), gmd.data_ptr(), W0.data_ptr(), G.data_ptr(), None, None, None, None, st), "G")
+    Gref = F.conv2d(grid[None], wt.detach()[:, Cf + Cw:], None, 1, 1)[0].permute(1, 2, 0).reshape(h * w, N)
+    assert_close(G, Gref, 2e-4, 2e-4, "G")
+    lmap = torch.empty(B, h, w, N, device="cuda")
+    L.check(L.lib.zsg_head_lang_map(V.data_ptr(), G.data_ptr(), B, h, w, N, lmap.data_ptr(), st), "lang_map")
+    lref = F.conv2d(x.detach()[:, Cf:], wt.detach()[:, Cf:], None, 1, 1).permute(0, 2, 3, 1)
+    assert_close(lmap, lref, 2e-4, 2e-4, "lang map")
+    out = torch.empty(B, h, w, N, device="cuda")
+    d0 = ops.fwd_desc(view_of(ops, featd, B, h, w, Cf), view_of(ops, out, B, h, w, N), Cf, N, 3, 1, 1, 1, wC=cp, wc0=0, relu=True)
+    L.check(L.lib.zsg_conv_igemm(C.byref(d0), featd.data_ptr(), W0.data_ptr(), out.data_ptr(), biasd.data_ptr(), lmap.data_ptr(), None, None, st), "conv0")
+    assert_close(out, y.permute(0, 2, 3, 1), 3e-4, 3e-4, "conv0 = window conv + map")
+
+    # ---- backward ---------------------------------------------------------------------------------------------------
+    dyd = dev(dy_ref)
+    dW = torch.full((N, 3, 3, cp), float("nan"), device="cuda")
+    dyv = view_of(ops, dyd, B, h, w, N)
+    dwf = ops.fwd_desc(view_of(ops, featd, B, h, w, Cf), dyv, Cf, N, 3, 1, 1, 1, wC=cp, wc0=0)
+    L.check(L.lib.zsg_conv_wgrad(C.byref(dwf), featd.data_ptr(), dyd.data_ptr(), dW.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgrad feat")
+    S = torch.zeros(2 * B * 9 * N, device="cuda")
+    S2p = S[B * 9 * N:]
+    L.check(L.lib.zsg_head_border_sums(dyd.data_ptr(), B, h, w, N, S.data_ptr(), S2p.data_ptr(), st), "border sums")
+    valid = torch.zeros(9, h, w)
+    for r in range(3):
+        for q in range(3):
+            ys, xs_ = torch.arange(h) + r - 1, torch.arange(w) + q - 1
+            valid[r * 3 + q] = ((ys >= 0) & (ys < h))[:, None] * ((xs_ >= 0) & (xs_ < w))[None, :]
+    S1ref = torch.einsum("bhwn,thw->bnt", dy_ref, valid).reshape(B, N * 9)
+    assert_close(S[:B * 9 * N].view(B, N * 9), S1ref, 2e-4, 2e-4 * float(S1ref.abs().max()), "S1")
+    assert_close(S2p.view(N * 9, B), S1ref.t(), 2e-4, 2e-4 * float(S1ref.abs().max()), "S2")
+    S1v = view_of(ops, S[:B * 9 * N], B, 1, 1, N * 9)
+    dwl = ops.fwd_desc(view_of(ops, wed, B, 1, 1, Cw), S1v, Cw, N * 9, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
+    L.check(L.lib.zsg_conv_wgrad(C.byref(dwl), wed.data_ptr(), S.data_ptr(), dW.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgrad lang")
+    # d(we)[b][c] = sum_{n,tap} S1[b][n*9+tap] W0[n][tap][Cf+c]: a wgrad whose 'pixels' are the N*9 weight rows
+    Wrows = ops.TView(W0.view(-1), 1, Cw, cp, [ops.Level(Cf, 1, N * 9, N * 9 * cp)])
+    S2v = ops.TView(S, 1, B, B, [ops.Level(B * 9 * N, 1, N * 9, N * 9 * B)])
+    gwe = torch.full((B, Cw), float("nan"), device="cuda")
+    dwe = ops.fwd_desc(Wrows, S2v, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
+    L.check(L.lib.zsg_conv_wgrad(C.byref(dwe), W0.data_ptr(), S.data_ptr(), gwe.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "dwe")
+    gwe_ref = x.grad[:, Cf:Cf + Cw].sum((2, 3))
+    assert_close(gwe, gwe_ref, 5e-4, 5e-4 * float(gwe_ref.abs().max()), "d(we)")
+    dys = torch.empty(h * w * N, device="cuda")
+    L.check(L.lib.zsg_batch_sum(dyd.data_ptr(), B, h * w * N, dys.data_ptr(), st), "batch_sum")
+    assert_close(dys.view(h, w, N), dy_ref.sum(0), 2e-4, 2e-4 * float(dy_ref.abs().max()), "batch sum")
+    dwg = ops.fwd_desc(view_of(ops, gmd, 1, h, w, 4), view_of(ops, dys, 1, h, w, N), 4, N, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
+    L.check(L.lib.zsg_conv_wgrad(C.byref(dwg), gmd.data_ptr(), dys.data_ptr(), dW.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgrad grid")
+    ref = ohwi(wt.grad, cp)
+    assert not torch.isnan(dW).any(), "the three window launches must cover every weight column"
+    assert_close(dW, ref, 5e-4, 5e-4 * float(ref.abs().max()), "dW0 (feat | lang | grid windows)")
+
+
 @pytest.mark.parametrize("rows,Cc", [(2 * 19 * 19, 64), (3 * 7 * 5, 256), (1000, 2048), (5000, 12)])
 def test_batchnorm(Z, rows, Cc):
     L, _ = Z

@@ -470,3 +470,111 @@ extern "C" int zsg_pad_rows(const float* src, int64_t rows, int32_t C, int32_t s
     ZSG_CHECK_LAUNCH("pad_rows");
     return 0;
 }
+
+// ---- head conv0 without the spatially-constant channels --------------------------------------------------------------
+// The first head convolution sees [features(256) | language vector(256, constant over the image) | grid(2)].  Its
+// language part is sum_tap valid(p,tap) * V[b][tap][co] with V = W_lang * we[b] (a tiny GEMM) and its grid part does not
+// depend on the batch index, so only the feature channels go through the big implicit GEMM (half the MACs); these
+// three kernels build the additive map and reduce the gradient for the two cheap parts.
+//   lang_map:     out[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9 + tap]          (3x3, pad 1)
+//   border_sums:  S1[b][n*9+tap] += sum_{p: tap valid} dy[b][p][n]   and its transpose S2[n*9+tap][b]
+//   batch_sum:    out[i] = sum_b x[b*stride + i]
+__global__ void head_lang_map_kernel(const float* __restrict__ V, const float* __restrict__ G, int B, int h, int w, int N,
+                                     float* __restrict__ out) {
+    const int n4 = N / 4;
+    const int64_t total = (int64_t)B * h * w * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % n4) * 4;
+        const int64_t pix = i / n4;
+        const int x = (int)(pix % w);
+        const int y = (int)((pix / w) % h);
+        const int b = (int)(pix / ((int64_t)w * h));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (G) acc = *(const f32x4*)(G + ((int64_t)y * w + x) * N + c);
+        const float* v = V + (int64_t)b * N * 9 + (int64_t)c * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if ((unsigned)(y + r - 1) >= (unsigned)h) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if ((unsigned)(x + q - 1) >= (unsigned)w) continue;
+                const int t = r * 3 + q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e * 9 + t];
+            }
+        }
+        *(f32x4*)(out + i * 4) = acc;
+    }
+}
+extern "C" int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int32_t w, int32_t N, float* out, void* stream) {
+    ZSG_REQUIRE(V && out && B > 0 && h > 0 && w > 0 && N > 0 && (N % 4) == 0, "head_lang_map: bad argument");
+    const int64_t n = (int64_t)B * h * w * (N / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("head_lang_map", st, 0, (double)B * h * w * N * 4);
+    hipLaunchKernelGGL(head_lang_map_kernel, dim3(grid_for(n)), dim3(256), 0, st, V, G, B, h, w, N, out);
+    ZSG_CHECK_LAUNCH("head_lang_map");
+    return 0;
+}
+
+// grid (N/64, row splits, B); block 256 = 64 channels x 4 row lanes; nine validity-masked column sums per thread.
+__global__ void head_border_sums_kernel(const float* __restrict__ dy, int B, int h, int w, int N, int rows_per_block,
+                                        float* __restrict__ S1, float* __restrict__ S2) {
+    __shared__ float red[4][9][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int rows = h * w;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    if (col < N) {
+        for (int p = r_begin + rl; p < r_end; p += 4) {
+            const int y = p / w, x = p - y * w;
+            const float v = dy[((int64_t)b * rows + p) * N + col];
+            // tap (r,q) reads input pixel (y+r-1, x+q-1): it contributes unless that pixel is outside the image
+            const bool r0 = y > 0, r2 = y < h - 1, q0 = x > 0, q2 = x < w - 1;
+            s[0] += (r0 && q0) ? v : 0.f; s[1] += r0 ? v : 0.f; s[2] += (r0 && q2) ? v : 0.f;
+            s[3] += q0 ? v : 0.f;         s[4] += v;            s[5] += q2 ? v : 0.f;
+            s[6] += (r2 && q0) ? v : 0.f; s[7] += r2 ? v : 0.f; s[8] += (r2 && q2) ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[rl][t][threadIdx.x & 63] = s[t];
+    __syncthreads();
+    if (rl == 0 && col < N) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = red[0][t][threadIdx.x] + red[1][t][threadIdx.x] + red[2][t][threadIdx.x] + red[3][t][threadIdx.x];
+            unsafeAtomicAdd(S1 + ((int64_t)b * N + col) * 9 + t, v);
+            unsafeAtomicAdd(S2 + ((int64_t)col * 9 + t) * B + b, v);
+        }
+    }
+}
+extern "C" int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* S1, float* S2, void* stream) {
+    ZSG_REQUIRE(dy && S1 && S2 && B > 0 && h > 0 && w > 0 && N > 0, "head_border_sums: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("head_border_sums", st, 0, (double)B * h * w * N * 4);
+    const int rows = h * w;
+    int splits = cdiv(rows, 128);
+    const int rpb = cdiv(rows, splits);
+    hipLaunchKernelGGL(head_border_sums_kernel, dim3(cdiv(N, 64), cdiv(rows, rpb), B), dim3(256), 0, st, dy, B, h, w, N, rpb, S1, S2);
+    ZSG_CHECK_LAUNCH("head_border_sums");
+    return 0;
+}
+
+__global__ void batch_sum_kernel(const float* __restrict__ x, int B, int64_t stride4, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = *(const f32x4*)(x + i * 4);
+        for (int b = 1; b < B; ++b) s += *(const f32x4*)(x + (b * stride4 + i) * 4);
+        *(f32x4*)(out + i * 4) = s;
+    }
+}
+extern "C" int zsg_batch_sum(const float* x, int32_t B, int64_t stride, float* out, void* stream) {
+    ZSG_REQUIRE(x && out && B > 0 && stride > 0 && (stride % 4) == 0, "batch_sum: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("batch_sum", st, 0, (double)B * stride * 4);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(grid_for(stride / 4)), dim3(256), 0, st, x, B, stride / 4, out);
+    ZSG_CHECK_LAUNCH("batch_sum");
+    return 0;
+}

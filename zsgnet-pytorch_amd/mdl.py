@@ -716,6 +716,21 @@ class _Plan:
         net = self.net
         C = net.convs
         e = "backbone.encoder."
+        # pyramid sizes of the 300-style trunk: conv4_3, conv7, then the four extras taps
+        l0 = x0.levels[0]
+
+        def trunk(n):
+            n = (n // 2) // 2                       # two floor-mode 2x2 pools
+            c43 = -(-n // 2)                        # ceil-mode pool ('C')
+            c7 = c43 // 2
+            e1 = conv_out(c7, 3, 2, 1)
+            e3 = conv_out(e1, 3, 2, 1)
+            e5 = conv_out(e3, 3, 1, 0)
+            e7 = conv_out(e5, 3, 1, 0)
+            return [c43, c7, e1, e3, e5, e7]
+        all_sizes = list(zip(trunk(l0.H), trunk(l0.W)))
+        fl = self._pyramid(all_sizes[1:] if net.six_hundred else all_sizes)
+        dest = ([None] + fl) if net.six_hundred else fl          # destination of out_sources[i]
         x = x0
         sources = []
         for layer in net.vgg_layers:
@@ -728,10 +743,11 @@ class _Plan:
                 x = self.maxpool(x, k, s, p, ceil, f"vgg.{idx}")
         sources.append(x)
         for k in range(net.n_extras):
-            x = self.conv(C[f"{e}extras.{k}"], x, relu=True, name=f"extras.{k}")
-            if k % 2 == 1:
+            tap = (k % 2 == 1)
+            x = self.conv(C[f"{e}extras.{k}"], x, relu=True, name=f"extras.{k}", out=dest[2 + (k - 1) // 2] if (tap and k > 1) else None)
+            if tap:
                 sources.append(x)
-        outs = [self.conv(C[f"{e}fproj{i + 1}"], sources[i], name=f"fproj{i + 1}") for i in range(3)] + sources[3:]
+        outs = [self.conv(C[f"{e}fproj{i + 1}"], sources[i], name=f"fproj{i + 1}", out=dest[i]) for i in range(3)] + sources[3:]
         return outs[1:] if net.six_hundred else outs
 
     def _lower_block(self, blk, x: Act) -> Act:
@@ -755,37 +771,55 @@ class _Plan:
             res = self.bn(BN[q + "downsample.1"], yd, False, name=q + "rd")
         return self.bn(last_bn, last_y, True, residual=res, name=q + "out")
 
+    def _pyramid(self, sizes) -> List[Act]:
+        """The head's input features: all pyramid levels packed level-major in ONE buffer (so every head convolution is
+        one grouped launch); the producers write their level in place."""
+        self.Fpack = self.packed("head.feat", self.B, sizes, 256)
+        lv = [self.Fpack.lvl(i) for i in range(len(sizes))]
+        for i, a in enumerate(lv):
+            a.name = f"feat{i}"
+        return lv
+
     def _lower_fpn(self, c3: Act, c4: Act, c5: Act) -> List[Act]:
         """fpn_resnet.py:154-178"""
         net, B = self.net, self.B
         C = net.convs
         f = "backbone.fpn."
+        hw = lambda a: (a.levels[0].H, a.levels[0].W)
+        s6 = tuple(conv_out(v, 3, 2, 1) for v in hw(c5))
+        s7 = tuple(conv_out(v, 3, 2, 1) for v in s6)
+        if net.six_hundred:
+            fl = self._pyramid([hw(c4), hw(c5), s6, s7])
+            o3, (o4, o5, o6, o7) = None, fl
+        else:
+            fl = self._pyramid([hw(c3), hw(c4), hw(c5), s6, s7, (1, 1)])
+            o3, o4, o5, o6, o7, o8 = fl
         p51 = self.conv(C[f + "P5_1"], c5, name="p51")
-        p5 = self.conv(C[f + "P5_2"], p51, name="p5")
+        p5 = self.conv(C[f + "P5_2"], p51, out=o5)
         t4 = self.conv(C[f + "P4_1"], c4, name="t4")
         p41 = self._upsample_add(t4, p51, "p41")
-        p4 = self.conv(C[f + "P4_2"], p41, name="p4")
+        p4 = self.conv(C[f + "P4_2"], p41, out=o4)
         t3 = self.conv(C[f + "P3_1"], c3, name="t3")
         p31 = self._upsample_add(t3, p41, "p31")
-        p3 = self.conv(C[f + "P3_2"], p31, name="p3")
-        p6 = self.conv(C[f + "P6"], c5, name="p6")
+        p3 = self.conv(C[f + "P3_2"], p31, out=o3, name="p3")
+        p6 = self.conv(C[f + "P6"], c5, out=o6)
         r6 = self.act("r6", B, p6.levels[0].H, p6.levels[0].W, 256)
         n6 = r6.buf.numel()
-        self.fwd.add(lib.zsg_relu_fwd, p6.buf, n6, r6.buf, what="relu(p6)")
+        self.fwd.add(lib.zsg_relu_fwd, self.base(p6), n6, r6.buf, what="relu(p6)")
 
         def relu_back():
             if r6.grad is None:
                 return
             g = self.grad_of(p6)
-            self.bwd.add(lib.zsg_relu_bwd, self.base(r6.grad), p6.buf, n6, self.base(g), int(g.gfilled), what="relu_bwd(p6)")
+            self.bwd.add(lib.zsg_relu_bwd, self.base(r6.grad), self.base(p6), n6, self.base(g), int(g.gfilled), what="relu_bwd(p6)")
             g.gfilled = True
         self.tape.append(relu_back)
-        p7 = self.conv(C[f + "P7_2"], r6, name="p7")
+        p7 = self.conv(C[f + "P7_2"], r6, out=o7)
         if net.six_hundred:
             return [p4, p5, p6, p7]           # p3 is computed and dropped, as the reference does (fpn_resnet.py:173-174)
         l7 = p7.levels[0]
-        p8 = self.act("p8", B, 1, 1, 256)
-        self.fwd.add(lib.zsg_avgpool_fwd, p7.buf, B, l7.H * l7.W, 256, p8.buf, what="avgpool")
+        p8 = o8
+        self.fwd.add(lib.zsg_avgpool_fwd, self.base(p7), B, l7.H * l7.W, 256, self.base(p8), what="avgpool")
 
         def avg_back():
             if p8.grad is None:
@@ -863,50 +897,84 @@ class _Plan:
         C = net.convs
         sizes = self.feat_sizes
         Cf, Cw = net.cf, net.cw
-        cin0 = net.start_dim_head
-        ld0 = pad4(cin0)
-        F0 = self.packed("head.in", B, sizes, ld0, ld0)
-        F0.requires_grad = False          # its gradient is routed by hand below (feature / language halves)
-        self.gy, self.gx = [], []
-        for i, (h, w) in enumerate(sizes):
-            g = anchors_mod.create_grid_np(h, w).reshape(h, w, 2)
-            gy = torch.from_numpy(np.ascontiguousarray(g[:, 0, 0])).to(self.dev)
-            gx = torch.from_numpy(np.ascontiguousarray(g[0, :, 1])).to(self.dev)
-            self.gy.append(gy)
-            self.gx.append(gx)
-            l = F0.levels[i]
-            self.fwd.add(lib.zsg_fuse_lang_grid, feats[i].buf[feats[i].levels[0].off:] if Cf else None, we.buf if Cw else None, gy, gx, B, h, w,
-                         Cf, Cw, int(net.use_grid), ld0, F0.buf[l.off:], what=f"fuse{i}")
         L0 = C["att_reg_box.0.0"]
+        W0n = L0.name + ".weight"
+        cp = L0.cpad
+        Fp = self.Fpack
+        nl = len(sizes)
+        assert Cf == 256 and [(f.levels[0].H, f.levels[0].W) for f in feats] == sizes
+        if bool(Cw) != bool(net.use_grid):
+            raise NotImplementedError("head input with exactly one of {language, grid} is not lowered (not a reference configuration)")
         h1 = self.packed("head.h1", B, sizes, 256)
-        self.conv(L0, F0, relu=True, out=h1)
-        self.tape.pop()                     # conv0's backward is split by hand (feature / language halves)
+        # conv0 sees [features | language vector (constant over the image) | grid (constant over the batch)]: only the
+        # features go through the big implicit GEMM; the other two enter as an additive map
+        #   lmap[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9+tap],  V = W0[:, :, :, lang] . we[b],  G = conv(grid, W0[..., grid])
+        lmap = None
+        if Cw:
+            V = self.act("head.V", B, 1, 1, 9 * 256)
+            dv = fwd_desc(we, V, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
+            self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what="head0.V")
+            gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
+            o = 0
+            for (h, w) in sizes:
+                g = anchors_mod.create_grid_np(h, w).reshape(h * w, 2)
+                gm[o:o + h * w, :2] = g
+                o += h * w
+            gridmap = self.packed("head.grid", 1, sizes, 4)
+            gridmap.buf.copy_(torch.from_numpy(gm.reshape(-1)))
+            gridmap.requires_grad = False
+            G = self.packed("head.G", 1, sizes, 256)
+            dg = fwd_desc(gridmap, G, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
+            self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what="head0.G")
+            lmap = self.packed("head.lmap", B, sizes, 256)
+            for i, (h, w) in enumerate(sizes):
+                self.fwd.add(lib.zsg_head_lang_map, V.buf, self.base(G.lvl(i)), B, h, w, 256, self.base(lmap.lvl(i)), what=f"lmap{i}")
+        d0 = fwd_desc(Fp, h1, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0, relu=True)
+        a0 = (Fp.buf, self.P(W0n), h1.buf, self.P(L0.name + ".bias"), lmap.buf if lmap is not None else None, None, None)
+        autotune_conv("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr())
+        self.fwd.add(lib.zsg_conv_igemm, d0, *a0, what=L0.name)
+        h1.needs_mask = True
 
         def head0_back():
             dy = h1.grad
             if dy is None:
                 return
-            dw0 = fwd_desc(F0, dy, L0.cpad, 256, 3, 1, 1, 1, wC=L0.cpad)
-            self.wgrad(dw0, F0, dy, L0.name + ".weight", "wgrad:head0")
+            gW0 = self.G(W0n)
+            dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
+            self.wgrad(dwf, Fp, dy, W0n, "wgrad:head0")
             self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0")
-            if Cf:                          # the grid channels are constants: no data gradient for them
-                dF = self.packed("head.dfeat", B, sizes, Cf)
-                self.dgrad(L0, dy, F0, n=Cf, row0=0, dx=dF)
-                for i, f in enumerate(feats):
-                    assert f.grad is None
-                    f.grad = dF.lvl(i)
-                    f.grad.gfilled = True
-                    if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
-                        n = f.B * f.levels[0].H * f.levels[0].W * f.ld
-                        self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
-            if Cw:
-                dWe = self.packed("head.dwe", B, sizes, Cw)
-                self.dgrad(L0, dy, F0, n=Cw, row0=Cf, dx=dWe)
-                gwe = self.grad_of(we)
-                for i, (hh, ww) in enumerate(sizes):
-                    l = dWe.levels[i]
-                    self.bwd.add(lib.zsg_colsum, dWe.buf[l.off:], B, hh * ww * Cw, hh * ww, Cw, 0, Cw, gwe.buf, int(i > 0), what=f"dwe{i}")
-                gwe.gfilled = True
+            dF = self.grad_of(Fp)
+            self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=dF)
+            for i, f in enumerate(feats):
+                assert f.grad is None
+                f.grad = dF.lvl(i)
+                f.grad.gfilled = True
+                if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
+                    n = f.B * f.levels[0].H * f.levels[0].W * f.ld
+                    self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
+            if not Cw:
+                return
+            # language / grid columns of dW0 and d(we) from the validity-masked sums of dy (no per-pixel work)
+            S = self._buf(2 * B * 9 * 256)
+            S1 = Act(S, B, 9 * 256, 9 * 256, [Level(0, 1, 1, 9 * 256)], "head.S1")
+            S2 = Act(S, 1, B, B, [Level(B * 9 * 256, 1, 9 * 256, 9 * 256 * B)], "head.S2")
+            self.bwd.add(lib.zsg_memset_f32, S, S.numel(), 0.0, what="zero:head.S")
+            for i, (h, w) in enumerate(sizes):
+                self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, S, self.base(S2), what=f"bsum{i}")
+            dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
+            self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, self.wg_ws, self.wg_ws_bytes, what="wgrad:head0.lang")
+            ent = net.store.entries[W0n]
+            Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
+            gwe = self.grad_of(we)
+            dwe = fwd_desc(Wrows, S2, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
+            self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), 0, self.wg_ws, self.wg_ws_bytes, what="dwe")
+            gwe.gfilled = True
+            dys = self.packed("head.dysum", 1, sizes, 256)
+            for i, (h, w) in enumerate(sizes):
+                self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
+            dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
+            self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, self.wg_ws, self.wg_ws_bytes, what="wgrad:head0.grid")
+            self.grad_ready[W0n] = len(self.bwd.calls)
         self.tape.append(head0_back)
         hs = [h1]
         for i in range(1, 5):
