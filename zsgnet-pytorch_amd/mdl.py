@@ -513,7 +513,7 @@ class _Plan:
         if L.bias:
             base = dy.levels[0].off
             self.bwd.add(lib.zsg_colsum, dy.buf[base:], 1, 0, dy.rows(), dy.ld, 0, L.cout, self.G(L.name + ".bias"), 1,
-                         what="bgrad:" + L.name)
+                         what="bgrad:" + L.name, lane=1)
         if src.requires_grad:
             self.dgrad(L, dy, src, n=L.cpad)
 
@@ -525,7 +525,7 @@ class _Plan:
         autotune_conv("wgrad", lib.zsg_conv_wgrad, d, args, stream_ptr(), self.wg_ws_bytes)
         if not d.tile_hint:          # autotune disabled: make sure the heuristic's slabs fit
             assert lib.zsg_conv_wgrad_workspace_bytes(d) <= self.wg_ws_bytes or True
-        self.bwd.add(lib.zsg_conv_wgrad, d, *args, what=what)
+        self.bwd.add(lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
@@ -881,13 +881,13 @@ class _Plan:
                              self.in_qlens, lens, B, Tn, Hd, dg.buf, what="lstm_bwd" + suf)
                 d_ih = fwd_desc(xin, dg, E, H4, 1, 1, 0, 1, wC=E)
                 self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
-                             what="wgrad:w_ih" + suf)
+                             what="wgrad:w_ih" + suf, lane=1)
                 hp = Act(hprev, B, Hd, Hd, [Level(0, 1, Tn, Tn * Hd)], "hprev" + suf)
                 d_hh = fwd_desc(hp, dg, Hd, H4, 1, 1, 0, 1, wC=Hd)
                 self.bwd.add(lib.zsg_conv_wgrad, d_hh, hp.buf, dg.buf, self.G("lstm.weight_hh_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
-                             what="wgrad:w_hh" + suf)
+                             what="wgrad:w_hh" + suf, lane=1)
                 for bname in ("lstm.bias_ih_l0", "lstm.bias_hh_l0"):
-                    self.bwd.add(lib.zsg_colsum, dg.buf, 1, 0, B * Tn, H4, 0, H4, self.G(bname + suf), 1, what="bgrad:" + bname + suf)
+                    self.bwd.add(lib.zsg_colsum, dg.buf, 1, 0, B * Tn, H4, 0, H4, self.G(bname + suf), 1, what="bgrad:" + bname + suf, lane=1)
             self.tape.append(back)
         return we
 
@@ -942,7 +942,7 @@ class _Plan:
             gW0 = self.G(W0n)
             dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
             self.wgrad(dwf, Fp, dy, W0n, "wgrad:head0")
-            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0")
+            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0", lane=1)
             dF = self.grad_of(Fp)
             self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=dF)
             for i, f in enumerate(feats):
@@ -955,6 +955,8 @@ class _Plan:
             if not Cw:
                 return
             # language / grid columns of dW0 and d(we) from the validity-masked sums of dy (no per-pixel work)
+            hws_bytes = 16 << 20           # these three run on the main stream: keep them off the side stream's slabs
+            hws = self._buf(hws_bytes // 4)
             S = self._buf(2 * B * 9 * 256)
             S1 = Act(S, B, 9 * 256, 9 * 256, [Level(0, 1, 1, 9 * 256)], "head.S1")
             S2 = Act(S, 1, B, B, [Level(B * 9 * 256, 1, 9 * 256, 9 * 256 * B)], "head.S2")
@@ -962,18 +964,18 @@ class _Plan:
             for i, (h, w) in enumerate(sizes):
                 self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, S, self.base(S2), what=f"bsum{i}")
             dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-            self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, self.wg_ws, self.wg_ws_bytes, what="wgrad:head0.lang")
+            self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:head0.lang")
             ent = net.store.entries[W0n]
             Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
             gwe = self.grad_of(we)
             dwe = fwd_desc(Wrows, S2, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
-            self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), 0, self.wg_ws, self.wg_ws_bytes, what="dwe")
+            self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), 0, hws, hws_bytes, what="dwe")
             gwe.gfilled = True
             dys = self.packed("head.dysum", 1, sizes, 256)
             for i, (h, w) in enumerate(sizes):
                 self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
             dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-            self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, self.wg_ws, self.wg_ws_bytes, what="wgrad:head0.grid")
+            self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, hws, hws_bytes, what="wgrad:head0.grid")
             self.grad_ready[W0n] = len(self.bwd.calls)
         self.tape.append(head0_back)
         hs = [h1]
@@ -1008,7 +1010,7 @@ class _Plan:
 
         def head5_back():
             self.bwd.add(lib.zsg_pad_rows, self.g5_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
-            self.bwd.add(lib.zsg_colsum, self.g5_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:head5")
+            self.bwd.add(lib.zsg_colsum, self.g5_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:head5", lane=1)
             dw = fwd_desc(h5, g5p, L5.cpad, nout, 3, 1, 1, 1, wC=L5.cpad)
             self.wgrad(dw, h5, g5p, L5.name + ".weight", "wgrad:head5")
             self.dgrad(L5, g5p, h5, n=256)

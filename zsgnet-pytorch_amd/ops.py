@@ -168,19 +168,60 @@ def marshal(fn, args, keep: Optional[list] = None) -> tuple:
     return tuple(conv)
 
 
+SIDE_STREAM = os.environ.get("ZSG_SIDE_STREAM", "1") != "0"
+
+
 class Program:
     """A static list of foreign calls.  `add(fn, *args)` marshals once; `run(stream)` replays."""
 
     def __init__(self, name: str = ""):
         self.name = name
         self.calls = []
+        self.lanes = []         # 0 = the caller's stream; 1 = side stream (leaf work nothing later in the program reads)
         self.keep = []          # ctypes structs / tensors that must outlive the program
+        self._side = None
 
-    def add(self, fn, *args, what: str = ""):
+    def add(self, fn, *args, what: str = "", lane: int = 0):
         self.calls.append((fn, marshal(fn, args, self.keep), what or fn.__name__))
+        self.lanes.append(lane)
+
+    def _run_lanes(self, stream: int, start: int, stop: int):
+        """Replay with lane-1 launches on a side HIP stream: each one waits for everything enqueued on the main stream
+        before it (its inputs), and the main stream re-joins the side stream at the end of the range.  Weight-gradient
+        kernels are leaves of the backward graph, so they fill the CUs the critical path's small launches leave idle."""
+        main = torch.cuda.current_stream()
+        assert main.cuda_stream == stream
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._ev_pool = []
+        side = self._side
+        st0, st1 = C.c_void_p(stream), C.c_void_p(side.cuda_stream)
+        dirty, used, nev = True, False, 0
+        for i in range(start, stop):
+            fn, args, what = self.calls[i]
+            if self.lanes[i]:
+                if dirty:
+                    if nev == len(self._ev_pool):
+                        self._ev_pool.append(torch.cuda.Event())
+                    ev = self._ev_pool[nev]
+                    nev += 1
+                    ev.record(main)
+                    side.wait_event(ev)
+                    dirty = False
+                used = True
+                rc = fn(*args, st1)
+            else:
+                dirty = True
+                rc = fn(*args, st0)
+            if rc:
+                raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
+        if used:
+            main.wait_stream(side)
 
     def run(self, stream: int, start: int = 0, stop: Optional[int] = None):
         st = C.c_void_p(stream)
+        if SIDE_STREAM and any(self.lanes) and not os.environ.get("ZSG_DEBUG_SYNC"):
+            return self._run_lanes(stream, start, len(self.calls) if stop is None else stop)
         calls = self.calls if (start == 0 and stop is None) else self.calls[start:stop]
         if os.environ.get("ZSG_DEBUG_SYNC"):          # locate a faulting launch: name it, run it, synchronise
             for fn, args, what in calls:
