@@ -127,13 +127,14 @@ int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t ro
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
 int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                       float* invstd, void* stream);
-/* out = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+/* out = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ).  relu_mask (optional, rows*C/4 bytes): bit e of byte i =
+ * (element 4i+e > 0) — what zsg_bn_backward needs of the output, at 1/16 of its HBM traffic. */
 int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd, const float* gamma,
-                 const float* beta, const float* residual, int32_t relu, float* out, void* stream);
-/* g = dout * (out > 0 if relu_out != NULL);  dgamma = sum g*xhat ; dbeta = sum g ;
+                 const float* beta, const float* residual, int32_t relu, float* out, uint8_t* relu_mask, void* stream);
+/* g = dout * (out > 0), the mask taken from relu_mask if given, else from relu_out if given, else g = dout;  dgamma = sum g*xhat ; dbeta = sum g ;
  * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) ; optional g_out = g (gradient of the residual branch).
  * dgamma/dbeta are ACCUMULATED (+=) when accumulate != 0, else overwritten. */
-int zsg_bn_backward(const float* dout, const float* relu_out, const float* x, int64_t rows, int32_t C,
+int zsg_bn_backward(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,
                     const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
                     float* dgamma, float* dbeta, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
 

@@ -366,19 +366,24 @@ def test_batchnorm(Z, rows, Cc):
     assert_close(rmd, rm_ref, 1e-5, 1e-6, "running_mean")
     assert_close(rvd, rv_ref, 1e-4, 1e-6, "running_var")
     out = torch.empty(rows, Cc, device="cuda")
+    rmask = torch.zeros(rows * Cc // 4, dtype=torch.uint8, device="cuda")
     L.check(L.lib.zsg_bn_apply(xd.data_ptr(), rows, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), resd.data_ptr(), 1,
-                               out.data_ptr(), st), "bn_apply")
+                               out.data_ptr(), rmask.data_ptr(), st), "bn_apply")
     assert_close(out, out_ref.reshape(Cc, rows).t(), 1e-4, 1e-5, "bn out")
+    bits = (out.view(-1, 4) > 0).to(torch.uint8)
+    assert torch.equal(rmask, bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)), "packed ReLU mask (exact)"
     dout = dev(gy.reshape(Cc, rows).t())
     dx, gout = torch.empty(rows, Cc, device="cuda"), torch.empty(rows, Cc, device="cuda")
     dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
-    L.check(L.lib.zsg_bn_backward(dout.data_ptr(), out.data_ptr(), xd.data_ptr(), rows, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
-                                  dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, ws.data_ptr(), wsb, st), "bn_backward")
     sc = float(xr.grad.abs().max())
-    assert_close(dx, xr.grad, 1e-3, 1e-4 * sc, "bn dx")
-    assert_close(gout, rr.grad, 1e-5, 1e-6, "bn residual grad")
-    assert_close(dg, gr.grad, 1e-3, 1e-4 * float(gr.grad.abs().max()), "bn dgamma")
-    assert_close(db, br.grad, 1e-3, 1e-4 * float(br.grad.abs().max()), "bn dbeta")
+    for how, y_ptr, m_ptr in (("mask from output", out.data_ptr(), None), ("packed mask", None, rmask.data_ptr())):
+        dg.zero_(), db.zero_()
+        L.check(L.lib.zsg_bn_backward(dout.data_ptr(), y_ptr, m_ptr, xd.data_ptr(), rows, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+                                      dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, ws.data_ptr(), wsb, st), "bn_backward")
+        assert_close(dx, xr.grad, 1e-3, 1e-4 * sc, f"bn dx ({how})")
+        assert_close(gout, rr.grad, 1e-5, 1e-6, f"bn residual grad ({how})")
+        assert_close(dg, gr.grad, 1e-3, 1e-4 * float(gr.grad.abs().max()), f"bn dgamma ({how})")
+        assert_close(db, br.grad, 1e-3, 1e-4 * float(br.grad.abs().max()), f"bn dbeta ({how})")
     # eval-mode statistics
     L.check(L.lib.zsg_bn_eval_stats(rmd.data_ptr(), rvd.data_ptr(), Cc, 1e-5, mean.data_ptr(), invstd.data_ptr(), st), "bn_eval_stats")
     assert_close(invstd, 1 / torch.sqrt(rvd.cpu() + 1e-5), 1e-6, 0, "eval invstd")

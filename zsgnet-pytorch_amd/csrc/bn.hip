@@ -32,9 +32,9 @@ extern "C" size_t zsg_bn_workspace_bytes(int64_t rows, int32_t C) {
 // MODE 0: (sum x, sum x^2).  MODE 1: backward (sum g, sum g*xhat) with g = dout * (relu_out > 0).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                         const float* __restrict__ relu_out, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, int64_t rows, int C, int lanes,
-                                                         int rpb, float* __restrict__ part) {
+                                                         const float* __restrict__ relu_out, const uint8_t* __restrict__ relu_mask,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         int64_t rows, int C, int lanes, int rpb, float* __restrict__ part) {
     __shared__ f32x4 red[2][256];
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                 s1 += v * v;
             } else {
                 f32x4 g = *(const f32x4*)(dout + r * C + c);
-                if (relu_out) {
+                if (relu_mask) {
+                    const unsigned m = relu_mask[(r * C + c) >> 2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+                } else if (relu_out) {
                     const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
@@ -139,7 +143,7 @@ __global__ void bn_eval_stats_kernel(const float* rmean, const float* rvar, int 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t rows, int C, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ residual, int relu,
-                                                       float* __restrict__ out, int lanes, int rpb) {
+                                                       float* __restrict__ out, uint8_t* __restrict__ relu_mask, int lanes, int rpb) {
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     const int c = (blockIdx.y * lanes + l) * 4;
@@ -153,6 +157,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         f32x4 v = (*(const f32x4*)(x + r * C + c) - mu) * sc + be;
         if (residual) v += *(const f32x4*)(residual + r * C + c);
         if (relu) {
+            if (relu_mask)          // 4 mask bits per 16-byte group: the backward reads this byte instead of the output
+                relu_mask[(r * C + c) >> 2] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(BN_FC * BN_FK) void bn_bwd_finalize_kernel(const fl
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ relu_out,
+                                                           const uint8_t* __restrict__ relu_mask,
                                                            const float* __restrict__ x, int64_t rows, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ coef,
@@ -193,7 +200,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
     for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
         f32x4 g = *(const f32x4*)(dout + r * C + c);
-        if (relu_out) {
+        if (relu_mask) {
+            const unsigned m = relu_mask[(r * C + c) >> 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+        } else if (relu_out) {
             const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
@@ -212,7 +223,7 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)rows * C * 4);
     float* part = (float*)ws;
-    hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps);
@@ -242,33 +253,33 @@ extern "C" int zsg_bn_eval_stats(const float* running_mean, const float* running
 }
 
 extern "C" int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd, const float* gamma,
-                            const float* beta, const float* residual, int32_t relu, float* out, void* stream) {
+                            const float* beta, const float* residual, int32_t relu, float* out, uint8_t* relu_mask, void* stream) {
     ZSG_REQUIRE(x && mean && invstd && gamma && beta && out && rows > 0 && C > 0 && (C % 4) == 0, "bn_apply: bad argument");
     BnGeom g = bn_geom(rows, C);
     hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("bn_apply", st, 0, (double)rows * C * 4 * (residual ? 3 : 2));
+    ZSG_PROF("bn_apply", st, 0, (double)rows * C * (4 * (residual ? 3 : 2) + (relu_mask && relu ? 0.25 : 0)));
     hipLaunchKernelGGL(bn_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, mean, invstd, gamma, beta, residual,
-                       relu, out, g.lanes, g.rpb);
+                       relu, out, relu_mask, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_apply");
     return 0;
 }
 
-extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const float* x, int64_t rows, int32_t C, const float* mean,
+extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C, const float* mean,
                                const float* invstd, const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta,
                                int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
     ZSG_REQUIRE(dout && x && mean && invstd && gamma && dx && ws && rows > 0 && C > 0 && (C % 4) == 0, "bn_backward: bad argument");
     if (ws_bytes < zsg_bn_workspace_bytes(rows, C)) ZSG_FAIL(-2, "bn_backward: workspace too small");
     BnGeom g = bn_geom(rows, C);
     hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("bn_backward", st, 0, (double)rows * C * 4 * ((relu_out ? 3 : 2) * 2 + 1 + (g_out ? 1 : 0)));
+    ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * ((relu_out && !relu_mask ? 3 : 2) * 2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.5 : 0)));
     float* part = (float*)ws;
     float* coef = part + (size_t)g.chunks * 2 * C;
-    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, mean, invstd, rows, C,
-                       g.lanes, g.rpb, part);
+    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
+                       rows, C, g.lanes, g.rpb, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, x, rows, C, mean, invstd, gamma,
-                       coef, dx, g_out, g.lanes, g.rpb);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
+                       gamma, coef, dx, g_out, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_backward");
     return 0;
 }

@@ -567,8 +567,9 @@ class _Plan:
             self.fwd.add(lib.zsg_bn_stats, x.buf, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, self.ws, self.ws_bytes, what=L.name)
         else:
             self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name)
+        rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
         self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
-                     int(relu), out.buf, what=L.name)
+                     int(relu), out.buf, rmask, what=L.name)
 
         def back():
             if out.grad is None:
@@ -580,7 +581,7 @@ class _Plan:
                 assert not rg.gfilled, "residual gradient must be produced first (tape order)"
                 g_out = rg.buf
                 rg.gfilled = True
-            self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), out.buf if relu else None, x.buf, rows, L.c, mean, invstd, gam,
+            self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
                          dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,
                          what="bnbwd:" + L.name)
             dx.gfilled = True
