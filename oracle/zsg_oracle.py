@@ -560,8 +560,26 @@ def head_forward(sd, x, prefix="att_reg_box."):
     return x.permute(0, 2, 3, 1).contiguous().view(x.shape[0], -1, 5)
 
 
-def zsgnet_forward(sd, batch, h0, c0, arch="resnet50", training=True, six_hundred=False, rank=None):
-    """Reference mdl.py:338-403.  Returns dict(att_out [B,A,1], bbx_out [B,A,4], feat_sizes [L,2], num_f_out [1])."""
+def head_input(feat, we, use_lang=True, use_img=True):
+    """What the head sees for one pyramid level (mdl.py:69-104 with the blind variants of mdl.py:363-375):
+    full = [feat || we || grid]; language-blind = feat; image-blind = we tile only; both blind = grid only."""
+    if use_lang and use_img:
+        return fuse_lang_grid(feat, we)
+    if use_img:
+        return feat
+    B, _, h, w = feat.shape
+    if use_lang:
+        return we.view(B, -1, 1, 1).expand(B, we.shape[1], h, w)
+    grid = torch.from_numpy(create_grid(h, w)).view(h, w, 2).permute(2, 0, 1).to(feat.dtype)
+    return grid.unsqueeze(0).expand(B, 2, h, w)
+
+
+def zsgnet_forward(sd, batch, h0, c0, arch="resnet50", training=True, six_hundred=False, rank=None,
+                   use_lang=True, use_img=True, do_norm=False):
+    """Reference mdl.py:338-403.  Returns dict(att_out [B,A,1], bbx_out [B,A,4], feat_sizes [L,2], num_f_out [1]).
+    The encoder always runs (the blind variants still take the pyramid sizes — and, in train mode, the BatchNorm
+    running-statistics update — from it, mdl.py:363-375); do_norm = per-pixel channel L2 normalisation of the maps and
+    of the language vector, without epsilon (mdl.py:118-130; not applied to `we` in the language-blind call)."""
     bn = BNState(sd, training)
     we = query_encoder(sd, batch["qvec"], batch["qlens"], h0, c0, rank)
     if arch == "ssd_vgg":
@@ -569,7 +587,11 @@ def zsgnet_forward(sd, batch, h0, c0, arch="resnet50", training=True, six_hundre
     else:
         c3, c4, c5 = encoder_forward(sd, batch["img"], arch, bn)
         feats = fpn_forward(sd, c3, c4, c5, six_hundred)
-    outs = [head_forward(sd, fuse_lang_grid(f, we)) for f in feats]
+    wn = we
+    if do_norm:
+        feats = [f / f.norm(dim=1, keepdim=True) for f in feats]
+        wn = we / we.norm(dim=1, keepdim=True)
+    outs = [head_forward(sd, head_input(f, wn, use_lang, use_img)) for f in feats]
     ab = torch.cat(outs, dim=1)
     return dict(att_out=ab[..., 4:5], bbx_out=ab[..., :4],
                 feat_sizes=torch.tensor([[f.shape[2], f.shape[3]] for f in feats]),

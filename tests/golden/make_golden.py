@@ -77,7 +77,12 @@ def import_reference():
     return dict(anchors=anchors, evaluator=evaluator, loss=loss, mdl=mdl, fpn_resnet=fpn_resnet, ssd_vgg=ssd_vgg, cfg=cfg)
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]     # e.g. `make_golden.py g12_` rewrites only the matching files
+
+
 def save(name, **arrs):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrs)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KB")
@@ -366,6 +371,43 @@ def main():
     for k in ("backbone.encoder.vgg.0.bias", "backbone.encoder.vgg.21.bias", "backbone.encoder.fproj1.bias", "backbone.encoder.extras.7.bias"):
         d["grad__" + k] = grads[k].numpy()
     save("g11_ssd", **d)
+
+    # ---- G12 ablation variants (mdl.py:118-130, 199-210, 363-375): blind heads and do_norm, 128x128, B=2 ------------
+    for tag, kw, head_in in (("lang_blind", dict(use_lang=False), 256), ("img_blind", dict(use_img=False), 256),
+                             ("both_blind", dict(use_lang=False, use_img=False), 2), ("do_norm", dict(do_norm=True), 514)):
+        c2 = cfg.__class__(dict(cfg))
+        c2.device = "cpu"
+        for k, v in kw.items():
+            c2[k] = v
+        sd = O.seeded_state_dict("resnet50", seed=11, head_in=head_in)
+        net = M.get_default_net(num_anchors=9, cfg=c2)
+        net.load_state_dict(sd, strict=False)
+        net.train()
+        bt = O.synthetic_batch(2, 128, 128, seed=4321)
+        gq = torch.Generator().manual_seed(56)
+        h0 = torch.randn(2, 2, 128, generator=gq)
+        c0 = torch.randn(2, 2, 128, generator=gq)
+        net.lstm_init_hidden = lambda bs: (h0, c0)
+        out = net(bt)
+        fs = [tuple(int(v) for v in r) for r in out["feat_sizes"].tolist()]
+        anc = A.create_anchors(fs, ratios, scales, device=cpu).float()
+        lf = L.get_default_loss(ratios, scales, c2)
+        lf.anchs = anc
+        ls = lf(out, bt)
+        net.zero_grad()
+        ls["loss"].backward()
+        grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        names = sorted(grads)
+        d = dict(seed=np.array([11]), batch_seed=np.array([4321]), head_in=np.array([head_in]), h0=h0.numpy(), c0=c0.numpy(),
+                 feat_sizes=np.array(fs), loss=np.float64(ls["loss"].item()), att_out=out["att_out"].detach().numpy(),
+                 bbx_out=out["bbx_out"].detach().numpy(), grad_names=np.array(names),
+                 grad_norms=np.array([grads[k].double().norm().item() for k in names]),
+                 unused=np.array(sorted(k for k, p in net.named_parameters() if p.grad is None)),
+                 rm_bn1=net.backbone.encoder.bn1.running_mean.numpy())
+        for k in ("att_reg_box.0.0.bias", "att_reg_box.5.bias"):
+            d["grad__" + k] = grads[k].numpy()
+        d["grad__att_reg_box.0.0.weight_s"] = grads["att_reg_box.0.0.weight"].numpy()[::8, ::5]
+        save("g12_" + tag, **d)
     print("done")
 
 

@@ -91,8 +91,10 @@ def test_no_cpu_fallback():
     bt = O.synthetic_batch(2, 64, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(bt)
-    with pytest.raises(NotImplementedError):
-        get_default_net(9, get_cfg(do_norm=True))
+    with pytest.raises(NotImplementedError):                       # the reference's unused two-head variant (mdl.py:220-225)
+        get_default_net(9, get_cfg(use_same_atb=False))
+    for kw, cin in ((dict(use_lang=False), 256), (dict(use_img=False), 256), (dict(use_lang=False, use_img=False), 2), (dict(do_norm=True), 514)):
+        assert get_default_net(9, get_cfg(**kw)).state_dict()["att_reg_box.0.0.weight"].shape == (256, cin, 3, 3)     # mdl.py:196-209
     ssd = get_default_net(9, get_cfg(mdl_to_use="ssd_vgg"))
     assert set(ssd.state_dict().keys()) == set(O.seeded_ssd_state_dict(0).keys())
 

@@ -255,3 +255,48 @@ def test_train_steps_match_oracle_and_reduce_loss(Z):
     for k in ("att_reg_box.5.bias", "backbone.fpn.P3_2.weight", "backbone.encoder.layer2.0.conv1.weight", "lstm.weight_hh_l0"):
         e = rel_err(got[k].cpu() - sd[k], params[k].detach() - sd[k])
         assert e < 1e-1, f"{k}: parameter update differs from the oracle by {e:.3g}"
+
+
+ABLATIONS = {"lang_blind": dict(use_lang=False), "img_blind": dict(use_img=False),
+             "both_blind": dict(use_lang=False, use_img=False), "do_norm": dict(do_norm=True)}
+
+
+@pytest.mark.parametrize("tag", sorted(ABLATIONS))
+def test_ablation_variants_vs_reference_golden(Z, gold, tag):
+    """Blind heads (mdl.py:199-210, 363-375) and do_norm (mdl.py:118-130) against the imported reference (g12):
+    outputs abs 5e-3, loss rel 2e-4, gradient norms within 3 % (B=2 train-mode BN), unused parameters get exactly 0."""
+    config, evaluator, loss, mdl, optim = Z
+    g = gold("g12_" + tag)
+    cfg = config.get_cfg(**ABLATIONS[tag])
+    net = mdl.get_default_net(9, cfg)
+    net.load_state_dict(O.seeded_state_dict("resnet50", int(g["seed"][0]), head_in=int(g["head_in"][0])))
+    net.to("cuda").train()
+    r, s = config.ratios_scales(cfg)
+    lf = loss.get_default_loss(r, s, cfg)
+    inp = to_dev(O.synthetic_batch(2, 128, 128, seed=int(g["batch_seed"][0])))
+    inp["h0"], inp["c0"] = torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"])
+    out = net(inp)
+    assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist()
+    np.testing.assert_allclose(out["att_out"].detach().cpu().numpy(), g["att_out"], rtol=2e-3, atol=5e-3)
+    np.testing.assert_allclose(out["bbx_out"].detach().cpu().numpy(), g["bbx_out"], rtol=2e-3, atol=5e-3)
+    ls = lf(out, inp)
+    np.testing.assert_allclose(ls["loss"].item(), g["loss"], rtol=2e-4)
+    ls["loss"].backward()
+    norms = dict(zip(g["grad_names"], g["grad_norms"]))
+    unused = set(g["unused"])
+    bad = []
+    for n, p in net.named_parameters():
+        gn = float(p.grad.double().norm())
+        if n in norms:
+            if abs(gn - norms[n]) > 3e-2 * norms[n] + 1e-7:
+                bad.append((n, gn, norms[n]))
+        else:
+            assert n in unused and gn == 0.0, f"{n}: the reference leaves this gradient unset, got norm {gn}"
+    assert not bad, f"{len(bad)} gradient norms off: {bad[:8]}"
+    P = dict(net.named_parameters())
+    for k in ("att_reg_box.0.0.bias", "att_reg_box.5.bias"):
+        e = rel_err(P[k].grad.cpu(), torch.from_numpy(g["grad__" + k]))
+        assert e < 5e-2, f"{k}: relative error {e:.3g}"
+    e = rel_err(P["att_reg_box.0.0.weight"].grad.cpu()[::8, ::5], torch.from_numpy(g["grad__att_reg_box.0.0.weight_s"]))
+    assert e < 5e-2, f"head conv0 weight gradient: relative error {e:.3g}"
+    np.testing.assert_allclose(net.state_dict()["backbone.encoder.bn1.running_mean"].cpu().numpy(), g["rm_bn1"], rtol=1e-4, atol=1e-6)

@@ -100,8 +100,7 @@ class ZSGNet(nn.Module):
             raise NotImplementedError("use_same_atb=False (separate att/reg heads, mdl.py:223-225) is not lowered yet")
         if backbone_kind not in ("retina", "ssd_vgg"):
             raise ValueError(f"mdl_to_use={backbone_kind!r}: expected 'retina' or 'ssd_vgg' (mdl.py:410-414)")
-        if cfg["do_norm"]:
-            raise NotImplementedError("do_norm=True (mdl.py:118-130) is not lowered yet")
+        self.do_norm = bool(cfg["do_norm"])
         # fpn_resnet.py:173 tests resize_img == [600,600]; ssd_vgg.py:98 tests resize_img[0] >= 600
         self.six_hundred = (list(cfg["resize_img"]) == [600, 600]) if backbone_kind == "retina" else (cfg["resize_img"][0] >= 600)
         self.cf = 256 if self.use_img else 0
@@ -426,6 +425,9 @@ class _Plan:
         return a
 
     def like(self, a: Act, name=None) -> Act:
+        if len(a.levels) == 1:           # a level of a packed buffer gets a compact twin, not a copy of the whole pack
+            l = a.levels[0]
+            return Act(self._buf(a.B * l.bstride), a.B, a.C, a.ld, [Level(0, l.H, l.W, l.bstride)], name or (a.name + ".grad"))
         g = Act(self._buf(a.buf.numel()), a.B, a.C, a.ld, a.levels, name or (a.name + ".grad"))
         return g
 
@@ -617,10 +619,12 @@ class _Plan:
             we = self._lower_lstm()
 
         # ---- encoder ------------------------------------------------------------------------------------------------------
+        # (the image-blind variants still run the encoder, as the reference does, mdl.py:363-375: the pyramid sizes and the
+        # train-mode BatchNorm running statistics come from it; no gradient reaches it, so its backward emits nothing)
         feats: List[Act] = []
-        if net.use_img and net.backbone_kind == "ssd_vgg":
+        if net.backbone_kind == "ssd_vgg":
             feats = self._lower_ssd(x0)
-        elif net.use_img:
+        else:
             y = self.conv(C[e + "conv1"], x0, name="stem.y", bn_fuse=BN[e + "bn1"])
             a = self.bn(BN[e + "bn1"], y, relu=True, name="stem.a")
             H2, W2 = conv_out(H1, 3, 2, 1), conv_out(W1, 3, 2, 1)
@@ -642,8 +646,6 @@ class _Plan:
                 if blk["last"]:
                     taps[blk["layer"]] = x
             feats = self._lower_fpn(taps[2], taps[3], taps[4])
-        else:
-            raise NotImplementedError("use_img=False (image-blind ablation, mdl.py:363-366) is not lowered yet")
         self.feat_sizes = [(f.levels[0].H, f.levels[0].W) for f in feats]
         self.feat_sizes_t = torch.tensor(self.feat_sizes, dtype=torch.long, device=self.dev)
         self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
@@ -666,9 +668,9 @@ class _Plan:
 
     def _grad_commit(self, a: Act, g: Act, tmp: Optional[Act]):
         if tmp is not None:
-            n = a.buf.numel()
+            n = sum(a.B * l.H * l.W * a.ld for l in a.levels)
             if a.needs_mask:
-                self.bwd.add(lib.zsg_relu_bwd, tmp.buf, a.buf, n, g.buf, int(g.gfilled), what="mask+acc:" + a.name)
+                self.bwd.add(lib.zsg_relu_bwd, self.base(tmp), self.base(a), n, self.base(g), int(g.gfilled), what="mask+acc:" + a.name)
             else:
                 raise AssertionError("accumulation without mask is not needed by any lowered model")
         g.gfilled = True
@@ -695,19 +697,20 @@ class _Plan:
         self.tape.append(back)
         return out
 
-    def l2norm(self, x: Act, name: str) -> Act:
-        """x / ||x||_2 over channels, no epsilon (ssd_vgg.py:80)"""
+    def l2norm(self, x: Act, name: str, out: Optional[Act] = None) -> Act:
+        """x / ||x||_2 over channels, no epsilon (ssd_vgg.py:80, mdl.py:118-130); x / out may be levels of packed buffers"""
         l = x.levels[0]
         rows = x.B * l.H * l.W
-        out = self.act(name, x.B, l.H, l.W, x.C)
+        if out is None:
+            out = self.act(name, x.B, l.H, l.W, x.C)
         nrm = self._buf(rows)
-        self.fwd.add(lib.zsg_l2norm_fwd, x.buf, rows, x.C, out.buf, nrm, what=name)
+        self.fwd.add(lib.zsg_l2norm_fwd, self.base(x), rows, x.C, self.base(out), nrm, what=name)
 
         def back():
             if out.grad is None:
                 return
             g, tmp = self._grad_sink(x)
-            self.bwd.add(lib.zsg_l2norm_bwd, self.base(out.grad), out.buf, nrm, rows, x.C, (tmp or g).buf, what=name + "_bwd")
+            self.bwd.add(lib.zsg_l2norm_bwd, self.base(out.grad), self.base(out), nrm, rows, x.C, self.base(tmp or g), what=name + "_bwd")
             self._grad_commit(x, g, tmp)
         self.tape.append(back)
         return out
@@ -775,7 +778,7 @@ class _Plan:
     def _pyramid(self, sizes) -> List[Act]:
         """The head's input features: all pyramid levels packed level-major in ONE buffer (so every head convolution is
         one grouped launch); the producers write their level in place."""
-        self.Fpack = self.packed("head.feat", self.B, sizes, 256)
+        self.Fpack = self.packed("head.feat_raw" if self.net.do_norm else "head.feat", self.B, sizes, 256)
         lv = [self.Fpack.lvl(i) for i in range(len(sizes))]
         for i, a in enumerate(lv):
             a.name = f"feat{i}"
@@ -897,43 +900,55 @@ class _Plan:
         net, B = self.net, self.B
         C = net.convs
         sizes = self.feat_sizes
-        Cf, Cw = net.cf, net.cw
+        Cf, Cw, Cg = net.cf, net.cw, (4 if net.use_grid else 0)
         L0 = C["att_reg_box.0.0"]
         W0n = L0.name + ".weight"
         cp = L0.cpad
-        Fp = self.Fpack
-        nl = len(sizes)
-        assert Cf == 256 and [(f.levels[0].H, f.levels[0].W) for f in feats] == sizes
-        if bool(Cw) != bool(net.use_grid):
-            raise NotImplementedError("head input with exactly one of {language, grid} is not lowered (not a reference configuration)")
+        assert [(f.levels[0].H, f.levels[0].W) for f in feats] == sizes and cp == Cf + Cw + Cg
+        # do_norm (mdl.py:118-130): per-pixel channel L2 normalisation of the maps and of the language vector
+        Fp = self.Fpack if Cf else None
+        heads_in = feats                         # the Acts whose .grad conv0's data gradient fills
+        if net.do_norm and Cf:
+            Fp = self.packed("head.feat", B, sizes, 256)
+            heads_in = [self.l2norm(f, f"featnorm{i}", out=Fp.lvl(i)) for i, f in enumerate(feats)]
+        if net.do_norm and Cw:
+            we = self.l2norm(we, "we.norm")
         h1 = self.packed("head.h1", B, sizes, 256)
-        # conv0 sees [features | language vector (constant over the image) | grid (constant over the batch)]: only the
-        # features go through the big implicit GEMM; the other two enter as an additive map
+        # conv0 sees [features | language vector (constant over the image) | grid (constant over the batch)] (or a subset,
+        # mdl.py:363-375): only the features go through the big implicit GEMM; the rest enters as an additive map
         #   lmap[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9+tap],  V = W0[:, :, :, lang] . we[b],  G = conv(grid, W0[..., grid])
-        lmap = None
-        if Cw:
-            V = self.act("head.V", B, 1, 1, 9 * 256)
-            dv = fwd_desc(we, V, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-            self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what="head0.V")
-            gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
-            o = 0
-            for (h, w) in sizes:
-                g = anchors_mod.create_grid_np(h, w).reshape(h * w, 2)
-                gm[o:o + h * w, :2] = g
-                o += h * w
-            gridmap = self.packed("head.grid", 1, sizes, 4)
-            gridmap.buf.copy_(torch.from_numpy(gm.reshape(-1)))
-            gridmap.requires_grad = False
-            G = self.packed("head.G", 1, sizes, 256)
-            dg = fwd_desc(gridmap, G, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-            self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what="head0.G")
+        lmap, gridmap = None, None
+        if Cw or Cg:
+            V = self.act("head.V", B, 1, 1, 9 * 256, requires_grad=False)          # stays zero without language
+            if Cw:
+                dv = fwd_desc(we, V, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
+                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what="head0.V")
+            G = None
+            if Cg:
+                gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
+                o = 0
+                for (h, w) in sizes:
+                    gm[o:o + h * w, :2] = anchors_mod.create_grid_np(h, w).reshape(h * w, 2)
+                    o += h * w
+                gridmap = self.packed("head.grid", 1, sizes, 4)
+                gridmap.buf.copy_(torch.from_numpy(gm.reshape(-1)))
+                gridmap.requires_grad = False
+                G = self.packed("head.G", 1, sizes, 256)
+                dg = fwd_desc(gridmap, G, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
+                self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what="head0.G")
             lmap = self.packed("head.lmap", B, sizes, 256)
             for i, (h, w) in enumerate(sizes):
-                self.fwd.add(lib.zsg_head_lang_map, V.buf, self.base(G.lvl(i)), B, h, w, 256, self.base(lmap.lvl(i)), what=f"lmap{i}")
-        d0 = fwd_desc(Fp, h1, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0, relu=True)
-        a0 = (Fp.buf, self.P(W0n), h1.buf, self.P(L0.name + ".bias"), lmap.buf if lmap is not None else None, None, None)
-        autotune_conv("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr())
-        self.fwd.add(lib.zsg_conv_igemm, d0, *a0, what=L0.name)
+                self.fwd.add(lib.zsg_head_lang_map, V.buf, self.base(G.lvl(i)) if G is not None else None, B, h, w, 256,
+                             self.base(lmap.lvl(i)), what=f"lmap{i}")
+        if Cf:
+            d0 = fwd_desc(Fp, h1, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0, relu=True)
+            a0 = (Fp.buf, self.P(W0n), h1.buf, self.P(L0.name + ".bias"), lmap.buf if lmap is not None else None, None, None)
+            autotune_conv("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr())
+            self.fwd.add(lib.zsg_conv_igemm, d0, *a0, what=L0.name)
+        else:                             # image-blind: h1 = relu(lmap + bias), an affine map with scale 1
+            one, zero = self._buf(256) + 1.0, self._buf(256)
+            self.fwd.add(lib.zsg_bn_apply, lmap.buf, h1.rows(), 256, zero, one, one, self.P(L0.name + ".bias"), None, 1, h1.buf, None,
+                         what=L0.name)
         h1.needs_mask = True
 
         def head0_back():
@@ -941,42 +956,43 @@ class _Plan:
             if dy is None:
                 return
             gW0 = self.G(W0n)
-            dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
-            self.wgrad(dwf, Fp, dy, W0n, "wgrad:head0")
             self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0", lane=1)
-            dF = self.grad_of(Fp)
-            self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=dF)
-            for i, f in enumerate(feats):
-                assert f.grad is None
-                f.grad = dF.lvl(i)
-                f.grad.gfilled = True
-                if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
-                    n = f.B * f.levels[0].H * f.levels[0].W * f.ld
-                    self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
-            if not Cw:
-                return
-            # language / grid columns of dW0 and d(we) from the validity-masked sums of dy (no per-pixel work)
-            hws_bytes = 16 << 20           # these three run on the main stream: keep them off the side stream's slabs
-            hws = self._buf(hws_bytes // 4)
-            S = self._buf(2 * B * 9 * 256)
-            S1 = Act(S, B, 9 * 256, 9 * 256, [Level(0, 1, 1, 9 * 256)], "head.S1")
-            S2 = Act(S, 1, B, B, [Level(B * 9 * 256, 1, 9 * 256, 9 * 256 * B)], "head.S2")
-            self.bwd.add(lib.zsg_memset_f32, S, S.numel(), 0.0, what="zero:head.S")
-            for i, (h, w) in enumerate(sizes):
-                self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, S, self.base(S2), what=f"bsum{i}")
-            dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-            self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:head0.lang")
-            ent = net.store.entries[W0n]
-            Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
-            gwe = self.grad_of(we)
-            dwe = fwd_desc(Wrows, S2, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
-            self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), 0, hws, hws_bytes, what="dwe")
-            gwe.gfilled = True
-            dys = self.packed("head.dysum", 1, sizes, 256)
-            for i, (h, w) in enumerate(sizes):
-                self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
-            dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-            self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, hws, hws_bytes, what="wgrad:head0.grid")
+            if Cf:
+                dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
+                self.wgrad(dwf, Fp, dy, W0n, "wgrad:head0")
+                dF = self.grad_of(Fp)
+                self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=dF)
+                for i, f in enumerate(heads_in):
+                    assert f.grad is None
+                    f.grad = dF.lvl(i)
+                    f.grad.gfilled = True
+                    if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
+                        n = f.B * f.levels[0].H * f.levels[0].W * f.ld
+                        self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
+            hws_bytes = 16 << 20           # the small wgrads below run on the main stream: keep them off the side stream's slabs
+            hws = self._buf(hws_bytes // 4) if (Cw or Cg) else None
+            if Cw:
+                # language columns of dW0 and d(we) from the validity-masked sums of dy (no per-pixel work)
+                S = self._buf(2 * B * 9 * 256)
+                S1 = Act(S, B, 9 * 256, 9 * 256, [Level(0, 1, 1, 9 * 256)], "head.S1")
+                S2 = Act(S, 1, B, B, [Level(B * 9 * 256, 1, 9 * 256, 9 * 256 * B)], "head.S2")
+                self.bwd.add(lib.zsg_memset_f32, S, S.numel(), 0.0, what="zero:head.S")
+                for i, (h, w) in enumerate(sizes):
+                    self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, S, self.base(S2), what=f"bsum{i}")
+                dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
+                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:head0.lang")
+                ent = net.store.entries[W0n]
+                Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
+                gwe = self.grad_of(we)
+                dwe = fwd_desc(Wrows, S2, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
+                self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), 0, hws, hws_bytes, what="dwe")
+                gwe.gfilled = True
+            if Cg:
+                dys = self.packed("head.dysum", 1, sizes, 256)
+                for i, (h, w) in enumerate(sizes):
+                    self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
+                dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
+                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, hws, hws_bytes, what="wgrad:head0.grid")
             self.grad_ready[W0n] = len(self.bwd.calls)
         self.tape.append(head0_back)
         hs = [h1]
