@@ -179,6 +179,12 @@ int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int3
 int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* S1, float* S2, void* stream);
 int zsg_batch_sum(const float* x, int32_t B, int64_t stride, float* out, void* stream);
 
+/* Separate attention / box heads (use_same_atb = False, mdl.py:220-225, 383-389): their [rows][groups*k] outputs are
+ * interleaved into the [B, A, 5] tensor the loss / evaluator read (dir 0), and the incoming gradient is split the same
+ * way (dir 1):  strided[(r*groups + a)*group_stride + offset + e] <-> compact[(r*groups + a)*k + e]. */
+int zsg_interleave(float* compact, int64_t rows, int32_t groups, int32_t k, float* strided, int32_t group_stride, int32_t offset,
+                   int32_t dir, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * BiLSTM query encoder — nn.LSTM(300,128,bidirectional) on a PackedSequence + last-token gather, mdl.py:296-336.
  * gin: input projections x_t W_ih^T + b_ih  [B][T][4H] (made with zsg_conv_igemm);  one launch per direction.

@@ -376,7 +376,7 @@ def fpn_in_channels(arch: str):
 
 
 def seeded_state_dict(arch: str = "resnet50", seed: int = 0, n_anchors: int = 9, emb_dim: int = 300,
-                      lstm_dim: int = 128, head_in: int = 514, bn_noise: bool = True) -> Dict[str, torch.Tensor]:
+                      lstm_dim: int = 128, head_in: int = 514, bn_noise: bool = True, same_atb: bool = True) -> Dict[str, torch.Tensor]:
     """Deterministic random weights keyed by the reference's parameter names:
     He-normal convs, BN gamma~1 beta~0 (slightly perturbed so the affine path is exercised),
     LSTM U(+-1/sqrt(H)), head bias pattern [0,0,0,0,-4]*n_anchors (mdl.py:214-219)."""
@@ -410,13 +410,18 @@ def seeded_state_dict(arch: str = "resnet50", seed: int = 0, n_anchors: int = 9,
     for name, co, ci, k in (("P7_2", 256, 256, 3), ("P6", 256, c5, 3), ("P5_1", 256, c5, 1), ("P5_2", 256, 256, 3),
                             ("P4_1", 256, c4, 1), ("P4_2", 256, 256, 3), ("P3_1", 256, c3, 1), ("P3_2", 256, 256, 3)):
         conv(fp + name, co, ci, k, bias=True)
-    conv("att_reg_box.0.0", 256, head_in, 3, bias=True)
-    for i in range(1, 5):
-        conv(f"att_reg_box.{i}.0", 256, 256, 3, bias=True)
-    conv("att_reg_box.5", 5 * n_anchors, 256, 3, bias=True)
-    hb = torch.zeros(5 * n_anchors)
-    hb[4::5] = -4.0
-    sd["att_reg_box.5.bias"] = hb
+    for prefix, ncls in ([("att_reg_box", 5)] if same_atb else [("att_box", 1), ("reg_box", 4)]):
+        conv(prefix + ".0.0", 256, head_in, 3, bias=True)
+        for i in range(1, 5):
+            conv(f"{prefix}.{i}.0", 256, 256, 3, bias=True)
+        conv(prefix + ".5", ncls * n_anchors, 256, 3, bias=True)
+    if same_atb:
+        hb = torch.zeros(5 * n_anchors)
+        hb[4::5] = -4.0
+        sd["att_reg_box.5.bias"] = hb
+    else:                                # mdl.py:221-225
+        sd["att_box.5.bias"] = torch.full((n_anchors,), -4.0)
+        sd["reg_box.5.bias"] = torch.zeros(4 * n_anchors)
     k = 1.0 / math.sqrt(lstm_dim)
     for suf in ("", "_reverse"):
         sd["lstm.weight_ih_l0" + suf] = (torch.rand(4 * lstm_dim, emb_dim, generator=g) * 2 - 1) * k
@@ -552,12 +557,12 @@ def fuse_lang_grid(feat, we):
                       grid.unsqueeze(0).expand(B, 2, h, w)], dim=1)
 
 
-def head_forward(sd, x, prefix="att_reg_box."):
-    """6-conv shared head (mdl.py:235-244) + permute_correctly (mdl.py:246-254) -> [B, h*w*9, 5]."""
+def head_forward(sd, x, prefix="att_reg_box.", outc=5):
+    """6-conv head (mdl.py:235-244) + permute_correctly (mdl.py:246-254) -> [B, h*w*9, outc]."""
     for i in range(5):
         x = F.relu(F.conv2d(x, sd[f"{prefix}{i}.0.weight"], sd[f"{prefix}{i}.0.bias"], 1, 1))
     x = F.conv2d(x, sd[prefix + "5.weight"], sd[prefix + "5.bias"], 1, 1)
-    return x.permute(0, 2, 3, 1).contiguous().view(x.shape[0], -1, 5)
+    return x.permute(0, 2, 3, 1).contiguous().view(x.shape[0], -1, outc)
 
 
 def head_input(feat, we, use_lang=True, use_img=True):
@@ -591,9 +596,14 @@ def zsgnet_forward(sd, batch, h0, c0, arch="resnet50", training=True, six_hundre
     if do_norm:
         feats = [f / f.norm(dim=1, keepdim=True) for f in feats]
         wn = we / we.norm(dim=1, keepdim=True)
-    outs = [head_forward(sd, head_input(f, wn, use_lang, use_img)) for f in feats]
-    ab = torch.cat(outs, dim=1)
-    return dict(att_out=ab[..., 4:5], bbx_out=ab[..., :4],
+    xs = [head_input(f, wn, use_lang, use_img) for f in feats]
+    if "att_reg_box.5.weight" in sd:                 # shared head (use_same_atb, the paper's configuration)
+        ab = torch.cat([head_forward(sd, x) for x in xs], dim=1)
+        att, bbx = ab[..., 4:5], ab[..., :4]
+    else:                                            # separate heads, mdl.py:383-389
+        att = torch.cat([head_forward(sd, x, "att_box.", 1) for x in xs], dim=1)
+        bbx = torch.cat([head_forward(sd, x, "reg_box.", 4) for x in xs], dim=1)
+    return dict(att_out=att, bbx_out=bbx,
                 feat_sizes=torch.tensor([[f.shape[2], f.shape[3]] for f in feats]),
                 num_f_out=torch.tensor([len(feats)]), we=we, feats=feats)
 

@@ -374,12 +374,13 @@ def main():
 
     # ---- G12 ablation variants (mdl.py:118-130, 199-210, 363-375): blind heads and do_norm, 128x128, B=2 ------------
     for tag, kw, head_in in (("lang_blind", dict(use_lang=False), 256), ("img_blind", dict(use_img=False), 256),
-                             ("both_blind", dict(use_lang=False, use_img=False), 2), ("do_norm", dict(do_norm=True), 514)):
+                             ("both_blind", dict(use_lang=False, use_img=False), 2), ("do_norm", dict(do_norm=True), 514),
+                             ("two_heads", dict(use_same_atb=False), 514)):
         c2 = cfg.__class__(dict(cfg))
         c2.device = "cpu"
         for k, v in kw.items():
             c2[k] = v
-        sd = O.seeded_state_dict("resnet50", seed=11, head_in=head_in)
+        sd = O.seeded_state_dict("resnet50", seed=11, head_in=head_in, same_atb=c2["use_same_atb"])
         net = M.get_default_net(num_anchors=9, cfg=c2)
         net.load_state_dict(sd, strict=False)
         net.train()
@@ -404,9 +405,13 @@ def main():
                  grad_norms=np.array([grads[k].double().norm().item() for k in names]),
                  unused=np.array(sorted(k for k, p in net.named_parameters() if p.grad is None)),
                  rm_bn1=net.backbone.encoder.bn1.running_mean.numpy())
-        for k in ("att_reg_box.0.0.bias", "att_reg_box.5.bias"):
+        hp = "att_reg_box" if c2["use_same_atb"] else "reg_box"
+        for k in (hp + ".0.0.bias", hp + ".5.bias"):
             d["grad__" + k] = grads[k].numpy()
-        d["grad__att_reg_box.0.0.weight_s"] = grads["att_reg_box.0.0.weight"].numpy()[::8, ::5]
+        d["grad__" + hp + ".0.0.weight_s"] = grads[hp + ".0.0.weight"].numpy()[::8, ::5]
+        if not c2["use_same_atb"]:
+            d["grad__att_box.5.bias"] = grads["att_box.5.bias"].numpy()
+            d["keys"] = np.array(sorted(net.state_dict().keys()))
         save("g12_" + tag, **d)
     print("done")
 

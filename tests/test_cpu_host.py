@@ -91,8 +91,9 @@ def test_no_cpu_fallback():
     bt = O.synthetic_batch(2, 64, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(bt)
-    with pytest.raises(NotImplementedError):                       # the reference's unused two-head variant (mdl.py:220-225)
-        get_default_net(9, get_cfg(use_same_atb=False))
+    two = get_default_net(9, get_cfg(use_same_atb=False))          # the reference's historical two-head variant (mdl.py:220-225)
+    assert set(two.state_dict().keys()) == set(O.seeded_state_dict("resnet50", 0, same_atb=False).keys())
+    assert float(two.state_dict()["att_box.5.bias"][0]) == -4.0 and two.state_dict()["reg_box.5.weight"].shape == (36, 256, 3, 3)
     for kw, cin in ((dict(use_lang=False), 256), (dict(use_img=False), 256), (dict(use_lang=False, use_img=False), 2), (dict(do_norm=True), 514)):
         assert get_default_net(9, get_cfg(**kw)).state_dict()["att_reg_box.0.0.weight"].shape == (256, cin, 3, 3)     # mdl.py:196-209
     ssd = get_default_net(9, get_cfg(mdl_to_use="ssd_vgg"))

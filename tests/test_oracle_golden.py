@@ -255,19 +255,24 @@ def test_ssd_vgg_backbone(gold):
 
 
 ABLATIONS = {"lang_blind": dict(use_lang=False), "img_blind": dict(use_img=False),
-             "both_blind": dict(use_lang=False, use_img=False), "do_norm": dict(do_norm=True)}
+             "both_blind": dict(use_lang=False, use_img=False), "do_norm": dict(do_norm=True),
+             "two_heads": dict(use_same_atb=False)}
 
 
 @pytest.mark.parametrize("tag", sorted(ABLATIONS))
 def test_ablation_variants(gold, tag):
     """mdl.py:118-130 (do_norm) and :199-210 / :363-375 (blind heads): outputs, loss, which parameters get a gradient."""
     g = gold("g12_" + tag)
-    sd = O.seeded_state_dict("resnet50", int(g["seed"][0]), head_in=int(g["head_in"][0]))
+    kw = dict(ABLATIONS[tag])
+    same = kw.pop("use_same_atb", True)
+    sd = O.seeded_state_dict("resnet50", int(g["seed"][0]), head_in=int(g["head_in"][0]), same_atb=same)
+    if not same:      # (the golden's stand-in encoder carries an unused FPN of its own, tests/golden/make_golden.py)
+        assert set(sd.keys()) == {str(k) for k in g["keys"] if not str(k).startswith("backbone.encoder.fpn.")}
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_()
     bt = O.synthetic_batch(2, 128, 128, seed=int(g["batch_seed"][0]))
-    out = O.zsgnet_forward(sd, bt, torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"]), **ABLATIONS[tag])
+    out = O.zsgnet_forward(sd, bt, torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"]), **kw)
     assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist()
     np.testing.assert_allclose(out["att_out"].detach().numpy(), g["att_out"], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(out["bbx_out"].detach().numpy(), g["bbx_out"], rtol=1e-3, atol=1e-3)
@@ -284,10 +289,10 @@ def test_ablation_variants(gold, tag):
             np.testing.assert_allclose(v.grad.double().norm().item(), norms[k], rtol=3e-3, atol=1e-6, err_msg=k)
         else:
             assert k in unused and (v.grad is None or float(v.grad.abs().max()) == 0), k
-    for k in ("att_reg_box.0.0.bias", "att_reg_box.5.bias"):
-        ref = g["grad__" + k]
-        np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
-    ref = g["grad__att_reg_box.0.0.weight_s"]
-    np.testing.assert_allclose(sd["att_reg_box.0.0.weight"].grad.numpy()[::8, ::5], ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    for k in g.files:
+        if k.startswith("grad__"):
+            ref, got = g[k], sd[k[6:].replace("_s", "") if k.endswith("weight_s") else k[6:]].grad.numpy()
+            got = got[::8, ::5] if k.endswith("weight_s") else got
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
     # the encoder runs (and updates its BatchNorm running statistics) even when the head never sees the image
     np.testing.assert_allclose(sd["backbone.encoder.bn1.running_mean"].numpy(), g["rm_bn1"], rtol=1e-5, atol=1e-7)

@@ -471,6 +471,31 @@ extern "C" int zsg_pad_rows(const float* src, int64_t rows, int32_t C, int32_t s
     return 0;
 }
 
+// Column-group interleave between a compact [rows][groups*k] tensor and a strided one:
+//   strided[r*groups*gs + a*gs + off + e]  <->  compact[r*groups*k + a*k + e]      (a < groups, e < k)
+// dir 0: compact -> strided (separate att / box head outputs into the [B, A, 5] tensor); dir 1: strided -> compact.
+__global__ void interleave_kernel(float* __restrict__ compact, int64_t rows, int groups, int k, float* __restrict__ strided, int gs, int off,
+                                  int dir) {
+    const int64_t total = rows * groups * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % k);
+        const int64_t ra = i / k;                              // r*groups + a
+        float* s = strided + ra * gs + off + e;
+        if (dir == 0) *s = compact[i];
+        else compact[i] = *s;
+    }
+}
+extern "C" int zsg_interleave(float* compact, int64_t rows, int32_t groups, int32_t k, float* strided, int32_t group_stride, int32_t offset,
+                              int32_t dir, void* stream) {
+    ZSG_REQUIRE(compact && strided && rows > 0 && groups > 0 && k > 0 && offset >= 0 && offset + k <= group_stride, "interleave: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("interleave", st, 0, (double)rows * groups * k * 8);
+    hipLaunchKernelGGL(interleave_kernel, dim3(grid_for(rows * groups * k)), dim3(256), 0, st, compact, rows, groups, k, strided, group_stride,
+                       offset, dir);
+    ZSG_CHECK_LAUNCH("interleave");
+    return 0;
+}
+
 // ---- head conv0 without the spatially-constant channels --------------------------------------------------------------
 // The first head convolution sees [features(256) | language vector(256, constant over the image) | grid(2)].  Its
 // language part is sum_tap valid(p,tap) * V[b][tap][co] with V = W_lang * we[b] (a tiny GEMM) and its grid part does not

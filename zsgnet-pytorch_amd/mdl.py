@@ -16,6 +16,7 @@ The whole forward is a single autograd node, so the reference trainer's `loss.ba
 keep working while no autograd graph is built per layer.
 """
 import math
+import types
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -96,8 +97,7 @@ class ZSGNet(nn.Module):
         self.lstm_out_dim = self.lstm_dim * (self.bid + 1)
         self.use_lang = bool(cfg["use_lang"])
         self.use_img = bool(cfg["use_img"])
-        if not cfg["use_same_atb"]:
-            raise NotImplementedError("use_same_atb=False (separate att/reg heads, mdl.py:223-225) is not lowered yet")
+        self.same_atb = bool(cfg["use_same_atb"])
         if backbone_kind not in ("retina", "ssd_vgg"):
             raise ValueError(f"mdl_to_use={backbone_kind!r}: expected 'retina' or 'ssd_vgg' (mdl.py:410-414)")
         self.do_norm = bool(cfg["do_norm"])
@@ -234,10 +234,13 @@ class ZSGNet(nn.Module):
         self._conv(f + "P3_2", 256, 256, 3, 1, 1, bias=True)
 
     def _declare_head_lstm(self):
-        self._conv("att_reg_box.0.0", self.start_dim_head, 256, 3, 1, 1, bias=True)
-        for i in range(1, 5):
-            self._conv(f"att_reg_box.{i}.0", 256, 256, 3, 1, 1, bias=True)
-        self._conv("att_reg_box.5", 256, 5 * self.n_anchors, 3, 1, 1, bias=True)
+        # shared head (the paper's configuration) or separate attention / box heads (mdl.py:211-225)
+        heads = [("att_reg_box", 5)] if self.same_atb else [("att_box", 1), ("reg_box", 4)]
+        for prefix, ncls in heads:
+            self._conv(prefix + ".0.0", self.start_dim_head, 256, 3, 1, 1, bias=True)
+            for i in range(1, 5):
+                self._conv(f"{prefix}.{i}.0", 256, 256, 3, 1, 1, bias=True)
+            self._conv(prefix + ".5", 256, ncls * self.n_anchors, 3, 1, 1, bias=True)
         H4 = 4 * self.lstm_dim
         for suf in ([""] + (["_reverse"] if self.bid else [])):       # nn.LSTM parameter order
             self.store.add_mat("lstm.weight_ih_l0" + suf, H4, self.emb_dim)
@@ -311,9 +314,13 @@ class ZSGNet(nn.Module):
                 p.fill_(1.0)
             else:                                # BN beta
                 p.zero_()
-        hb = torch.zeros(5 * self.n_anchors)
-        hb[4::5] = -4.0
-        self.store.view("att_reg_box.5.bias").copy_(hb)
+        if self.same_atb:                        # final biases, mdl.py:214-225
+            hb = torch.zeros(5 * self.n_anchors)
+            hb[4::5] = -4.0
+            self.store.view("att_reg_box.5.bias").copy_(hb)
+        else:
+            self.store.view("att_box.5.bias").fill_(-4.0)
+            self.store.view("reg_box.5.bias").zero_()
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         """Accepts reference checkpoints: strips DDP's 'module.' prefix (utils.py:489) and tolerates torchvision's
@@ -896,47 +903,102 @@ class _Plan:
         return we
 
     def _lower_head(self, feats: List[Act], we: Optional[Act]):
-        """concat_we (mdl.py:69-104) + shared head (mdl.py:235-244) over all pyramid levels in grouped launches."""
+        """concat_we (mdl.py:69-104, blind variants :363-375, do_norm :118-130) + the head(s) (mdl.py:211-244, 377-389)
+        over all pyramid levels in grouped launches."""
+        net, B = self.net, self.B
+        sizes = self.feat_sizes
+        Cf, Cw, Cg = net.cf, net.cw, (4 if net.use_grid else 0)
+        assert [(f.levels[0].H, f.levels[0].W) for f in feats] == sizes
+        hc = types.SimpleNamespace(Cf=Cf, Cw=Cw, Cg=Cg, we=we, gridmap=None)
+        # do_norm: per-pixel channel L2 normalisation of the maps and of the language vector
+        hc.Fp = self.Fpack if Cf else None
+        heads_in = feats                         # the Acts whose .grad conv0's data gradient fills
+        if net.do_norm and Cf:
+            hc.Fp = self.packed("head.feat", B, sizes, 256)
+            heads_in = [self.l2norm(f, f"featnorm{i}", out=hc.Fp.lvl(i)) for i, f in enumerate(feats)]
+        if net.do_norm and Cw:
+            hc.we = self.l2norm(we, "we.norm")
+        if Cg:
+            gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
+            o = 0
+            for (h, w) in sizes:
+                gm[o:o + h * w, :2] = anchors_mod.create_grid_np(h, w).reshape(h * w, 2)
+                o += h * w
+            hc.gridmap = self.packed("head.grid", 1, sizes, 4)
+            hc.gridmap.buf.copy_(torch.from_numpy(gm.reshape(-1)))
+            hc.gridmap.requires_grad = False
+        P = sum(hh * ww for hh, ww in sizes)
+        self.A = P * net.n_anchors
+        nA = net.n_anchors
+
+        def out_view(buf, nout):                 # [B][P][nout]: the levels concatenated along the anchor axis
+            lv, off = [], 0
+            for (hh, ww) in sizes:
+                lv.append(Level(off * nout, hh, ww, P * nout))
+                off += hh * ww
+            return Act(buf, B, nout, nout, lv, "head.out")
+
+        if Cf and self.training:                 # runs after every head's conv0 data gradient (reverse tape order)
+            def feats_back():
+                dF = hc.Fp.grad
+                if dF is None:
+                    return
+                for i, f in enumerate(heads_in):
+                    assert f.grad is None
+                    f.grad = dF.lvl(i)
+                    f.grad.gfilled = True
+                    if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
+                        n = f.B * f.levels[0].H * f.levels[0].W * f.ld
+                        self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
+            self.tape.append(feats_back)
+
+        self.out5 = out_view(self._buf(B * P * 5 * nA), 5 * nA)
+        self.g5_in = self._buf(B * P * 5 * nA) if self.training else None
+        if net.same_atb:
+            self._head_stack("att_reg_box", 5 * nA, hc, self.out5, self.g5_in)
+            return
+        # separate heads (mdl.py:220-225, 383-389): their outputs are interleaved into the [B, A, (4 box | 1 att)] tensor the
+        # loss / evaluator kernels read, and the incoming gradient is split the same way
+        o_att, o_reg = out_view(self._buf(B * P * nA), nA), out_view(self._buf(B * P * 4 * nA), 4 * nA)
+        g_att = self._buf(B * P * nA) if self.training else None
+        g_reg = self._buf(B * P * 4 * nA) if self.training else None
+        self._head_stack("att_box", nA, hc, o_att, g_att)
+        self._head_stack("reg_box", 4 * nA, hc, o_reg, g_reg)
+        self.fwd.add(lib.zsg_interleave, o_reg.buf, B * P, nA, 4, self.out5.buf, 5, 0, 0, what="out5<-reg")
+        self.fwd.add(lib.zsg_interleave, o_att.buf, B * P, nA, 1, self.out5.buf, 5, 4, 0, what="out5<-att")
+        if self.training:
+            def split_back():
+                self.bwd.add(lib.zsg_interleave, g_reg, B * P, nA, 4, self.g5_in, 5, 0, 1, what="g5->reg")
+                self.bwd.add(lib.zsg_interleave, g_att, B * P, nA, 1, self.g5_in, 5, 4, 1, what="g5->att")
+            self.tape.append(split_back)
+
+    def _head_stack(self, prefix: str, nout: int, hc, out: Act, g_in: Optional[torch.Tensor]):
+        """One 6-convolution head `prefix`.{0..4}.0 / .5 (mdl.py:235-244) on the shared input described by hc; writes
+        `out` [B][P][nout]; its backward starts from g_in (same layout)."""
         net, B = self.net, self.B
         C = net.convs
         sizes = self.feat_sizes
-        Cf, Cw, Cg = net.cf, net.cw, (4 if net.use_grid else 0)
-        L0 = C["att_reg_box.0.0"]
+        Cf, Cw, Cg, we, Fp, gridmap = hc.Cf, hc.Cw, hc.Cg, hc.we, hc.Fp, hc.gridmap
+        L0 = C[prefix + ".0.0"]
         W0n = L0.name + ".weight"
         cp = L0.cpad
-        assert [(f.levels[0].H, f.levels[0].W) for f in feats] == sizes and cp == Cf + Cw + Cg
-        # do_norm (mdl.py:118-130): per-pixel channel L2 normalisation of the maps and of the language vector
-        Fp = self.Fpack if Cf else None
-        heads_in = feats                         # the Acts whose .grad conv0's data gradient fills
-        if net.do_norm and Cf:
-            Fp = self.packed("head.feat", B, sizes, 256)
-            heads_in = [self.l2norm(f, f"featnorm{i}", out=Fp.lvl(i)) for i, f in enumerate(feats)]
-        if net.do_norm and Cw:
-            we = self.l2norm(we, "we.norm")
-        h1 = self.packed("head.h1", B, sizes, 256)
+        assert cp == Cf + Cw + Cg
+        h1 = self.packed(prefix + ".h1", B, sizes, 256)
         # conv0 sees [features | language vector (constant over the image) | grid (constant over the batch)] (or a subset,
         # mdl.py:363-375): only the features go through the big implicit GEMM; the rest enters as an additive map
         #   lmap[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9+tap],  V = W0[:, :, :, lang] . we[b],  G = conv(grid, W0[..., grid])
-        lmap, gridmap = None, None
+        lmap = None
         if Cw or Cg:
-            V = self.act("head.V", B, 1, 1, 9 * 256, requires_grad=False)          # stays zero without language
+            V = self.act(prefix + ".V", B, 1, 1, 9 * 256, requires_grad=False)          # stays zero without language
             if Cw:
                 dv = fwd_desc(we, V, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what="head0.V")
+                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what=prefix + "0.V")
             G = None
             if Cg:
-                gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
-                o = 0
-                for (h, w) in sizes:
-                    gm[o:o + h * w, :2] = anchors_mod.create_grid_np(h, w).reshape(h * w, 2)
-                    o += h * w
-                gridmap = self.packed("head.grid", 1, sizes, 4)
-                gridmap.buf.copy_(torch.from_numpy(gm.reshape(-1)))
-                gridmap.requires_grad = False
-                G = self.packed("head.G", 1, sizes, 256)
+                G = self.packed(prefix + ".G", 1, sizes, 256)
                 dg = fwd_desc(gridmap, G, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-                self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what="head0.G")
-            lmap = self.packed("head.lmap", B, sizes, 256)
+                self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what=prefix + "0.G")
+            lmap = self.packed(prefix + ".lmap", B, sizes, 256)
             for i, (h, w) in enumerate(sizes):
                 self.fwd.add(lib.zsg_head_lang_map, V.buf, self.base(G.lvl(i)) if G is not None else None, B, h, w, 256,
                              self.base(lmap.lvl(i)), what=f"lmap{i}")
@@ -956,19 +1018,11 @@ class _Plan:
             if dy is None:
                 return
             gW0 = self.G(W0n)
-            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:head0", lane=1)
+            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:" + L0.name, lane=1)
             if Cf:
                 dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
-                self.wgrad(dwf, Fp, dy, W0n, "wgrad:head0")
-                dF = self.grad_of(Fp)
-                self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=dF)
-                for i, f in enumerate(heads_in):
-                    assert f.grad is None
-                    f.grad = dF.lvl(i)
-                    f.grad.gfilled = True
-                    if f.needs_mask:             # SSD extras feed the head post-ReLU: turn d(relu(y)) into d(y) in place
-                        n = f.B * f.levels[0].H * f.levels[0].W * f.ld
-                        self.bwd.add(lib.zsg_relu_bwd, self.base(f.grad), self.base(f), n, self.base(f.grad), 0, what=f"mask:feat{i}")
+                self.wgrad(dwf, Fp, dy, W0n, "wgrad:" + L0.name)
+                self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=self.grad_of(Fp))
             hws_bytes = 16 << 20           # the small wgrads below run on the main stream: keep them off the side stream's slabs
             hws = self._buf(hws_bytes // 4) if (Cw or Cg) else None
             if Cw:
@@ -980,56 +1034,47 @@ class _Plan:
                 for i, (h, w) in enumerate(sizes):
                     self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, S, self.base(S2), what=f"bsum{i}")
                 dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:head0.lang")
+                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:" + L0.name + ".lang")
                 ent = net.store.entries[W0n]
                 Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
                 gwe = self.grad_of(we)
                 dwe = fwd_desc(Wrows, S2, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
-                self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), 0, hws, hws_bytes, what="dwe")
+                self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), int(gwe.gfilled), hws, hws_bytes, what="dwe:" + prefix)
                 gwe.gfilled = True
             if Cg:
-                dys = self.packed("head.dysum", 1, sizes, 256)
+                dys = self.packed(prefix + ".dysum", 1, sizes, 256)
                 for i, (h, w) in enumerate(sizes):
                     self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
                 dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, hws, hws_bytes, what="wgrad:head0.grid")
+                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, hws, hws_bytes, what="wgrad:" + L0.name + ".grid")
             self.grad_ready[W0n] = len(self.bwd.calls)
         self.tape.append(head0_back)
         hs = [h1]
         for i in range(1, 5):
-            nxt = self.packed(f"head.h{i + 1}", B, sizes, 256)
-            self.conv(C[f"att_reg_box.{i}.0"], hs[-1], relu=True, out=nxt)      # backward via the tape
+            nxt = self.packed(f"{prefix}.h{i + 1}", B, sizes, 256)
+            self.conv(C[f"{prefix}.{i}.0"], hs[-1], relu=True, out=nxt)      # backward via the tape
             hs.append(nxt)
-        L5 = C["att_reg_box.5"]
-        nout = L5.cout
-        P = sum(hh * ww for hh, ww in sizes)
-        self.A = P * net.n_anchors
-        lv, off = [], 0
-        for (hh, ww) in sizes:
-            lv.append(Level(off * nout, hh, ww, P * nout))
-            off += hh * ww
-        out5 = Act(self._buf(B * P * nout), B, nout, nout, lv, "out5")
-        self.acts["out5"] = out5
-        self.out5 = out5
-        self.conv(L5, hs[-1], relu=False, out=out5)
+        L5 = C[prefix + ".5"]
+        assert L5.cout == nout
+        self.conv(L5, hs[-1], relu=False, out=out)
         self.tape.pop()
         if not self.training:
             return
-        # ---- last conv backward: the incoming [B,A,5] gradient is re-packed to 48 channels (16-byte GEMM rows) ------
+        # ---- last conv backward: the incoming gradient is re-packed to a multiple of 4 channels (16-byte GEMM rows) -----
         npad = pad4(nout)
+        P = sum(hh * ww for hh, ww in sizes)
         lvp, off = [], 0
         for (hh, ww) in sizes:
             lvp.append(Level(off * npad, hh, ww, P * npad))
             off += hh * ww
-        self.g5_in = self._buf(B * P * nout)
-        g5p = Act(self._buf(B * P * npad), B, npad, npad, lvp, "g5p")
+        g5p = Act(self._buf(B * P * npad), B, npad, npad, lvp, prefix + ".g5p")
         h5 = hs[-1]
 
         def head5_back():
-            self.bwd.add(lib.zsg_pad_rows, self.g5_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
-            self.bwd.add(lib.zsg_colsum, self.g5_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:head5", lane=1)
+            self.bwd.add(lib.zsg_pad_rows, g_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
+            self.bwd.add(lib.zsg_colsum, g_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:" + L5.name, lane=1)
             dw = fwd_desc(h5, g5p, L5.cpad, nout, 3, 1, 1, 1, wC=L5.cpad)
-            self.wgrad(dw, h5, g5p, L5.name + ".weight", "wgrad:head5")
+            self.wgrad(dw, h5, g5p, L5.name + ".weight", "wgrad:" + L5.name)
             self.dgrad(L5, g5p, h5, n=256)
         self.tape.append(head5_back)
 
