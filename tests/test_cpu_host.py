@@ -190,3 +190,35 @@ def test_bucket_reducer_and_ddp_wrapper_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_reducer_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_eval_script_prediction_files(tmp_path):
+    """eval_script.py:19-56 — pickle format, per-rank merge, each id once, STRICT IoU > thr; box_iou against the oracle."""
+    import pickle
+    from zsgnet_pytorch_amd import eval_script as E
+    rng = np.random.default_rng(0)
+    gt = np.sort(rng.uniform(0, 300, (12, 2, 2)), axis=1).transpose(0, 2, 1).reshape(12, 4)        # x1 y1 x2 y2? -> fix below
+    gt = np.stack([np.minimum(gt[:, 0], gt[:, 2]), np.minimum(gt[:, 1], gt[:, 3]), np.maximum(gt[:, 0], gt[:, 2]), np.maximum(gt[:, 1], gt[:, 3])], 1)
+    pred = gt + rng.normal(0, 25, gt.shape)
+    pred[3] = gt[3]                                              # identical box: IoU just below 1
+    pred[4] = [0, 0, 1, 1]
+    ious = [E.box_iou(p, g) for p, g in zip(pred, gt)]
+    ref = [float(O.iou_values(np.float32(p)[None], np.float32(g)[None])[0, 0]) for p, g in zip(pred, gt)]
+    assert ious == ref, "fp32 IoU must follow the reference's operation order bit for bit"
+    with open(tmp_path / "gt.csv", "w") as f:
+        f.write("img_id,bbox,query\n")
+        for i, b in enumerate(gt):
+            f.write(f'{i}.jpg,"{[float(v) for v in b]}",a thing\n')
+    recs = [{"id": float(i), "pred_boxes": [float(v) for v in pred[i]], "pred_scores": 0.5} for i in range(12)]
+    with open(tmp_path / "0_preds.pkl", "wb") as f:
+        pickle.dump(recs[:7] + recs[:2], f)                    # DDP's padded sampler repeats samples
+    with open(tmp_path / "1_preds.pkl", "wb") as f:
+        pickle.dump(recs[7:], f)
+    with pytest.raises(AssertionError):
+        E.evaluate(tmp_path / "preds.pkl", tmp_path / "gt.csv")
+    acc, corr, tot = E.evaluate(tmp_path / "preds.pkl", tmp_path / "gt.csv", num_gpus=2)
+    assert tot == 12 and corr == sum(v > 0.5 for v in ref) and acc == corr / 12 and (tmp_path / "preds.pkl").exists()
+    thr = ref[0]                                                # strict: a box exactly at the threshold is wrong
+    _, corr_at, _ = E.evaluate(tmp_path / "preds.pkl", tmp_path / "gt.csv", acc_iou_thresh=thr)
+    assert corr_at == sum(v > thr for v in ref)
+    assert E.main([str(tmp_path / "preds.pkl"), str(tmp_path / "gt.csv"), "--acc_iou_thresh=0.5"])[2] == 12

@@ -33,6 +33,7 @@ class SyntheticLoader:
         H, W = self.cfg["resize_img"]
         for i in range(self.steps):
             bt = synthetic_batch(self.bs, H, W, seed=self.seed + 1000003 * self.rank + 7919 * self.epoch + i, emb=self.cfg["emb_dim"])
+            bt["idxs"] += float((self.rank * self.steps + i) * self.bs)          # dataset row ids (dat_loader.py:140), unique per sample
             yield bt
         self.epoch += 1
 

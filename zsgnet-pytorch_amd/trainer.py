@@ -2,6 +2,7 @@
 validation loop (:353-391), the text log, and the checkpoint format (:440-497) — enough to drive the MI355X hot path
 from the same CLI.  The progress bars / tensorboard dir of the reference are not reproduced."""
 import json
+import pickle
 import logging
 import os
 import time
@@ -35,9 +36,11 @@ class Learner:
         self.log_dir = Path(cfg["tmp_path"]) / "txt_logs"
         self.model_dir = Path(cfg["tmp_path"]) / "models"
         self.model_file = self.model_dir / f"{uid}.pth"
+        self.predictions_dir = Path(cfg["tmp_path"]) / "predictions" / uid          # utils.py:248-250
         if self.rank == 0:
             self.log_dir.mkdir(parents=True, exist_ok=True)
             self.model_dir.mkdir(parents=True, exist_ok=True)
+        self.predictions_dir.mkdir(parents=True, exist_ok=True)
         self.logger = logging.getLogger("zsg." + uid)
         self.optimizer, self.lr_scheduler = None, None
         if cfg["resume"] and (cfg["resume_path"] or self.model_file.exists()):
@@ -102,12 +105,15 @@ class Learner:
         return res
 
     @torch.no_grad()
-    def validate(self, dl=None) -> Dict[str, float]:
-        """utils.py:353-391 (eval mode; metrics averaged over batches weighted by batch size, reduced to rank 0)"""
+    def validate(self, dl=None, with_predictions: bool = False):
+        """utils.py:353-391 (eval mode; losses / metrics averaged over batches weighted by batch size, reduced to rank 0).
+        with_predictions: also return the per-sample records the reference pickles — a list of
+        {'id': idxs, 'pred_boxes': [x1,y1,x2,y2] pixels, 'pred_scores': float} (utils.py:377-383, README 'Evaluation')."""
         self.mdl.eval()
         dl = dl or self.data.valid_dl
         sums = {k: torch.zeros((), device=self.device) for k in self.loss_keys + self.met_keys}
         n = 0
+        recs = []                                        # device tensors; one host copy after the loop
         for batch in dl:
             batch = self._to_device(batch)
             out = self.mdl(batch)
@@ -119,10 +125,34 @@ class Learner:
             for k in self.met_keys:
                 sums[k] += met[k] * b
             n += b
+            if with_predictions:
+                recs.append((met["idxs"], met["pred_boxes"], met["pred_scores"]))
         sums["__n"] = torch.tensor(float(n), device=self.device)
         red = zdist.reduce_dict(sums)
         tot = float(red["__n"])
-        return {k: float(red[k]) / tot for k in self.loss_keys + self.met_keys}
+        res = {k: float(red[k]) / tot for k in self.loss_keys + self.met_keys}
+        if not with_predictions:
+            return res
+        preds = []
+        if recs:
+            ids = torch.cat([r[0].reshape(-1) for r in recs]).cpu().tolist()
+            boxes = torch.cat([r[1] for r in recs]).cpu().tolist()
+            scores = torch.cat([r[2].reshape(-1) for r in recs]).cpu().tolist()
+            preds = [{"id": i, "pred_boxes": bx, "pred_scores": sc} for i, bx, sc in zip(ids, boxes, scores)]
+        return res, preds
+
+    def update_prediction_file(self, predictions, pred_file: Path):
+        """utils.py:500-509: one pickle per rank ('<rank>_<name>') when distributed — eval_script.evaluate merges them —
+        else a single file."""
+        pred_file = Path(pred_file)
+        if zdist.get_world_size() > 1:
+            with open(pred_file.parent / f"{self.rank}_{pred_file.name}", "wb") as f:
+                pickle.dump(predictions, f)
+            if self.rank == 0 and pred_file.exists():
+                pred_file.unlink()
+        else:
+            with open(pred_file, "wb") as f:
+                pickle.dump(predictions, f)
 
     def fit(self, epochs: int, lr: float):
         if self.optimizer is None:
@@ -130,7 +160,7 @@ class Learner:
         for _ in range(epochs):
             self.num_epoch += 1
             tr = self.train_epoch()
-            va = self.validate()
+            va, preds = self.validate(with_predictions=True)
             if self.lr_scheduler is not None:
                 self.lr_scheduler.step(va["Acc"])
             if self.rank == 0:
@@ -139,16 +169,18 @@ class Learner:
                 print(line, flush=True)
                 with open(self.log_dir / f"{self.uid}.txt", "a") as f:
                     f.write(line + "\n")
-                if va["Acc"] >= self.best_met:       # checkpoints only on improvement (utils.py:606-611)
-                    self.best_met = va["Acc"]
-                    self.save_model_dict()
+            if self.best_met < va[self.met_keys[0]]:       # checkpoint + predictions only on improvement (utils.py:606-611)
+                self.best_met = va[self.met_keys[0]]
+                self.save_model_dict()
+                self.update_prediction_file(preds, self.predictions_dir / f"val_preds_{self.uid}.pkl")
         return tr, va
 
     def testing(self, dls):
         dls = dls if isinstance(dls, dict) else {"valid": dls}
         out = {}
         for name, dl in dls.items():
-            out[name] = self.validate(dl)
+            out[name], preds = self.validate(dl, with_predictions=True)
+            self.update_prediction_file(preds, self.predictions_dir / f"{name}_preds.pkl")      # utils.py:664-665
             if self.rank == 0:
                 print(f"test {name}: " + " ".join(f"{k} {v:.4f}" for k, v in out[name].items()), flush=True)
         return out
