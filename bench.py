@@ -138,41 +138,65 @@ def main():
 
     roof, prof_rows = None, []
     if rank == 0 and not a.no_roofline:
-        lib.zsg_prof_enable(1)
-        nprof = 2
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
-        lib.zsg_prof_enable(0)
-        arr = (ProfEntry * 64)()
-        n = lib.zsg_prof_collect(arr, 64)
-        tot = sum(arr[i].ms for i in range(n))
-        for i in range(n):
-            e = arr[i]
-            prof_rows.append(dict(kernel=e.name.decode(), launches_per_step=e.launches / nprof, ms_per_step=e.ms / nprof,
-                                  tflops=(e.flops / (e.ms * 1e9)) if e.ms > 0 and e.flops > 0 else None,
-                                  gbps=(e.bytes / (e.ms * 1e6)) if e.ms > 0 and e.bytes > 0 else None,
-                                  share=e.ms / tot if tot else 0))
-        prof_rows.sort(key=lambda x: -x["ms_per_step"])
+        from zsgnet_pytorch_amd import ops as zops
+
+        def profiled(nprof, side):
+            """per-kernel HIP-event times (events recorded on the stream each kernel is launched on) over nprof steps"""
+            keep = zops.SIDE_STREAM
+            zops.SIDE_STREAM = side
+            step()                                    # settle into the mode
+            torch.cuda.synchronize()
+            lib.zsg_prof_enable(1)
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+            lib.zsg_prof_enable(0)
+            zops.SIDE_STREAM = keep
+            arr = (ProfEntry * 96)()
+            n = lib.zsg_prof_collect(arr, 96)
+            tot = sum(arr[i].ms for i in range(n))
+            rows = []
+            for i in range(n):
+                e = arr[i]
+                rows.append(dict(kernel=e.name.decode(), launches_per_step=e.launches / nprof, ms_per_step=e.ms / nprof,
+                                 tflops=(e.flops / (e.ms * 1e9)) if e.ms > 0 and e.flops > 0 else None,
+                                 gbps=(e.bytes / (e.ms * 1e6)) if e.ms > 0 and e.bytes > 0 else None,
+                                 share=e.ms / tot if tot else 0))
+            rows.sort(key=lambda x: -x["ms_per_step"])
+            return rows, tot / nprof
+        # as timed: weight-gradient kernels run concurrently on the side stream (what rocprofv3 of this command sees);
+        # isolated: every launch alone on the GPU (the kernel's own quality)
+        prof_rows, tot = profiled(2, zops.SIDE_STREAM)
+        iso_rows, iso_tot = profiled(2, False)
         dom = prof_rows[0]
-        traffic = None                 # HBM bytes per launch of the dominant kernel class from the separate rocprofv3 --pmc passes
-        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")       # (FETCH_SIZE x2 + WRITE_SIZE, tools/rocprof_round.sh)
+        iso = next((r for r in iso_rows if r["kernel"] == dom["kernel"]), None)
+        traffic, rp_avg = None, None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")       # written by tools/rocprof_round.sh
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(tfile)).get(dom["kernel"], {})
+                traffic, rp_avg = ent.get("hbm_bytes_per_launch"), ent.get("rocprof_avg_ms")
             except Exception:
                 traffic = None
+        flops_all = sum((r["tflops"] or 0) * r["ms_per_step"] for r in iso_rows)         # GFLOP per step over all MFMA kernels
+        mfma_ms = sum(r["ms_per_step"] for r in iso_rows if r["tflops"])
         if dom["tflops"]:
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom["ms_per_step"] / dom["launches_per_step"], 5), "launches_per_step": dom["launches_per_step"],
-                    "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(tot / nprof, 3)}
+                    "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(tot, 3),
+                    "rocprof_avg_launch_ms": rp_avg,
+                    "isolated": {"achieved": round(iso["tflops"], 2), "frac": round(iso["tflops"] / PEAK_TF, 4),
+                                 "avg_launch_ms": round(iso["ms_per_step"] / iso["launches_per_step"], 5)} if iso and iso["tflops"] else None,
+                    "all_mfma_kernels_isolated": {"achieved": round(flops_all / mfma_ms, 2) if mfma_ms else None,
+                                                  "frac": round(flops_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
+                                                  "ms_per_step": round(mfma_ms, 3)}}
         else:
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": None}
+                    "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": traffic}
         if a.prof_out:
             with open(a.prof_out, "w") as f:
-                json.dump(prof_rows, f, indent=1)
+                json.dump({"as_timed": prof_rows, "isolated": iso_rows}, f, indent=1)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.arch, a.img, a.tokens)

@@ -20,13 +20,11 @@ if ks:
 
 
 def klass(name):
-    if name.startswith("void igemm_kernel"):
-        return "conv_igemm"
-    if name.startswith("void wgrad_kernel"):
-        return "conv_wgrad"
-    if "wgrad_reduce" in name:
-        return "conv_wgrad_reduce"
-    return name.split("(")[0].replace("void ", "")[:40]
+    """the kernel name as libzsg's event profiler reports it: 'igemm_kernel<64, 64, 2, 2, false>', 'wgrad_kernel<2, 1, 16, 2, 4>'"""
+    name = name.replace("void ", "")
+    if name.startswith("wgrad_reduce_kernel"):
+        return "wgrad_reduce_kernel"
+    return name.split("(")[0][:47]
 
 
 res = {}
@@ -43,9 +41,12 @@ for pass_, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         res[k]["launches_in_pass"] = n
 for k, d in res.items():
     d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
+if ks:                                   # average duration per kernel from the --stats pass, for bench.py's cross-check
+    for r in csv.DictReader(open(ks[0])):
+        res.setdefault(klass(r["Name"]), {})["rocprof_avg_ms"] = float(r["AverageNs"]) / 1e6
 json.dump(res, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
-for k in ("conv_igemm", "conv_wgrad"):
-    if k in res:
-        print(k, {a: round(b) for a, b in res[k].items()})
+for k in sorted(res):
+    if k.startswith(("igemm_kernel", "wgrad_kernel")):
+        print(k, {a: round(b, 4) for a, b in res[k].items()})
 if ks:
     print(open(ks[0]).read()[:3000])

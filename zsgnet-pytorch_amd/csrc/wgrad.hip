@@ -345,7 +345,7 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
         p.ws = (float*)ws;
     }
     hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("conv_wgrad", st, 2.0 * rows_all * d->N * p.ncols, 0);
+    const double wg_flops = 2.0 * rows_all * d->N * p.ncols;
     dim3 grid(nmn * p.splits);
 #define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_)                                                                                 \
     do {                                                                                                                   \
@@ -357,6 +357,7 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
+        ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, 0);                        \
         hipLaunchKernelGGL((wgrad_kernel<TM_, TN_, BK_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), lds, st, p);                \
     } while (0)
     if (w8) {
@@ -376,6 +377,7 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
 #undef WG_LAUNCH
     if (p.splits > 1) {
         const int64_t total4 = (int64_t)d->N * (p.ncols / 4);
+        ZSG_PROF("wgrad_reduce_kernel", st, 0, (double)(p.splits + 1) * d->N * p.ncols * 4);
         if (p.splits >= 32 || total4 < 65536)
             hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((int)cdiv(total4, 16)), dim3(256), 0, st, p);
         else
