@@ -164,6 +164,9 @@ int zsg_l2norm_bwd(const float* dout, const float* out, const float* norm, int64
                    void* stream);
 /* image NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel zero) */
 int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t W, float* out, void* stream);
+/* uint8 [pixels][3] (HWC, as PIL decodes) -> float [pixels][4] = (r,g,b)/255, 0 — `pil2tensor(img).float().div_(255)`
+ * (dat_loader.py:26-33, 134) fused with the stem layout; IEEE division: equal to the host conversion bit for bit. */
+int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out, void* stream);
 /* head input  out[b][y][x][0:ld] = [feat(Cf) | we[b](Cw) | gridy,gridx | 0...]  — BackBone.concat_we, mdl.py:69-104.
  * gy [h], gx [w] are the create_grid centres (anchors.py:47-63).  Cf or Cw may be 0 (ablations mdl.py:363-375). */
 int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, const float* gx, int32_t B, int32_t h,

@@ -413,6 +413,60 @@ def main():
             d["grad__att_box.5.bias"] = grads["att_box.5.bias"].numpy()
             d["keys"] = np.array(sorted(net.state_dict().keys()))
         save("g12_" + tag, **d)
+
+    # ---- G13 batch producer: ImgQuDataset + collater (dat_loader.py:68-196) on a tiny on-disk dataset ----------------
+    # spaCy is absent: `nlp` is replaced by a table tokenizer (runs of word characters | single punctuation marks;
+    # unknown words -> zero vector), the same rule zsgnet_pytorch_amd.dat_loader.TableEmbedder implements.
+    import re
+    import tempfile
+    import PIL.Image
+    rng = np.random.default_rng(13)
+    words = ["the", "red", "dog", "left", "of", "a", "tree", "man", "in", "blue", "shirt", ",", "sky", "PD"]
+    table = rng.normal(0, 0.3, (len(words), 300)).astype(np.float32)
+    table[words.index("PD")] = 0.01
+
+    class Tok:
+        def __init__(self, t):
+            self.text = t
+            self.vector = table[words.index(t)] if t in words else np.zeros(300, np.float32)
+
+    def fake_nlp(text):
+        return [Tok(t) for t in re.findall(r"\w+|[^\w\s]", str(text))]
+    imgs = {"a.png": rng.integers(0, 256, (30, 40, 3), dtype=np.uint8), "b.png": rng.integers(0, 256, (47, 33, 3), dtype=np.uint8),
+            "c.png": rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)}
+    rows = [("a.png", [3, 4, 30, 25], "the red dog"), ("b.png", [0, 0, 33, 47], "man in blue shirt , left of a tree"),
+            ("c.png", [10.5, 20.25, 50, 60], "sky"), ("a.png", [5, 5, 12, 9], "unknownword left_of the tree"),
+            ("c.png", [1, 2, 3, 4], "a dog in the sky , a man")]
+    with tempfile.TemporaryDirectory() as td:
+        for k, v in imgs.items():
+            PIL.Image.fromarray(v).save(os.path.join(td, k))
+        with open(os.path.join(td, "d.csv"), "w") as f:
+            f.write("img_id,bbox,query\n")
+            for i, b, q in rows:
+                f.write(f'{i},"{b}","{q}"\n')
+        os.chdir(REF)
+        import dat_loader as DL
+        os.chdir(REPO)
+        DL.nlp = fake_nlp
+        if not hasattr(np, "float_"):
+            np.float_ = np.float64       # alias removed in NumPy 2.0; the reference (dat_loader.py:135) was written for 1.x
+        c3 = cfg.__class__(dict(cfg))
+        c3.resize_img = [48, 40]
+        c3.ds_info = cfg.__class__({"refclef": cfg.__class__({"img_dir": td})})
+        ds = DL.ImgQuDataset(c3, os.path.join(td, "d.csv"), "refclef")
+        items = [ds[i] for i in range(len(ds))]
+        batch = DL.collater(items[:3])
+    d = dict(words=np.array(words), table=table, csv_img=np.array([r[0] for r in rows]), csv_bbox=np.array([r[1] for r in rows], dtype=np.float64),
+             csv_query=np.array([r[2] for r in rows]), resize_img=np.array([48, 40]))
+    for k, v in imgs.items():
+        d["png_" + k[0]] = v
+    for i, it in enumerate(items):
+        for k, v in it.items():
+            d[f"item{i}_{k}"] = v.numpy()
+    for k, v in batch.items():
+        d["batch_" + k] = v.numpy()
+        d["batchdtype_" + k] = np.array(str(v.dtype))
+    save("g13_dataset", **d)
     print("done")
 
 

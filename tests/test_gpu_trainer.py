@@ -47,3 +47,49 @@ def test_fit_validate_predictions_and_eval_script(tmp_path):
         assert set(ck) >= {"model_state_dict", "optimizer_state_dict", "num_it", "num_epoch", "best_met"}
         again = main_dist("t0", **{k: str(v) for k, v in dict(kw, resume=True, only_val=True).items()})
         assert again.num_it == 10
+
+
+def test_real_data_loader_uint8_ingest_and_training(tmp_path, gold):
+    """dat_loader path end to end: PIL decode -> uint8 HWC pinned batch -> side-stream copy -> /255 + NHWC4 on the GPU
+    (bit-identical network output to the reference's float NCHW batch) -> a few training steps through the CLI."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import PIL.Image
+    from zsgnet_pytorch_amd import dat_loader as D
+    from zsgnet_pytorch_amd import config, mdl
+    from zsgnet_pytorch_amd.main_dist import main_dist
+    g = gold("g13_dataset")
+    for k in "abc":
+        PIL.Image.fromarray(g["png_" + k]).save(tmp_path / f"{k}.png")
+    with open(tmp_path / "d.csv", "w") as f:
+        f.write("img_id,bbox,query\n")
+        for i, b, q in zip(g["csv_img"], g["csv_bbox"], g["csv_query"]):
+            f.write(f'{i},"{[float(v) for v in b]}","{q}"\n')
+    np.savez(tmp_path / "vec.npz", words=g["words"], vectors=g["table"])
+    kw = {"resize_img": [96, 64], "word_vectors": str(tmp_path / "vec.npz"), "ds_to_use": "refclef", "bs": 2, "bsv": 2, "nw": 0, "nwv": 0,
+          "resnet_arch": "resnet18", "synthetic": False, "epochs": 2, "tmp_path": str(tmp_path / "run"),
+          "ds_info.refclef.img_dir": str(tmp_path), "ds_info.refclef.trn_csv_file": str(tmp_path / "d.csv"),
+          "ds_info.refclef.val_csv_file": str(tmp_path / "d.csv"), "ds_info.refclef.test_csv_file": str(tmp_path / "d.csv")}
+    cfg = config.get_cfg(**kw)
+    ds_f = D.ImgQuDataset(cfg, tmp_path / "d.csv", "refclef", gpu_normalise=False)
+    ds_u = D.ImgQuDataset(cfg, tmp_path / "d.csv", "refclef", gpu_normalise=True)
+    bf, bu = D.collater([ds_f[0], ds_f[1]]), D.collater([ds_u[0], ds_u[1]])
+    assert bu["img"].dtype == torch.uint8 and tuple(bu["img"].shape) == (2, 64, 96, 3) and tuple(bf["img"].shape) == (2, 3, 64, 96)
+    net = mdl.get_default_net(9, cfg).to("cuda").eval()
+    h0, c0 = torch.zeros(2, 2, 128), torch.zeros(2, 2, 128)
+    with torch.no_grad():
+        of = net({**{k: v.cuda() for k, v in bf.items()}, "h0": h0, "c0": c0})["att_bbx_out"].clone()
+        ou = net({**{k: v.cuda() for k, v in bu.items()}, "h0": h0, "c0": c0})["att_bbx_out"].clone()
+    # the kernel itself: bit-identical to pil2tensor(...).float().div_(255), channel 3 zero
+    from zsgnet_pytorch_amd import _lib as L
+    u8 = bu["img"].cuda()
+    x4 = torch.full((2, 64, 96, 4), float("nan"), device="cuda")
+    L.check(L.lib.zsg_u8hwc_to_nhwc4(u8.data_ptr(), 2 * 64 * 96, x4.data_ptr(), L.stream_ptr()), "u8hwc_to_nhwc4")
+    assert torch.equal(x4[..., :3].cpu(), bf["img"].permute(0, 2, 3, 1)) and float(x4[..., 3].abs().max()) == 0.0
+    # the network on either ingest path (split-K launches use fp32 atomics: equal up to summation order)
+    assert float((of - ou).abs().max()) < 1e-5
+    learn = main_dist("real0", **{k: str(v) for k, v in kw.items()})
+    assert isinstance(learn.data.train_dl, D.DevicePrefetcher) and learn.num_it == 4        # 5 rows, bs 2, drop_last, 2 epochs
+    res = learn.testing(learn.data.test_dl)
+    preds = pickle.load(open(learn.predictions_dir / "test0_preds.pkl", "rb"))
+    assert sorted(int(p["id"]) for p in preds) == [0, 1, 2, 3, 4] and 0.0 <= res["test0"]["Acc"] <= 1.0

@@ -23,6 +23,18 @@ DEFAULTS: Dict[str, Any] = {
     "synthetic": True,              # synthetic batches instead of the CSV datasets
     "steps_per_epoch": 50,
     "use_hip_graph": False,
+    "word_vectors": "",             # .npz word-vector table (`words`, `vectors`) used when spaCy is not installed
+    "gpu_img_normalise": True,      # images travel as uint8 HWC; /255 + NHWC4 on the GPU (bit-identical to the host path)
+    # configs/ds_info.json: where each dataset's images and csv files live (override with --ds_info.<name>.<key>=...)
+    "ds_info": {name: {"data_dir": f"./data/{root}", "img_dir": f"./data/{imgs}",
+                       **{f"{s}_csv_file": f"./data/{csv}/csv_dir/{f}.csv" for s, f in (("trn", trn), ("val", "val"), ("test", "test"))}}
+                for name, root, imgs, csv, trn in (
+                    ("flickr30k", "flickr30k", "flickr30k/flickr30k_images", "flickr30k", "train_flat"),
+                    ("refclef", "referit/refclef", "referit/saiapr_tc12_images", "referit", "train_flat"),
+                    ("flickr30k_c0", "flickr30k", "flickr30k/flickr30k_images", "flickr30k_c0", "train"),
+                    ("flickr30k_c1", "flickr30k", "flickr30k/flickr30k_images", "flickr30k_c1", "train"),
+                    ("vg_split_c2", "visual_genome/vg_split", "visual_genome", "vg_split_c2", "train"),
+                    ("vg_split_c3", "visual_genome/vg_split", "visual_genome", "vg_split_c3", "train"))},
 }
 
 

@@ -294,6 +294,24 @@ extern "C" int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t
     return 0;
 }
 
+// uint8 HWC image (as PIL decodes it) -> float NHWC4 in [0,1]: `pil2tensor(img).float().div_(255)` (dat_loader.py:26-33,
+// 134) plus the stem's layout in one pass; IEEE division, so the values equal the host conversion bit for bit.
+__global__ void u8hwc_to_nhwc4_kernel(const uint8_t* __restrict__ img, int64_t pixels, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t* p = img + i * 3;
+        f32x4 v = {(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 0.f};
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+extern "C" int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out, void* stream) {
+    ZSG_REQUIRE(img && out && pixels > 0, "u8hwc_to_nhwc4: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("u8hwc_to_nhwc4", st, 0, (double)pixels * 19);
+    hipLaunchKernelGGL(u8hwc_to_nhwc4_kernel, dim3(grid_for(pixels)), dim3(256), 0, st, img, pixels, out);
+    ZSG_CHECK_LAUNCH("u8hwc_to_nhwc4");
+    return 0;
+}
+
 // ---- head input: [feat | we | grid | 0-pad] -----------------------------------------------------------------------
 __global__ void fuse_lang_grid_kernel(const float* __restrict__ feat, const float* __restrict__ we, const float* __restrict__ gy,
                                       const float* __restrict__ gx, int B, int h, int w, int Cf, int Cw, int use_grid, int ld,

@@ -39,10 +39,14 @@ def learner_init(uid: str, cfg):
     from .loss import get_default_loss
     from .mdl import get_default_net
     from .optim import FusedAdam
-    from .synth import get_data
     from .trainer import Learner
     device = torch.device(cfg["device"])
-    data = get_data(cfg, zdist.get_rank())
+    if cfg["synthetic"]:
+        from .synth import get_data
+        data = get_data(cfg, zdist.get_rank())
+    else:                                   # CSV / image datasets of cfg.ds_to_use (dat_loader.py:233-257)
+        from .dat_loader import get_data
+        data = get_data(cfg)
     ratios, scales = ratios_scales(cfg)
     num_anchors = len(ratios) * len(scales)
     mdl = get_default_net(num_anchors=num_anchors, cfg=cfg)

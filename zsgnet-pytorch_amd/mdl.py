@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from . import anchors as anchors_mod
-from ._lib import lib, require_gpu, stream_ptr
+from ._lib import check, lib, require_gpu, stream_ptr
 from .ops import Level, Program, TView, autotune_conv, conv_out, dgrad_desc, fwd_desc
 from .params import ParamStore, pad4, register_named
 
@@ -361,7 +361,10 @@ class ZSGNet(nn.Module):
         img, qvec, qlens = inp["img"], inp["qvec"], inp["qlens"]
         if img.device.type != "cuda" or self.device.type != "cuda":
             raise RuntimeError("ZSGNet.forward needs the model and the batch on the MI355X (no CPU fallback)")
-        B, _, H, W = img.shape
+        if img.dtype == torch.uint8:           # [B, H, W, 3] as PIL decodes (dat_loader gpu_normalise): /255 happens on the GPU
+            B, H, W, _ = img.shape
+        else:
+            B, _, H, W = img.shape
         T = qvec.shape[1]
         plan = self._plan_for(B, H, W, T)
         if "h0" in inp:
@@ -1083,7 +1086,8 @@ class _Plan:
         net = self.net
         B = self.B
         img = img.contiguous()
-        if img.dtype != torch.float32:
+        u8 = img.dtype == torch.uint8
+        if not u8 and img.dtype != torch.float32:
             img = img.float()
         self.in_qvec.view(B, self.T, net.emb_dim).copy_(qvec, non_blocking=True)
         self.in_qlens.copy_(qlens.reshape(B), non_blocking=True)
@@ -1097,7 +1101,11 @@ class _Plan:
         self._img_keepalive = img
         if self.training:
             net._nbt.add_(1)
-        self.fwd.run(stream_ptr())
+        if u8:
+            check(lib.zsg_u8hwc_to_nhwc4(img.data_ptr(), B * self.H * self.W, self.fwd.calls[self.img_slot][1][5], stream_ptr()), "u8hwc_to_nhwc4")
+            self.fwd.run(stream_ptr(), self.img_slot + 1)
+        else:
+            self.fwd.run(stream_ptr())
         return self.out5.buf.view(B, self.A, 5).clone()
 
     def run_backward(self, g5: torch.Tensor):
