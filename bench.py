@@ -142,8 +142,8 @@ def main():
 
         def profiled(nprof, side):
             """per-kernel HIP-event times (events recorded on the stream each kernel is launched on) over nprof steps"""
-            keep = zops.SIDE_STREAM
-            zops.SIDE_STREAM = side
+            keep, keep_g = zops.SIDE_STREAM, zops.HIP_GRAPH
+            zops.SIDE_STREAM, zops.HIP_GRAPH = side, False      # per-launch events need eager launches
             step()                                    # settle into the mode
             torch.cuda.synchronize()
             lib.zsg_prof_enable(1)
@@ -151,7 +151,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             lib.zsg_prof_enable(0)
-            zops.SIDE_STREAM = keep
+            zops.SIDE_STREAM, zops.HIP_GRAPH = keep, keep_g
             arr = (ProfEntry * 96)()
             n = lib.zsg_prof_collect(arr, 96)
             tot = sum(arr[i].ms for i in range(n))

@@ -98,6 +98,9 @@ class ZSGNet(nn.Module):
         self.use_lang = bool(cfg["use_lang"])
         self.use_img = bool(cfg["use_img"])
         self.same_atb = bool(cfg["use_same_atb"])
+        if "use_hip_graph" in cfg and cfg["use_hip_graph"]:
+            from . import ops as _ops          # opt-in: replay launch ranges as hipGraphs (measured slower on ROCm 7.2)
+            _ops.HIP_GRAPH = True
         if backbone_kind not in ("retina", "ssd_vgg"):
             raise ValueError(f"mdl_to_use={backbone_kind!r}: expected 'retina' or 'ssd_vgg' (mdl.py:410-414)")
         self.do_norm = bool(cfg["do_norm"])
@@ -1101,11 +1104,12 @@ class _Plan:
         self._img_keepalive = img
         if self.training:
             net._nbt.add_(1)
+        assert self.img_slot == 0
         if u8:
             check(lib.zsg_u8hwc_to_nhwc4(img.data_ptr(), B * self.H * self.W, self.fwd.calls[self.img_slot][1][5], stream_ptr()), "u8hwc_to_nhwc4")
-            self.fwd.run(stream_ptr(), self.img_slot + 1)
         else:
-            self.fwd.run(stream_ptr())
+            self.fwd.run(stream_ptr(), 0, 1, graph=False)          # the one launch with a per-call pointer (the caller's image)
+        self.fwd.run(stream_ptr(), 1)
         return self.out5.buf.view(B, self.A, 5).clone()
 
     def run_backward(self, g5: torch.Tensor):

@@ -169,6 +169,9 @@ def marshal(fn, args, keep: Optional[list] = None) -> tuple:
 
 
 SIDE_STREAM = os.environ.get("ZSG_SIDE_STREAM", "1") != "0"
+HIP_GRAPH = os.environ.get("ZSG_HIP_GRAPH", "0")     # replay launch ranges as hipGraphs once they are warm ("0", "1", or program names "fwd,bwd")
+HIP_GRAPH = False if HIP_GRAPH == "0" else (True if HIP_GRAPH == "1" else tuple(HIP_GRAPH.split(",")))
+GRAPH_WARMUP = 2                                             # eager replays of a range before it is captured
 
 
 class Program:
@@ -180,6 +183,7 @@ class Program:
         self.lanes = []         # 0 = the caller's stream; 1 = side stream (leaf work nothing later in the program reads)
         self.keep = []          # ctypes structs / tensors that must outlive the program
         self._side = None
+        self._graphs = {}       # (start, stop, side-stream mode) -> [eager replays so far, captured graph | None]
 
     def add(self, fn, *args, what: str = "", lane: int = 0):
         self.calls.append((fn, marshal(fn, args, self.keep), what or fn.__name__))
@@ -190,7 +194,7 @@ class Program:
         before it (its inputs), and the main stream re-joins the side stream at the end of the range.  Weight-gradient
         kernels are leaves of the backward graph, so they fill the CUs the critical path's small launches leave idle."""
         main = torch.cuda.current_stream()
-        assert main.cuda_stream == stream
+        assert main.cuda_stream == stream, "Program.run expects torch's current stream"
         if self._side is None:
             self._side = torch.cuda.Stream()
             self._ev_pool = []
@@ -218,20 +222,42 @@ class Program:
         if used:
             main.wait_stream(side)
 
-    def run(self, stream: int, start: int = 0, stop: Optional[int] = None):
-        st = C.c_void_p(stream)
-        if SIDE_STREAM and any(self.lanes) and not os.environ.get("ZSG_DEBUG_SYNC"):
-            return self._run_lanes(stream, start, len(self.calls) if stop is None else stop)
-        calls = self.calls if (start == 0 and stop is None) else self.calls[start:stop]
+    def run(self, stream: int, start: int = 0, stop: Optional[int] = None, graph: bool = True):
+        """Replay calls[start:stop] on `stream` (torch's current stream).  A range that has been replayed GRAPH_WARMUP
+        times is captured into a hipGraph (both lanes, with their event edges) and launched as ONE graph from then on:
+        a step is ~430 launches of 10-300 us kernels, and the host needs ~35 us per eager launch."""
+        stop = len(self.calls) if stop is None else stop
         if os.environ.get("ZSG_DEBUG_SYNC"):          # locate a faulting launch: name it, run it, synchronise
-            for fn, args, what in calls:
+            st = C.c_void_p(stream)
+            for fn, args, what in self.calls[start:stop]:
                 print(f"[zsg] {self.name}/{what}", flush=True)
                 rc = fn(*args, st)
                 if rc:
                     raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
                 torch.cuda.synchronize()
             return
-        for fn, args, what in calls:
+        if not (HIP_GRAPH and graph) or stop - start < 8 or (isinstance(HIP_GRAPH, tuple) and self.name not in HIP_GRAPH):
+            return self._run_eager(stream, start, stop)
+        key = (start, stop, SIDE_STREAM)
+        ent = self._graphs.setdefault(key, [0, None])
+        if ent[1] is not None:
+            ent[1].replay()
+            return
+        if ent[0] < GRAPH_WARMUP:
+            ent[0] += 1
+            return self._run_eager(stream, start, stop)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            self._run_eager(torch.cuda.current_stream().cuda_stream, start, stop)
+        ent[1] = g
+        g.replay()
+
+    def _run_eager(self, stream: int, start: int, stop: int):
+        if SIDE_STREAM and any(self.lanes[start:stop]):
+            return self._run_lanes(stream, start, stop)
+        st = C.c_void_p(stream)
+        for fn, args, what in self.calls[start:stop]:
             rc = fn(*args, st)
             if rc:
                 raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
