@@ -218,6 +218,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

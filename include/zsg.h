@@ -177,9 +177,14 @@ int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, cons
  * go through the implicit GEMM (half the MACs of the reference's dense conv); their contribution is an additive map
  *   out[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9 + tap],   V = W[:, :, lang] * we[b]  (tiny GEMM),
  * and the backward needs the validity-masked sums  S1[b][n*9+tap] += sum_{p: tap valid at p} dy[b][p][n]  (S2 = the
- * [n*9+tap][b] transpose) plus the batch sum of dy for the grid weights.  dy / out: one pyramid level [B][h*w][N]. */
+ * [n*9+tap][b] transpose) plus the batch sum of dy for the grid weights.  The masked sums come by inclusion-exclusion
+ * from nine plain per-image sums Q (all pixels, first/last row, first/last column, four corners) that
+ * zsg_head_border_sums accumulates level by level (caller zeroes Q) and zsg_head_border_finalize turns into S1, S2 and,
+ * optionally, the bias gradient sum_b Q[0][b][:].  dy / out: one pyramid level [B][h*w][N]. */
 int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int32_t w, int32_t N, float* out, void* stream);
-int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* S1, float* S2, void* stream);
+int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* Q /* [9][B][N], += */, void* stream);
+int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad /* [N] or NULL */,
+                             void* stream);
 int zsg_batch_sum(const float* x, int32_t B, int64_t stride, float* out, void* stream);
 
 /* Separate attention / box heads (use_same_atb = False, mdl.py:220-225, 383-389): their [rows][groups*k] outputs are

@@ -307,9 +307,13 @@ def test_head_conv0_decomposition(Z, B, h, w):
     dyv = view_of(ops, dyd, B, h, w, N)
     dwf = ops.fwd_desc(view_of(ops, featd, B, h, w, Cf), dyv, Cf, N, 3, 1, 1, 1, wC=cp, wc0=0)
     L.check(L.lib.zsg_conv_wgrad(C.byref(dwf), featd.data_ptr(), dyd.data_ptr(), dW.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgrad feat")
-    S = torch.zeros(2 * B * 9 * N, device="cuda")
+    S = torch.full((2 * B * 9 * N,), float("nan"), device="cuda")
     S2p = S[B * 9 * N:]
-    L.check(L.lib.zsg_head_border_sums(dyd.data_ptr(), B, h, w, N, S.data_ptr(), S2p.data_ptr(), st), "border sums")
+    Q = torch.zeros(9 * B * N, device="cuda")
+    bg = torch.full((N,), float("nan"), device="cuda")
+    L.check(L.lib.zsg_head_border_sums(dyd.data_ptr(), B, h, w, N, Q.data_ptr(), st), "border sums")
+    L.check(L.lib.zsg_head_border_finalize(Q.data_ptr(), B, N, S.data_ptr(), S2p.data_ptr(), bg.data_ptr(), st), "border finalize")
+    assert_close(bg, dy_ref.sum((0, 1, 2)), 2e-4, 2e-4 * float(dy_ref.abs().max()) * B, "bias gradient from the image sums")
     valid = torch.zeros(9, h, w)
     for r in range(3):
         for q in range(3):

@@ -74,7 +74,8 @@ SIGNATURES = {
     "zsg_interleave": (I32, [P, I64, I32, I32, P, I32, I32, I32, P]),
     "zsg_fuse_lang_grid": (I32, [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, P]),
     "zsg_head_lang_map": (I32, [P, P, I32, I32, I32, I32, P, P]),
-    "zsg_head_border_sums": (I32, [P, I32, I32, I32, I32, P, P, P]),
+    "zsg_head_border_sums": (I32, [P, I32, I32, I32, I32, P, P]),
+    "zsg_head_border_finalize": (I32, [P, I32, I32, P, P, P, P]),
     "zsg_batch_sum": (I32, [P, I32, I64, P, P]),
     "zsg_lstm_gather_last": (I32, [P, P, I32, I32, I32, P, P]),
     "zsg_lstm_fwd": (I32, [P, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, I32, I32, P]),

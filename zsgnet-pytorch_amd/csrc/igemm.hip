@@ -121,7 +121,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
     int jx = (it0 / n_cc) % n_jx;
     int jy = it0 / (n_cc * n_jx);
 
-    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
+    // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
+    // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
+    // outstanding loads exactly (a branch made it wait for ALL of them, vmcnt(0), before parking the previous tile).
+    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], bool live) {
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
         int ws_, dxx, koff;
@@ -130,12 +133,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
             ws_ = sg.tx.w0;
             dxx = g;
             koff = 4 * g;
-            kok = g < sg.tx.n;
+            kok = live & (g < sg.tx.n);
         } else {
             ws_ = sg.tx.w0 + jx * sg.tx.wstep;
             dxx = jx * sg.tx.dstep;
             koff = cc * IG_BK + 4 * g;
-            kok = koff < Cdim;
+            kok = live & (koff < Cdim);
         }
         const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
 #pragma unroll
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
-        load_tile(ra0, rb0);
+        load_tile(ra0, rb0, true);
         store_tile(0, ra0, rb0);
-        if (n_it > 1) load_tile(ra0, rb0);           // tile 1 stays in flight across the first compute phase
+        load_tile(ra0, rb0, n_it > 1);               // tile 1 stays in flight across the first compute phase
     }
     __syncthreads();
 
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
     // one K tile: prefetch tile it+2 into `nxt`, MFMA on LDS[it&1], then park tile it+1 (already in `cur`) in the other
     // LDS buffer.  The global->register latency is covered by two compute phases instead of one.
     auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB]) {
-        if (it + 2 < n_it) load_tile(nxt_a, nxt_b);
+        load_tile(nxt_a, nxt_b, it + 2 < n_it);
         const float* a = As + (it & 1) * BM * IG_LDK + a_row * IG_LDK + 4 * lh;
         const float* b = Bs + (it & 1) * BN * IG_LDK + b_row * IG_LDK + 4 * lh;
 #pragma unroll
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < n_it) store_tile((it + 1) & 1, cur_a, cur_b);
+        store_tile((it + 1) & 1, cur_a, cur_b);      // (after the last tile: zeros into the idle buffer)
         __syncthreads();
     };
     for (int it = 0; it < n_it; it += 2) {

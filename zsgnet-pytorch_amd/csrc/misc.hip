@@ -439,6 +439,39 @@ __global__ void colsum_kernel(const float* __restrict__ x, int64_t gstride, int 
         unsafeAtomicAdd(out + (int64_t)g * C + col, s);
     }
 }
+// 16-byte variant: a thread owns 4 consecutive columns; CL column lanes x (256/CL) row lanes; four independent loads
+// in flight per thread (the scalar kernel above keeps one: measured 0.3 TB/s).
+__global__ void colsum4_kernel(const float* __restrict__ x, int64_t gstride, int rows, int ld, int c0, int C, float* __restrict__ out,
+                               int rows_per_block, int CL) {
+    __shared__ f32x4 red[256];
+    const int RL = 256 / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int col = (blockIdx.x * CL + cl) * 4;
+    const int g = blockIdx.z;
+    const int r_begin = blockIdx.y * rows_per_block;
+    const int r_end = min(rows, r_begin + rows_per_block);
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    if (col < C) {
+        const float* base = x + g * gstride + c0 + col;
+        int r = r_begin + rl;
+        for (; r + 3 * RL < r_end; r += 4 * RL) {
+            s0 += *(const f32x4*)(base + (int64_t)r * ld);
+            s1 += *(const f32x4*)(base + (int64_t)(r + RL) * ld);
+            s2 += *(const f32x4*)(base + (int64_t)(r + 2 * RL) * ld);
+            s3 += *(const f32x4*)(base + (int64_t)(r + 3 * RL) * ld);
+        }
+        for (; r < r_end; r += RL) s0 += *(const f32x4*)(base + (int64_t)r * ld);
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        f32x4 s = red[cl];
+        for (int k = 1; k < RL; ++k) s += red[k * CL + cl];
+        float* o = out + (int64_t)g * C + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, s[e]);
+    }
+}
 __global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -464,6 +497,17 @@ extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32
         if (e != hipSuccess) ZSG_FAIL(-3, "colsum: %s", hipGetErrorString(e));
     }
     ZSG_PROF("colsum", st, 0, (double)groups * rows * C * 4);
+    if ((C % 4) == 0 && (ld % 4) == 0 && (c0 % 4) == 0 && (gstride % 4) == 0 && (((uintptr_t)x) & 15) == 0) {
+        const int c4 = C / 4;
+        const int CL = c4 >= 16 ? 16 : (c4 >= 8 ? 8 : 4);     // 64 columns (256 B runs) x 16 row lanes per block
+        const int cb4 = cdiv(c4, CL);
+        int sp = cdiv(rows, 8 * (256 / CL));                  // >= 8 rows per thread ...
+        if (sp > 64) sp = 64;                                 // ... and at most 64 atomic adds per output element
+        const int rpb4 = cdiv(rows, sp);
+        hipLaunchKernelGGL(colsum4_kernel, dim3(cb4, cdiv(rows, rpb4), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CL);
+        ZSG_CHECK_LAUNCH("colsum");
+        return 0;
+    }
     int splits = cdiv(rows, 256);
     const int cb = cdiv(C, 64);
     while (splits > 1 && (int64_t)splits * cb * groups > 2048) splits = (splits + 1) / 2;
@@ -520,7 +564,7 @@ extern "C" int zsg_interleave(float* compact, int64_t rows, int32_t groups, int3
 // depend on the batch index, so only the feature channels go through the big implicit GEMM (half the MACs); these
 // three kernels build the additive map and reduce the gradient for the two cheap parts.
 //   lang_map:     out[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9 + tap]          (3x3, pad 1)
-//   border_sums:  S1[b][n*9+tap] += sum_{p: tap valid} dy[b][p][n]   and its transpose S2[n*9+tap][b]
+//   border_sums:  S1[b][n*9+tap] = sum_{p: tap valid} dy[b][p][n]   and its transpose S2[n*9+tap][b] (via nine plain sums)
 //   batch_sum:    out[i] = sum_b x[b*stride + i]
 __global__ void head_lang_map_kernel(const float* __restrict__ V, const float* __restrict__ G, int B, int h, int w, int N,
                                      float* __restrict__ out) {
@@ -559,50 +603,113 @@ extern "C" int zsg_head_lang_map(const float* V, const float* G, int32_t B, int3
     return 0;
 }
 
-// grid (N/64, row splits, B); block 256 = 64 channels x 4 row lanes; nine validity-masked column sums per thread.
-__global__ void head_border_sums_kernel(const float* __restrict__ dy, int B, int h, int w, int N, int rows_per_block,
-                                        float* __restrict__ S1, float* __restrict__ S2) {
-    __shared__ float red[4][9][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+// The nine validity-masked sums follow by inclusion-exclusion from nine plain sums per (image, channel):
+//   Q[0] = all pixels, Q[1]/Q[2] = first / last row, Q[3]/Q[4] = first / last column, Q[5..8] = the four corners;
+//   S(r,q) = Q0 - R(r) - C(q) + X(r,q)   with R(0) = first row (tap row 0 reads y-1: invalid at y = 0), R(2) = last row, ...
+// so the big pass is ONE per-image column sum with 16-byte loads (it is also the bias gradient), the borders are a few
+// pixels, and everything accumulates over pyramid levels (the sums are linear).  Q: [9][B][N], zeroed by the caller.
+__global__ void head_image_sums_kernel(const float* __restrict__ dy, int rows, int N, int rows_per_block, float* __restrict__ Q0, int CL) {
+    __shared__ f32x4 red[256];
+    const int RL = 256 / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int col = (blockIdx.x * CL + cl) * 4;
     const int b = blockIdx.z;
-    const int rows = h * w;
     const int r_begin = blockIdx.y * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
-    float s[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0;
     if (col < N) {
-        for (int p = r_begin + rl; p < r_end; p += 4) {
-            const int y = p / w, x = p - y * w;
-            const float v = dy[((int64_t)b * rows + p) * N + col];
-            // tap (r,q) reads input pixel (y+r-1, x+q-1): it contributes unless that pixel is outside the image
-            const bool r0 = y > 0, r2 = y < h - 1, q0 = x > 0, q2 = x < w - 1;
-            s[0] += (r0 && q0) ? v : 0.f; s[1] += r0 ? v : 0.f; s[2] += (r0 && q2) ? v : 0.f;
-            s[3] += q0 ? v : 0.f;         s[4] += v;            s[5] += q2 ? v : 0.f;
-            s[6] += (r2 && q0) ? v : 0.f; s[7] += r2 ? v : 0.f; s[8] += (r2 && q2) ? v : 0.f;
+        const float* base = dy + ((int64_t)b * rows) * N + col;
+        int r = r_begin + rl;
+        for (; r + RL < r_end; r += 2 * RL) {
+            s0 += *(const f32x4*)(base + (int64_t)r * N);
+            s1 += *(const f32x4*)(base + (int64_t)(r + RL) * N);
         }
+        if (r < r_end) s0 += *(const f32x4*)(base + (int64_t)r * N);
     }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) red[rl][t][threadIdx.x & 63] = s[t];
+    red[threadIdx.x] = s0 + s1;
     __syncthreads();
     if (rl == 0 && col < N) {
+        f32x4 s = red[cl];
+        for (int k = 1; k < RL; ++k) s += red[k * CL + cl];
+        float* o = Q0 + (int64_t)b * N + col;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float v = red[0][t][threadIdx.x] + red[1][t][threadIdx.x] + red[2][t][threadIdx.x] + red[3][t][threadIdx.x];
-            unsafeAtomicAdd(S1 + ((int64_t)b * N + col) * 9 + t, v);
-            unsafeAtomicAdd(S2 + ((int64_t)col * 9 + t) * B + b, v);
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, s[e]);
+    }
+}
+// one block per (image, border line): first / last row, first / last column (and their end pixels = the corners) of this
+// level, added to Q[1..8] (levels run one after another on the stream and a (b, n, quantity) element belongs to one
+// thread: plain read-modify-write)
+__global__ void head_border_lines_kernel(const float* __restrict__ dy, int B, int h, int w, int N, float* __restrict__ Q) {
+    const int b = blockIdx.x, line = blockIdx.y;
+    const float* img = dy + (int64_t)b * h * w * N;
+    const int64_t qs = (int64_t)B * N;
+    const bool is_row = line < 2;
+    const int len = is_row ? w : h;
+    const int64_t first = is_row ? (line == 0 ? 0 : (int64_t)(h - 1) * w) : (line == 2 ? 0 : w - 1);
+    const int64_t step = is_row ? 1 : w;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = 0;
+        for (; i + 3 < len; i += 4) {
+            s0 += img[(first + (int64_t)i * step) * N + n];
+            s1 += img[(first + (int64_t)(i + 1) * step) * N + n];
+            s2 += img[(first + (int64_t)(i + 2) * step) * N + n];
+            s3 += img[(first + (int64_t)(i + 3) * step) * N + n];
+        }
+        for (; i < len; ++i) s0 += img[(first + (int64_t)i * step) * N + n];
+        float* q = Q + (int64_t)b * N + n;
+        q[(1 + line) * qs] += (s0 + s1) + (s2 + s3);
+        if (is_row) {                                 // corners: (0,0), (0,w-1) from the first row; (h-1,0), (h-1,w-1) from the last
+            q[(5 + 2 * line) * qs] += img[first * N + n];
+            q[(6 + 2 * line) * qs] += img[(first + w - 1) * N + n];
         }
     }
 }
-extern "C" int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* S1, float* S2, void* stream) {
-    ZSG_REQUIRE(dy && S1 && S2 && B > 0 && h > 0 && w > 0 && N > 0, "head_border_sums: bad argument");
+extern "C" int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* Q, void* stream) {
+    ZSG_REQUIRE(dy && Q && B > 0 && h > 0 && w > 0 && N > 0 && (N % 4) == 0, "head_border_sums: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("head_border_sums", st, 0, (double)B * h * w * N * 4);
-    const int rows = h * w;
-    int splits = cdiv(rows, 128);
-    const int rpb = cdiv(rows, splits);
-    hipLaunchKernelGGL(head_border_sums_kernel, dim3(cdiv(N, 64), cdiv(rows, rpb), B), dim3(256), 0, st, dy, B, h, w, N, rpb, S1, S2);
+    const int rows = h * w, c4 = N / 4;
+    const int CL = c4 >= 16 ? 16 : (c4 >= 8 ? 8 : 4);
+    int sp = cdiv(rows, 4 * (256 / CL));
+    if (sp > 32) sp = 32;
+    const int rpb = cdiv(rows, sp);
+    hipLaunchKernelGGL(head_image_sums_kernel, dim3(cdiv(c4, CL), cdiv(rows, rpb), B), dim3(256), 0, st, dy, rows, N, rpb, Q, CL);
+    hipLaunchKernelGGL(head_border_lines_kernel, dim3(B, 4), dim3(256), 0, st, dy, B, h, w, N, Q);
     ZSG_CHECK_LAUNCH("head_border_sums");
+    return 0;
+}
+// S1[b][n*9 + r*3+q] = Q0 - R(r) - C(q) + X(r,q), S2 = its [n*9+tap][b] transpose, bias_grad[n] = sum_b Q0[b][n] (optional)
+__global__ void head_border_finalize_kernel(const float* __restrict__ Q, int B, int N, float* __restrict__ S1, float* __restrict__ S2,
+                                            float* __restrict__ bias_grad) {
+    const int64_t qs = (int64_t)B * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * N; i += gridDim.x * blockDim.x) {
+        const int b = i / N, n = i - b * N;
+        float q[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q[k] = Q[k * qs + i];
+        const float R[3] = {q[1], 0.f, q[2]}, Cc[3] = {q[3], 0.f, q[4]};
+        const float X[3][3] = {{q[5], 0.f, q[6]}, {0.f, 0.f, 0.f}, {q[7], 0.f, q[8]}};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = ((q[0] - R[r]) - Cc[c]) + X[r][c];
+                const int t = r * 3 + c;
+                S1[((int64_t)b * N + n) * 9 + t] = v;
+                S2[((int64_t)n * 9 + t) * B + b] = v;
+            }
+    }
+    if (bias_grad)
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += Q[(int64_t)b * N + n];
+            bias_grad[n] = s;
+        }
+}
+extern "C" int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad, void* stream) {
+    ZSG_REQUIRE(Q && S1 && S2 && B > 0 && N > 0, "head_border_finalize: bad argument");
+    hipLaunchKernelGGL(head_border_finalize_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, (hipStream_t)stream, Q, B, N, S1, S2, bias_grad);
+    ZSG_CHECK_LAUNCH("head_border_finalize");
     return 0;
 }
 

@@ -1024,7 +1024,8 @@ class _Plan:
             if dy is None:
                 return
             gW0 = self.G(W0n)
-            self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:" + L0.name, lane=1)
+            if not Cw:       # (with language the bias gradient falls out of the border sums below)
+                self.bwd.add(lib.zsg_colsum, dy.buf, 1, 0, dy.rows(), 256, 0, 256, self.G(L0.name + ".bias"), 1, what="bgrad:" + L0.name, lane=1)
             if Cf:
                 dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
                 self.wgrad(dwf, Fp, dy, W0n, "wgrad:" + L0.name)
@@ -1032,13 +1033,15 @@ class _Plan:
             hws_bytes = 16 << 20           # the small wgrads below run on the main stream: keep them off the side stream's slabs
             hws = self._buf(hws_bytes // 4) if (Cw or Cg) else None
             if Cw:
-                # language columns of dW0 and d(we) from the validity-masked sums of dy (no per-pixel work)
+                # language columns of dW0 and d(we) from validity-masked sums of dy, themselves nine plain per-image sums
                 S = self._buf(2 * B * 9 * 256)
+                Q = self._buf(9 * B * 256)
                 S1 = Act(S, B, 9 * 256, 9 * 256, [Level(0, 1, 1, 9 * 256)], "head.S1")
                 S2 = Act(S, 1, B, B, [Level(B * 9 * 256, 1, 9 * 256, 9 * 256 * B)], "head.S2")
-                self.bwd.add(lib.zsg_memset_f32, S, S.numel(), 0.0, what="zero:head.S")
+                self.bwd.add(lib.zsg_memset_f32, Q, Q.numel(), 0.0, what="zero:head.Q")
                 for i, (h, w) in enumerate(sizes):
-                    self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, S, self.base(S2), what=f"bsum{i}")
+                    self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, Q, what=f"bsum{i}")
+                self.bwd.add(lib.zsg_head_border_finalize, Q, B, 256, S, self.base(S2), self.G(L0.name + ".bias"), what="bsum.finalize")
                 dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
                 self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:" + L0.name + ".lang")
                 ent = net.store.entries[W0n]
