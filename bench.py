@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FWD_GF = {"resnet50": 32.569, "resnet101": None, "resnet18": None}     # BASELINE.md §3 (conv 2*MAC per image @300^2)
+FWD_GF = {"resnet50": 32.569, "resnet101": None, "resnet18": None, "ssd_vgg": 75.003}     # BASELINE.md §3 (conv 2*MAC per image @300^2)
 PEAK_TF = 157.3                                                         # fp32-input MFMA, MI355X_MICROARCH.md
 
 
@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bs", type=int, default=16, help="per-GPU batch (configs[1]: 16)")
     ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--backbone", default="retina", choices=["retina", "ssd_vgg"], help="retina = ResNet(--arch)+FPN; ssd_vgg = config 4")
     ap.add_argument("--img", type=int, default=300)
     ap.add_argument("--tokens", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +91,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
-    cfg = config.get_cfg(resnet_arch=a.arch, bs=a.bs, resize_img=[a.img, a.img])
+    cfg = config.get_cfg(resnet_arch=a.arch, bs=a.bs, resize_img=[a.img, a.img], mdl_to_use=a.backbone)
+    if a.backbone == "ssd_vgg":
+        a.arch = "ssd_vgg"
     torch.manual_seed(1234)                       # identical initial weights on every rank (and C3 broadcasts anyway)
     net = mdl.get_default_net(9, cfg).to("cuda")
     net.train()
@@ -208,8 +211,8 @@ def main():
             "metric": "train images/sec", "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (img~U[0,1), qvec~N(0,.35), random boxes; random-init weights)",
-            "config": {"workload": f"ZSGNet train step, {a.arch}+FPN, {a.img}x{a.img}, per-GPU bs={a.bs}, {a.tokens}-token queries "
-                                   f"(BASELINE configs[{1 if world == 1 else 2}] shape)", "global_batch": a.bs * world,
+            "config": {"workload": f"ZSGNet train step, {a.arch + '+FPN' if a.backbone == 'retina' else 'SSD-VGG16'}, {a.img}x{a.img}, per-GPU bs={a.bs}, {a.tokens}-token queries "
+                                   f"(BASELINE configs[{3 if a.backbone == 'ssd_vgg' else (1 if world == 1 else 2)}] shape)", "global_batch": a.bs * world,
                        "parallelism": f"dp{world}", "step": "zero_grad+fwd+loss+bwd(+allreduce)+adam+eval"},
             "step_mfma_frac": round(step_frac, 4) if step_frac else None,
             "final_loss": round(loss_val, 4), "final_acc": acc,

@@ -627,9 +627,14 @@ class _Plan:
         self.fwd.add(lib.zsg_nchw_to_nhwc4, self.in_qvec, B, 3, H, W, x0.buf, what="img")     # src pointer patched per call
 
         # ---- query encoder ----------------------------------------------------------------------------------------------
-        we = None
+        # The query encoder is independent of the image encoder: its launches go to the side stream (joined where the head
+        # first reads `we`), and its backward is replayed right after the head's — not at the very end of the step.
+        we, lstm_tape = None, []
         if net.use_lang:
+            t0 = len(self.tape)
             we = self._lower_lstm()
+            lstm_tape = self.tape[t0:]
+            del self.tape[t0:]
 
         # ---- encoder ------------------------------------------------------------------------------------------------------
         # (the image-blind variants still run the encoder, as the reference does, mdl.py:363-375: the pyramid sizes and the
@@ -662,6 +667,7 @@ class _Plan:
         self.feat_sizes = [(f.levels[0].H, f.levels[0].W) for f in feats]
         self.feat_sizes_t = torch.tensor(self.feat_sizes, dtype=torch.long, device=self.dev)
         self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
+        self.tape.extend(lstm_tape)
         self._lower_head(feats, we)
 
         # ---- backward program: replay the tape in reverse ----------------------------------------------------------
@@ -710,14 +716,14 @@ class _Plan:
         self.tape.append(back)
         return out
 
-    def l2norm(self, x: Act, name: str, out: Optional[Act] = None) -> Act:
+    def l2norm(self, x: Act, name: str, out: Optional[Act] = None, lane: int = 0) -> Act:
         """x / ||x||_2 over channels, no epsilon (ssd_vgg.py:80, mdl.py:118-130); x / out may be levels of packed buffers"""
         l = x.levels[0]
         rows = x.B * l.H * l.W
         if out is None:
             out = self.act(name, x.B, l.H, l.W, x.C)
         nrm = self._buf(rows)
-        self.fwd.add(lib.zsg_l2norm_fwd, self.base(x), rows, x.C, self.base(out), nrm, what=name)
+        self.fwd.add(lib.zsg_l2norm_fwd, self.base(x), rows, x.C, self.base(out), nrm, what=name, lane=lane)
 
         def back():
             if out.grad is None:
@@ -878,24 +884,24 @@ class _Plan:
             Tn = T if di == 0 else 1
             xin = x_all if di == 0 else xlast
             if di == 1:
-                self.fwd.add(lib.zsg_lstm_gather_last, self.in_qvec, self.in_qlens, B, T, E, xlast.buf, what="gather_last")
+                self.fwd.add(lib.zsg_lstm_gather_last, self.in_qvec, self.in_qlens, B, T, E, xlast.buf, what="gather_last", lane=1)
             gin = self.act("gin" + suf, B, 1, Tn, H4)
             d = fwd_desc(xin, gin, E, H4, 1, 1, 0, 1, wC=E)
             self.fwd.add(lib.zsg_conv_igemm, d, xin.buf, self.P("lstm.weight_ih_l0" + suf), gin.buf, self.P("lstm.bias_ih_l0" + suf),
-                         None, None, None, what="lstm_in" + suf)
+                         None, None, None, what="lstm_in" + suf, lane=1)
             gates, cst, hprev = self._buf(B * Tn * H4), self._buf(B * Tn * Hd), self._buf(B * Tn * Hd)
             h0 = self.in_h0[di * B * Hd:(di + 1) * B * Hd]
             c0 = self.in_c0[di * B * Hd:(di + 1) * B * Hd]
             lens = self.in_qlens if di == 0 else None
             self.fwd.add(lib.zsg_lstm_fwd, gin.buf, self.P("lstm.weight_hh_l0" + suf), self.P("lstm.bias_hh_l0" + suf), h0, c0,
-                         self.in_qlens, lens, B, Tn, Hd, gates, cst, hprev, we.buf, net.lstm_out_dim, di * Hd, what="lstm" + suf)
+                         self.in_qlens, lens, B, Tn, Hd, gates, cst, hprev, we.buf, net.lstm_out_dim, di * Hd, what="lstm" + suf, lane=1)
 
             def back(suf=suf, di=di, Tn=Tn, xin=xin, gates=gates, cst=cst, hprev=hprev, c0=c0, lens=lens):
                 if we.grad is None:
                     return
                 dg = Act(self._buf(B * Tn * H4), B, H4, H4, [Level(0, 1, Tn, Tn * H4)], "dgates" + suf)
                 self.bwd.add(lib.zsg_lstm_bwd, we.grad.buf, net.lstm_out_dim, di * Hd, self.P("lstm.weight_hh_l0" + suf), gates, cst, c0,
-                             self.in_qlens, lens, B, Tn, Hd, dg.buf, what="lstm_bwd" + suf)
+                             self.in_qlens, lens, B, Tn, Hd, dg.buf, what="lstm_bwd" + suf, lane=1)
                 d_ih = fwd_desc(xin, dg, E, H4, 1, 1, 0, 1, wC=E)
                 self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
                              what="wgrad:w_ih" + suf, lane=1)
@@ -923,7 +929,7 @@ class _Plan:
             hc.Fp = self.packed("head.feat", B, sizes, 256)
             heads_in = [self.l2norm(f, f"featnorm{i}", out=hc.Fp.lvl(i)) for i, f in enumerate(feats)]
         if net.do_norm and Cw:
-            hc.we = self.l2norm(we, "we.norm")
+            hc.we = self.l2norm(we, "we.norm", lane=2)
         if Cg:
             gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
             o = 0
@@ -998,7 +1004,7 @@ class _Plan:
             V = self.act(prefix + ".V", B, 1, 1, 9 * 256, requires_grad=False)          # stays zero without language
             if Cw:
                 dv = fwd_desc(we, V, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what=prefix + "0.V")
+                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what=prefix + "0.V", lane=2)
             G = None
             if Cg:
                 G = self.packed(prefix + ".G", 1, sizes, 256)

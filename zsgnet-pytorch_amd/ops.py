@@ -180,7 +180,8 @@ class Program:
     def __init__(self, name: str = ""):
         self.name = name
         self.calls = []
-        self.lanes = []         # 0 = the caller's stream; 1 = side stream (leaf work nothing later in the program reads)
+        self.lanes = []         # 0 = the caller's stream; 1 = side stream (work whose results are not read before the next
+                                # join); 2 = the caller's stream after it has waited for the side stream (a join)
         self.keep = []          # ctypes structs / tensors that must outlive the program
         self._side = None
         self._graphs = {}       # (start, stop, side-stream mode) -> [eager replays so far, captured graph | None]
@@ -203,7 +204,10 @@ class Program:
         dirty, used, nev = True, False, 0
         for i in range(start, stop):
             fn, args, what = self.calls[i]
-            if self.lanes[i]:
+            if self.lanes[i] == 2 and used:
+                main.wait_stream(side)
+                used = False
+            if self.lanes[i] == 1:
                 if dirty:
                     if nev == len(self._ev_pool):
                         self._ev_pool.append(torch.cuda.Event())
