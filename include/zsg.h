@@ -183,7 +183,7 @@ int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, cons
  * optionally, the bias gradient sum_b Q[0][b][:].  dy / out: one pyramid level [B][h*w][N]. */
 int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int32_t w, int32_t N, float* out, void* stream);
 int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* Q /* [9][B][N], += */, void* stream);
-int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad /* [N] or NULL */,
+int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad /* [N], += ; or NULL */,
                              void* stream);
 int zsg_batch_sum(const float* x, int32_t B, int64_t stride, float* out, void* stream);
 

@@ -310,7 +310,7 @@ def test_head_conv0_decomposition(Z, B, h, w):
     S = torch.full((2 * B * 9 * N,), float("nan"), device="cuda")
     S2p = S[B * 9 * N:]
     Q = torch.zeros(9 * B * N, device="cuda")
-    bg = torch.full((N,), float("nan"), device="cuda")
+    bg = torch.zeros(N, device="cuda")                          # the finalize kernel accumulates (+=) the bias gradient
     L.check(L.lib.zsg_head_border_sums(dyd.data_ptr(), B, h, w, N, Q.data_ptr(), st), "border sums")
     L.check(L.lib.zsg_head_border_finalize(Q.data_ptr(), B, N, S.data_ptr(), S2p.data_ptr(), bg.data_ptr(), st), "border finalize")
     assert_close(bg, dy_ref.sum((0, 1, 2)), 2e-4, 2e-4 * float(dy_ref.abs().max()) * B, "bias gradient from the image sums")

@@ -678,7 +678,7 @@ extern "C" int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32
     ZSG_CHECK_LAUNCH("head_border_sums");
     return 0;
 }
-// S1[b][n*9 + r*3+q] = Q0 - R(r) - C(q) + X(r,q), S2 = its [n*9+tap][b] transpose, bias_grad[n] = sum_b Q0[b][n] (optional)
+// S1[b][n*9 + r*3+q] = Q0 - R(r) - C(q) + X(r,q), S2 = its [n*9+tap][b] transpose, bias_grad[n] += sum_b Q0[b][n] (optional)
 __global__ void head_border_finalize_kernel(const float* __restrict__ Q, int B, int N, float* __restrict__ S1, float* __restrict__ S2,
                                             float* __restrict__ bias_grad) {
     const int64_t qs = (int64_t)B * N;
@@ -703,7 +703,7 @@ __global__ void head_border_finalize_kernel(const float* __restrict__ Q, int B, 
         for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
             float s = 0.f;
             for (int b = 0; b < B; ++b) s += Q[(int64_t)b * N + n];
-            bias_grad[n] = s;
+            bias_grad[n] += s;
         }
 }
 extern "C" int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad, void* stream) {

@@ -124,6 +124,7 @@ class ZSGNet(nn.Module):
         self._register()
         self.reset_parameters()
         self._plans: Dict[Tuple, "_Plan"] = {}
+        self._anchor = None
         self.debug = False
 
     # ------------------------------------------------------------------------------------------------------
@@ -374,22 +375,26 @@ class ZSGNet(nn.Module):
             h0, c0 = inp["h0"], inp["c0"]
         else:
             h0, c0 = self.lstm_init_hidden(B)
-        params = self._ordered_params()
-        out5 = _NetFn.apply(self, plan, img, qvec, qlens, h0, c0, *params)
+        # ONE differentiable input ties the custom Function into autograd: run_backward writes the parameter gradients
+        # straight into the flat gradient buffer that every p.grad views, so autograd has nothing to accumulate per
+        # parameter (161 AccumulateGrad nodes cost the host ~0.5 ms per step with the GPU idle at the end of backward)
+        if self._anchor is None or self._anchor.device != img.device:
+            self._anchor = torch.zeros(1, device=img.device, requires_grad=True)
+        out5 = _NetFn.apply(self, plan, img, qvec, qlens, h0, c0, self._anchor)
         return dict(att_out=out5[..., 4:5], bbx_out=out5[..., :4], feat_sizes=plan.feat_sizes_t,
                     num_f_out=plan.num_f_out_t, att_bbx_out=out5)
 
 
 class _NetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, plan, img, qvec, qlens, h0, c0, *params):
+    def forward(ctx, net, plan, img, qvec, qlens, h0, c0, anchor):
         ctx.net, ctx.plan = net, plan
         return plan.run_forward(img, qvec, qlens, h0, c0)
 
     @staticmethod
     def backward(ctx, g5):
-        grads = ctx.plan.run_backward(g5)
-        return (None,) * 7 + tuple(grads)
+        ctx.plan.run_backward(g5)
+        return (None,) * 8
 
 
 class _Plan:
@@ -533,11 +538,13 @@ class _Plan:
             self.dgrad(L, dy, src, n=L.cpad)
 
     def wgrad(self, d, src: Act, dy: Act, pname: str, what: str):
-        """weight gradient of one parameter (written, not accumulated: every parameter has exactly one wgrad launch;
-        the shared head's pyramid levels are segments of that one launch)"""
+        """weight gradient of one parameter, accumulated into the flat gradient buffer (every parameter has exactly one
+        wgrad launch per backward; the shared head's pyramid levels are segments of that one launch).  The autotuner's
+        trial launches write a scratch image, never the gradient buffer."""
         gw = self.G(pname)
-        args = (src.buf, dy.buf, gw, 0, self.wg_ws, self.wg_ws_bytes)
-        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, args, stream_ptr(), self.wg_ws_bytes)
+        args = (src.buf, dy.buf, gw, 1, self.wg_ws, self.wg_ws_bytes)
+        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, (src.buf, dy.buf, self.tune_dw, 0, self.wg_ws, self.wg_ws_bytes), stream_ptr(),
+                      self.wg_ws_bytes)
         if not d.tile_hint:          # autotune disabled: make sure the heuristic's slabs fit
             assert lib.zsg_conv_wgrad_workspace_bytes(d) <= self.wg_ws_bytes or True
         self.bwd.add(lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
@@ -615,6 +622,7 @@ class _Plan:
         self.ws = self._buf(self.ws_bytes // 4)
         self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
+        self.tune_dw = self._buf(max(e.size for e in net.store.entries.values()) + 64)
 
         # ---- static inputs ------------------------------------------------------------------------------------------
         self.in_qvec = self._buf(B * T * net.emb_dim)
@@ -903,11 +911,11 @@ class _Plan:
                 self.bwd.add(lib.zsg_lstm_bwd, we.grad.buf, net.lstm_out_dim, di * Hd, self.P("lstm.weight_hh_l0" + suf), gates, cst, c0,
                              self.in_qlens, lens, B, Tn, Hd, dg.buf, what="lstm_bwd" + suf, lane=1)
                 d_ih = fwd_desc(xin, dg, E, H4, 1, 1, 0, 1, wC=E)
-                self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
+                self.bwd.add(lib.zsg_conv_wgrad, d_ih, xin.buf, dg.buf, self.G("lstm.weight_ih_l0" + suf), 1, self.wg_ws, self.wg_ws_bytes,
                              what="wgrad:w_ih" + suf, lane=1)
                 hp = Act(hprev, B, Hd, Hd, [Level(0, 1, Tn, Tn * Hd)], "hprev" + suf)
                 d_hh = fwd_desc(hp, dg, Hd, H4, 1, 1, 0, 1, wC=Hd)
-                self.bwd.add(lib.zsg_conv_wgrad, d_hh, hp.buf, dg.buf, self.G("lstm.weight_hh_l0" + suf), 0, self.wg_ws, self.wg_ws_bytes,
+                self.bwd.add(lib.zsg_conv_wgrad, d_hh, hp.buf, dg.buf, self.G("lstm.weight_hh_l0" + suf), 1, self.wg_ws, self.wg_ws_bytes,
                              what="wgrad:w_hh" + suf, lane=1)
                 for bname in ("lstm.bias_ih_l0", "lstm.bias_hh_l0"):
                     self.bwd.add(lib.zsg_colsum, dg.buf, 1, 0, B * Tn, H4, 0, H4, self.G(bname + suf), 1, what="bgrad:" + bname + suf, lane=1)
@@ -1049,7 +1057,7 @@ class _Plan:
                     self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, Q, what=f"bsum{i}")
                 self.bwd.add(lib.zsg_head_border_finalize, Q, B, 256, S, self.base(S2), self.G(L0.name + ".bias"), what="bsum.finalize")
                 dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 0, hws, hws_bytes, what="wgrad:" + L0.name + ".lang")
+                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 1, hws, hws_bytes, what="wgrad:" + L0.name + ".lang")
                 ent = net.store.entries[W0n]
                 Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
                 gwe = self.grad_of(we)
@@ -1061,7 +1069,7 @@ class _Plan:
                 for i, (h, w) in enumerate(sizes):
                     self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
                 dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 0, hws, hws_bytes, what="wgrad:" + L0.name + ".grid")
+                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 1, hws, hws_bytes, what="wgrad:" + L0.name + ".grid")
             self.grad_ready[W0n] = len(self.bwd.calls)
         self.tape.append(head0_back)
         hs = [h1]
@@ -1125,11 +1133,14 @@ class _Plan:
         net = self.net
         if not self.training:
             raise RuntimeError("backward through an eval-mode plan")
+        # Gradients are ACCUMULATED (+=) into the flat gradient buffer, as autograd does into p.grad: the buffer is zeroed by
+        # FusedAdam.zero_grad() (one memset, the p.grad views stay), or here when the p.grad were set to None.
         params = net._ordered_params()
-        fresh = all(p.grad is None for p in params)
         st = stream_ptr()
-        if fresh:
+        if any(p.grad is None for p in params):
             lib.zsg_memset_f32(net.store.grad.data_ptr(), net.store.grad.numel(), 0.0, st)
+            for n, p in zip(net._param_names, params):
+                p.grad = net.store.view(n, net.store.grad)
         self.g5_in.view_as(g5).copy_(g5)
         ddp = getattr(net, "_ddp", None)
         self.prep.run(st)
@@ -1145,9 +1156,6 @@ class _Plan:
             self.reducer.wait()
         else:
             self.bwd.run(st)
-        if not fresh:
-            return [None] * len(params)      # gradients were accumulated in place into the tensors p.grad already views
-        return [net.store.view(n, net.store.grad) for n in net._param_names]
 
 
 def get_default_net(num_anchors=1, cfg=None):

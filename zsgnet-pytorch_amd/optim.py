@@ -18,9 +18,16 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = torch.zeros(1, dtype=torch.int32, device=flat.device)
         self.grad_scale = grad_scale
 
-    def zero_grad(self, set_to_none: bool = True):
-        for p in self.net._ordered_params():
-            p.grad = None            # gradients live in the flat buffer, which backward re-zeroes
+    def zero_grad(self, set_to_none: bool = False):
+        """One memset of the flat gradient buffer; the p.grad views stay (backward accumulates into them).  With
+        set_to_none=True the views are dropped instead and the next backward re-creates them."""
+        if set_to_none:
+            for p in self.net._ordered_params():
+                p.grad = None
+            return
+        st = self.net.store
+        if st.grad is not None and st.grad.is_cuda:
+            check(lib.zsg_memset_f32(st.grad.data_ptr(), st.grad.numel(), 0.0, stream_ptr()), "zero_grad")
 
     @torch.no_grad()
     def step(self, closure=None):
