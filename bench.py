@@ -10,8 +10,9 @@ img ~ U[0,1) 300x300, 20-token queries, per-GPU batch 16 = BASELINE configs[1]).
 steps between barrier + torch.cuda.synchronize(); MAX over ranks; rank 0 prints ONE JSON line.
 
 Extra legs (rank 0, outside the timed region):
-  roofline     — per-launch HIP-event timing of every kernel class (zsg_prof_*); the dominant class is reported as
-                 achieved TFLOP/s = algorithmic 2*MAC / event time against the 157.3 TFLOP/s fp32-MFMA peak.
+  roofline     — per-launch HIP-event timing of every kernel (zsg_prof_*, entries named as rocprofv3 names them); the
+                 kernel with the largest share is reported as achieved TFLOP/s = algorithmic 2*MAC / event time against the
+                 157.3 TFLOP/s fp32-MFMA peak: with every launch alone on the GPU (primary) and as timed (side stream on).
   cpu_baseline — the CPU oracle's same step (torch-CPU fp32, B=4) on the host cores ("port"); N=1 only.
 """
 import argparse
@@ -169,16 +170,19 @@ def main():
             return rows, tot / nprof
         # as timed: weight-gradient kernels run concurrently on the side stream (what rocprofv3 of this command sees);
         # isolated: every launch alone on the GPU (the kernel's own quality)
-        prof_rows, tot = profiled(2, zops.SIDE_STREAM)
+        # isolated: every launch alone on the GPU (one stream) — the kernel's own duration, what the roofline fraction is
+        # about; as timed: with the weight-gradient kernels co-running on the side stream (the timed region's mode), where
+        # kernels time-share the CUs and one kernel's duration is no longer a property of that kernel
         iso_rows, iso_tot = profiled(2, False)
-        dom = prof_rows[0]
-        iso = next((r for r in iso_rows if r["kernel"] == dom["kernel"]), None)
-        traffic, rp_avg = None, None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        prof_rows, tot = profiled(2, zops.SIDE_STREAM)
+        dom = iso_rows[0]
+        timed = next((r for r in prof_rows if r["kernel"] == dom["kernel"]), None)
+        traffic, rp_avg, rp_ser = None, None, None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
         tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")       # written by tools/rocprof_round.sh
         if os.path.exists(tfile):
             try:
                 ent = json.load(open(tfile)).get(dom["kernel"], {})
-                traffic, rp_avg = ent.get("hbm_bytes_per_launch"), ent.get("rocprof_avg_ms")
+                traffic, rp_avg, rp_ser = ent.get("hbm_bytes_per_launch"), ent.get("rocprof_avg_ms"), ent.get("rocprof_avg_ms_serial")
             except Exception:
                 traffic = None
         flops_all = sum((r["tflops"] or 0) * r["ms_per_step"] for r in iso_rows)         # GFLOP per step over all MFMA kernels
@@ -187,13 +191,15 @@ def main():
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom["ms_per_step"] / dom["launches_per_step"], 5), "launches_per_step": dom["launches_per_step"],
-                    "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(tot, 3),
-                    "rocprof_avg_launch_ms": rp_avg,
-                    "isolated": {"achieved": round(iso["tflops"], 2), "frac": round(iso["tflops"] / PEAK_TF, 4),
-                                 "avg_launch_ms": round(iso["ms_per_step"] / iso["launches_per_step"], 5)} if iso and iso["tflops"] else None,
-                    "all_mfma_kernels_isolated": {"achieved": round(flops_all / mfma_ms, 2) if mfma_ms else None,
-                                                  "frac": round(flops_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
-                                                  "ms_per_step": round(mfma_ms, 3)}}
+                    "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(iso_tot, 3),
+                    "rocprof_avg_launch_ms": rp_ser, "mode": "one stream (ZSG_SIDE_STREAM=0): every launch alone on the GPU",
+                    "as_timed": {"achieved": round(timed["tflops"], 2), "frac": round(timed["tflops"] / PEAK_TF, 4),
+                                 "avg_launch_ms": round(timed["ms_per_step"] / timed["launches_per_step"], 5),
+                                 "rocprof_avg_launch_ms": rp_avg, "all_kernels_ms_per_step": round(tot, 3),
+                                 "mode": "weight-gradient kernels co-running on the side stream"} if timed and timed["tflops"] else None,
+                    "all_mfma_kernels": {"achieved": round(flops_all / mfma_ms, 2) if mfma_ms else None,
+                                         "frac": round(flops_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
+                                         "ms_per_step": round(mfma_ms, 3)}}
         else:
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": traffic}

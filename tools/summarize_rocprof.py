@@ -44,6 +44,11 @@ for k, d in res.items():
 if ks:                                   # average duration per kernel from the --stats pass, for bench.py's cross-check
     for r in csv.DictReader(open(ks[0])):
         res.setdefault(klass(r["Name"]), {})["rocprof_avg_ms"] = float(r["AverageNs"]) / 1e6
+kser = glob.glob(out + "/stats_serial/*/*kernel_stats.csv")        # ZSG_SIDE_STREAM=0: every launch alone on the GPU
+if kser:
+    shutil.copy(kser[0], os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))
+    for r in csv.DictReader(open(kser[0])):
+        res.setdefault(klass(r["Name"]), {})["rocprof_avg_ms_serial"] = float(r["AverageNs"]) / 1e6
 json.dump(res, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(res):
     if k.startswith(("igemm_kernel", "wgrad_kernel")):

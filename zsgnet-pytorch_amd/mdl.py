@@ -1095,7 +1095,8 @@ class _Plan:
 
         def head5_back():
             self.bwd.add(lib.zsg_pad_rows, g_in, B * P, nout, nout, g5p.buf, npad, what="pad g5")
-            self.bwd.add(lib.zsg_colsum, g_in, 1, 0, B * P, nout, 0, nout, self.G(L5.name + ".bias"), 1, what="bgrad:" + L5.name, lane=1)
+            # column sums of the PADDED copy (16-byte loads; its pad columns are zero and land in the 4-float storage padding)
+            self.bwd.add(lib.zsg_colsum, g5p.buf, 1, 0, B * P, npad, 0, npad, self.G(L5.name + ".bias"), 1, what="bgrad:" + L5.name, lane=1)
             dw = fwd_desc(h5, g5p, L5.cpad, nout, 3, 1, 1, 1, wC=L5.cpad)
             self.wgrad(dw, h5, g5p, L5.name + ".weight", "wgrad:" + L5.name)
             self.dgrad(L5, g5p, h5, n=256)
