@@ -48,7 +48,8 @@ __device__ __forceinline__ int fdiv(int a, int d, float rcp) {   // a < 2^24, ex
 }
 
 // Block tile (32*TM*WM) x (32*TN*WN) computed by WM x WN waves, each TM x TN MFMA tiles of 32x32.
-template <int TM, int TN, int WG_BK, int WM, int WN>
+// AVEC: dY rows are 16-byte addressable (out_ld % 4 == 0; a ragged channel count just reads the row's own padding).
+template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -80,7 +81,6 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     const int gb = tid % GB, kb = tid / GB;
     const int na = m0 + 4 * ga;                    // first dY channel of this thread's 16-byte group
     const bool a_colok = na < p.N;
-    const bool a_vec = ((p.out_ld & 3) == 0) && (na + 4 <= p.N);
     const int q = n0 + 4 * gb;                     // first logical weight column of this thread's group
     const bool b_colok = q < p.ncols;
     int b_dy, b_dx, b_c;
@@ -103,7 +103,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     int kt_next = kt_begin;
 
     f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];      // two register stages: global loads run two K tiles ahead
-    auto load_tile = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+    // live == false (past this block's last K tile): every lane gets an out-of-range offset — the loads still issue and
+    // return zeros without touching memory, so the K loop has no branch around them and the compiler counts the
+    // outstanding loads exactly (with a branch it waited for ALL of them, vmcnt(0), before parking the previous tile).
+    auto load_tile = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], bool live) {
         if (si + 1 < p.nseg && kt_next >= p.seg[si + 1].kt0) {     // wave-uniform segment switch
             ++si;
             sg = p.seg[si];
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int r = rbase + ka + PA * j;
-            const bool rok = r < sg.rows;
+            const bool rok = live & (r < sg.rows);
             const int rr = rok ? r : 0;
             int b = fdiv(rr, per, sg.inv_per);
             int rem = rr - b * per;
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
             if (p.dbg & 1) { b = 0; y = 0; x = rr & 31; }
             const unsigned off = 4u * (unsigned)(sg.out_off + b * sg.out_bstride +
                                                   ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld + na);
-            if (a_vec) {
+            if (AVEC) {
                 ra[j] = buf_load4(rs_a, (rok & a_colok) ? off : ZSG_OOB);
-            } else {                                                  // unaligned / ragged channel count (N = 45)
+            } else {                                                  // rows not 16-byte addressable (out_ld % 4 != 0)
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = buf_load1(rs_a, (rok & (na + e < p.N)) ? off + 4u * e : ZSG_OOB);
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int r = rbase + kb + PB * j;
-            const bool rok = r < sg.rows;
+            const bool rok = live & (r < sg.rows);
             const int rr = rok ? r : 0;
             int b = fdiv(rr, per, sg.inv_per);
             int rem = rr - b * per;
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
 
     const int n_kt = kt_end - kt_begin;
     if (n_kt > 0) {
-        load_tile(ra0, rb0);
+        load_tile(ra0, rb0, true);
         store_tile(0, ra0, rb0);
-        if (n_kt > 1) load_tile(ra0, rb0);
+        load_tile(ra0, rb0, n_kt > 1);
     }
     __syncthreads();
 
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     const int bn = wn * (32 * TN) + li;
     auto k_step = [&](int it, f32x4 (&cur_a)[NA], f32x4 (&cur_b)[NB], f32x4 (&nxt_a)[NA], f32x4 (&nxt_b)[NB]) {
         const int buf = it & 1;
-        if (it + 2 < n_kt) load_tile(nxt_a, nxt_b);
+        load_tile(nxt_a, nxt_b, it + 2 < n_kt);
+        __builtin_amdgcn_sched_barrier(0);           // keep the global loads AHEAD of the MFMA phase (the scheduler sinks them otherwise)
 #pragma unroll
         for (int kk = 0; kk < WG_BK / 2; ++kk) {
             const int k = 2 * kk + lh;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < n_kt) store_tile(buf ^ 1, cur_a, cur_b);
+        store_tile(buf ^ 1, cur_a, cur_b);           // (after the last tile: zeros into the idle buffer)
         __syncthreads();
     };
     for (int it = 0; it < n_kt; it += 2) {
@@ -296,7 +300,8 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
     p.ncols = p.ty.n * p.tx.n * d->C;
     int kt = 0;
     double rows_all = 0;
-    const int BKsel = ((d->tile_hint >> 25) & 1) ? 32 : 16;       // tile_hint bit 25: 32-pixel K tiles
+    const bool avec = (d->out_ld & 3) == 0;                       // else: the single scalar-load variant (64x64 tile, BK 16)
+    const int BKsel = (avec && ((d->tile_hint >> 25) & 1)) ? 32 : 16;       // tile_hint bit 25: 32-pixel K tiles
     p.bk = BKsel;
     for (int s = 0; s < d->nseg; ++s) {
         const zsg_seg& a = d->seg[s];
@@ -330,6 +335,7 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
         want_splits = (d->tile_hint >> 16) & 0xff;
         w8 = ((d->tile_hint >> 24) & 1) && TM == 2 && TN == 2;      // 8-wave workgroup: 128x128 tile only
     }
+    if (!avec) { TM = 1; TN = 1; w8 = 0; }
     p.m_tiles = cdiv(d->N, 64 * TM);
     p.n_tiles = cdiv(p.ncols, 64 * TN);
     const int nmn = p.m_tiles * p.n_tiles;
@@ -347,20 +353,23 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
     hipStream_t st = (hipStream_t)stream;
     const double wg_flops = 2.0 * rows_all * d->N * p.ncols;
     dim3 grid(nmn * p.splits);
-#define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_)                                                                                 \
+#define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_) WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, true)
+#define WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, AV_)                                                                          \
     do {                                                                                                                   \
         const size_t lds = (size_t)2 * BK_ * ((32 * TM_ * WM_ + WG_PAD) + (32 * TN_ * WN_ + WG_PAD)) * sizeof(float);       \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_>,                          \
+            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>,                     \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
         ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, 0);                        \
-        hipLaunchKernelGGL((wgrad_kernel<TM_, TN_, BK_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), lds, st, p);                \
+        hipLaunchKernelGGL((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>), grid, dim3(64 * WM_ * WN_), lds, st, p);           \
     } while (0)
-    if (w8) {
+    if (!avec) {                                      // dY rows not 16-byte addressable: the one scalar-load variant
+        WG_LAUNCH_A(1, 1, 16, 2, 2, false);
+    } else if (w8) {
         if (BKsel == 32) WG_LAUNCH(2, 1, 32, 2, 4);
         else WG_LAUNCH(2, 1, 16, 2, 4);
     } else if (BKsel == 32) {
@@ -375,6 +384,7 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
         else WG_LAUNCH(1, 1, 16, 2, 2);
     }
 #undef WG_LAUNCH
+#undef WG_LAUNCH_A
     if (p.splits > 1) {
         const int64_t total4 = (int64_t)d->N * (p.ncols / 4);
         ZSG_PROF("wgrad_reduce_kernel", st, 0, (double)(p.splits + 1) * d->N * p.ncols * 4);
