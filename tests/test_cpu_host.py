@@ -166,7 +166,8 @@ def _reducer_worker(rank, world, port, ret):
             self.store = Store()
             self.store.flat = torch.full((16,), float(rank))
             self.store.grad = torch.zeros(16)
-            self._rm, self._rv = torch.full((4,), float(rank)), torch.full((4,), float(rank) + 1)
+            self._rmv = torch.cat([torch.full((4,), float(rank)), torch.full((4,), float(rank) + 1)])     # means | variances, one buffer
+            self._rm, self._rv = self._rmv[:4], self._rmv[4:]
             self._nbt = torch.tensor([rank])
 
         def forward(self, x):

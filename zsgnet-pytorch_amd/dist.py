@@ -116,13 +116,16 @@ class DistributedDataParallel(nn.Module):
         object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a cycle
         if self.world > 1:
             dist.broadcast(module.store.flat, src=0, group=self.group)
-            self._sync_buffers()
+            self._sync_buffers(counters=True)
 
-    def _sync_buffers(self):
+    def _sync_buffers(self, counters: bool = False):
+        """C2 of the reference's DDP (broadcast_buffers=True): rank 0's BatchNorm running statistics before every training
+        forward — all 53 layers' means and variances live in one buffer, so this is ONE broadcast (~0.2 MB).  The
+        num_batches_tracked counters advance identically on every rank; they are sent once, at wrap time."""
         m = self.module
-        dist.broadcast(m._rm, src=0, group=self.group)
-        dist.broadcast(m._rv, src=0, group=self.group)
-        dist.broadcast(m._nbt, src=0, group=self.group)
+        dist.broadcast(m._rmv, src=0, group=self.group)
+        if counters:
+            dist.broadcast(m._nbt, src=0, group=self.group)
 
     def forward(self, inp):
         if self.world > 1 and self.broadcast_buffers and self.module.training:

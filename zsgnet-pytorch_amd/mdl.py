@@ -118,8 +118,8 @@ class ZSGNet(nn.Module):
         self._declare()
         self.store.allocate(torch.device("cpu"))
         nb = sum(b.c for b in self.bns.values())
-        self._rm = torch.zeros(nb)
-        self._rv = torch.ones(nb)
+        self._rmv = torch.cat([torch.zeros(nb), torch.ones(nb)])      # running means | running variances: ONE buffer, so the
+        self._rm, self._rv = self._rmv[:nb], self._rmv[nb:]            # per-forward DDP buffer sync (C2) is one broadcast
         self._nbt = torch.zeros(len(self.bns), dtype=torch.long)
         self._register()
         self.reset_parameters()
@@ -282,7 +282,9 @@ class ZSGNet(nn.Module):
             raise TypeError("zsgnet-pytorch_amd computes in fp32 only (fp32 MFMA); dtype conversion is not supported")
         self.store.flat = flat
         self.store.grad = torch.zeros_like(flat)
-        self._rm, self._rv = fn(self._rm), fn(self._rv)
+        self._rmv = fn(self._rmv)
+        nb = self._rmv.numel() // 2
+        self._rm, self._rv = self._rmv[:nb], self._rmv[nb:]
         self._nbt = self._nbt.to(flat.device)
         self._rebind()
         return self
