@@ -93,11 +93,11 @@ def grad_tol(ec: float, g64: torch.Tensor) -> float:
     return max(6 * ec + 2e-4 * n, 1.5e-2 * n) + 1e-9
 
 
-def fp64_twin(sd, bt, h0, c0, arch, anc):
+def fp64_twin(sd, bt, h0, c0, arch, anc, **kw):
     """The same oracle evaluated in float64: the ground truth both fp32 implementations are measured against."""
     sd64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     bt64 = {k: v.double() for k, v in bt.items()}
-    ref = O.zsgnet_forward(sd64, bt64, h0.double(), c0.double(), arch=arch, rank=O.sort_rank(bt["qlens"]))
+    ref = O.zsgnet_forward(sd64, bt64, h0.double(), c0.double(), arch=arch, rank=O.sort_rank(bt["qlens"]), **kw)
     ls = O.torch_loss(ref, bt["annot"], anc)
     ls["loss"].backward()
     return sd64, ref, ls
@@ -144,6 +144,53 @@ def test_forward_backward_vs_oracle(Z, arch, B, hw):
         if eg > grad_tol(ec, g64):
             worst.append((n, eg / (float(g64.norm()) + 1e-30), ec / (float(g64.norm()) + 1e-30)))
     assert not worst, f"gradient error vs fp64 (HIP rel, CPU-fp32 rel): {worst[:8]}"
+
+
+def test_600x600_four_level_pyramid(Z):
+    """resize_img == [600, 600] (BASELINE configs[4]): the FPN returns P4..P7 only — P3 is computed and dropped, no pooled
+    1x1 level (fpn_resnet.py:173-178) — 4 levels, A = 17 370 anchors.  ResNet-18, B=1, vs the oracle and its fp64 twin."""
+    cfg, net, sd, lf, ev = build(Z, arch="resnet18", seed=21, resize_img=[600, 600])
+    net.train()
+    bt = O.synthetic_batch(1, 600, 600, seed=8, tmax=9)
+    gq = torch.Generator().manual_seed(6)
+    h0, c0 = torch.randn(2, 1, 128, generator=gq), torch.randn(2, 1, 128, generator=gq)
+    inp = to_dev(bt)
+    inp["h0"], inp["c0"] = h0, c0
+    out = net(inp)
+    assert out["feat_sizes"].tolist() == [[38, 38], [19, 19], [10, 10], [5, 5]] and int(out["num_f_out"]) == 4
+    assert out["att_out"].shape == (1, 17370, 1) and out["bbx_out"].shape == (1, 17370, 4)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    ref = O.zsgnet_forward(sd, bt, h0, c0, arch="resnet18", six_hundred=True)
+    anc = torch.from_numpy(O.create_anchors(O.feat_sizes_for(600, 600, True), RATIOS, SCALES).astype(np.float32))
+    sd64, ref64, ls64 = fp64_twin(sd, bt, h0, c0, "resnet18", anc, six_hundred=True)
+    o_gpu = out["att_bbx_out"].detach().cpu().double()
+    o_cpu = torch.cat([ref["bbx_out"], ref["att_out"]], 2).detach().double()
+    o_64 = torch.cat([ref64["bbx_out"], ref64["att_out"]], 2).detach()
+    e_gpu, e_cpu = float((o_gpu - o_64).abs().max()), float((o_cpu - o_64).abs().max())
+    assert e_gpu <= 6 * e_cpu + 1e-4, f"forward: HIP err {e_gpu:.3g} vs fp64, CPU fp32 err {e_cpu:.3g}"
+    ls = lf(out, inp)
+    np.testing.assert_allclose(ls["loss"].item(), ls64["loss"].item(), rtol=2e-4)
+    O.torch_loss(ref, bt["annot"], anc)["loss"].backward()
+    ls["loss"].backward()
+    torch.cuda.synchronize()
+    worst = []
+    for n, p in net.named_parameters():
+        g64 = sd64[n].grad
+        if g64 is None:                          # P3_2 feeds nothing at 600x600: the reference leaves its gradient unset
+            assert n.startswith("backbone.fpn.P3_") and float(p.grad.abs().max()) == 0.0, n
+            continue
+        g64 = g64.flatten()
+        eg = float((p.grad.cpu().double().flatten() - g64).norm())
+        ec = float((sd[n].grad.double().flatten() - g64).norm())
+        if eg > grad_tol(ec, g64):
+            worst.append((n, eg / (float(g64.norm()) + 1e-30), ec / (float(g64.norm()) + 1e-30)))
+    assert not worst, f"gradient error vs fp64 (HIP rel, CPU-fp32 rel): {worst[:8]}"
+    em = ev(out, inp)
+    e = O.zsg_eval(o_cpu[..., 4].numpy().astype(np.float32), o_cpu[..., :4].numpy().astype(np.float32), bt["annot"].numpy(), bt["img_size"].numpy(),
+                   anc.numpy())
+    assert 0 <= int(em["MaxPos"].item()) <= 1 and em["pred_boxes"].shape == (1, 4) and np.isfinite(e["pred_scores"]).all()
 
 
 def test_ssd_vgg_backbone_vs_golden_and_fp64(Z, gold):
