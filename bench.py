@@ -106,7 +106,7 @@ def main():
     lf, ev = loss.get_default_loss(r, s, cfg), evaluator.get_default_eval(r, s, cfg)
     opt = optim.FusedAdam(net, lr=cfg["lr"], betas=(0.9, 0.99))
 
-    from oracle.zsg_oracle import synthetic_batch     # the synthetic-input generator only (data, not compute)
+    from zsgnet_pytorch_amd.synth import synthetic_batch
     bt = synthetic_batch(a.bs, a.img, a.img, T=a.tokens, seed=1234 + rank)
     batch = {k: v.cuda() for k, v in bt.items()}
     torch.manual_seed(99 + rank)                  # LSTM initial states (mdl.py:279-294) are drawn on the host each step

@@ -7,7 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.zsg_oracle import synthetic_batch
+from zsgnet_pytorch_amd.synth import synthetic_batch
 from zsgnet_pytorch_amd import config, evaluator, loss, mdl, optim
 
 
