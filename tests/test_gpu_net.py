@@ -350,3 +350,30 @@ def test_ablation_variants_vs_reference_golden(Z, gold, tag):
             e = rel_err(got, torch.from_numpy(g[k]))
             assert e < 5e-2, f"{k}: relative error {e:.3g}"
     np.testing.assert_allclose(net.state_dict()["backbone.encoder.bn1.running_mean"].cpu().numpy(), g["rm_bn1"], rtol=1e-4, atol=1e-6)
+
+
+def test_query_length_buckets_share_one_plan(Z):
+    """The collater cuts qvec to the batch's longest query (dat_loader.py:187-196): T varies per batch.  Plans are built
+    per geometry with T bucketed (20 / 50); a shorter qvec is zero-padded into the same plan and gives the same output."""
+    cfg, net, sd, lf, ev = build(Z, arch="resnet18", seed=5)
+    net.eval()
+    bt = O.synthetic_batch(3, 96, 96, seed=12, tmax=11)
+    tmax = int(bt["qlens"].max())
+    h0, c0 = torch.zeros(2, 3, 128), torch.zeros(2, 3, 128)
+    outs = []
+    with torch.no_grad():
+        for T in (20, tmax, 15):
+            inp = to_dev({**bt, "qvec": bt["qvec"][:, :T].contiguous()})
+            inp["h0"], inp["c0"] = h0, c0
+            outs.append(net(inp)["att_bbx_out"].clone())
+    assert len(net._plans) == 1, "T = 20, 15 and the batch maximum must share one plan"
+    tol = 1e-4 * float(outs[0].abs().max())          # split-K launches use fp32 atomics: equal up to summation order
+    assert float((outs[0] - outs[1]).abs().max()) < tol and float((outs[0] - outs[2]).abs().max()) < tol
+    ref = O.zsgnet_forward(sd, bt, h0, c0, arch="resnet18", training=False)
+    o_cpu = torch.cat([ref["bbx_out"], ref["att_out"]], 2)
+    assert float((outs[1].cpu() - o_cpu).abs().max()) < 2e-3
+    with torch.no_grad():
+        long = to_dev({**bt, "qvec": torch.cat([bt["qvec"], torch.zeros(3, 17, 300)], 1)})          # T = 37 -> the 50-token bucket
+        long["h0"], long["c0"] = h0, c0
+        o37 = net(long)["att_bbx_out"]
+    assert len(net._plans) == 2 and float((o37 - outs[0]).abs().max()) < tol

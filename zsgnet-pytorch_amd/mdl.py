@@ -371,8 +371,12 @@ class ZSGNet(nn.Module):
             B, H, W, _ = img.shape
         else:
             B, _, H, W = img.shape
+        # The collater cuts qvec to the longest query of the batch (dat_loader.py:187-196), so T changes from batch to batch;
+        # a launch plan (and its buffers) is built per geometry, so T is bucketed: the plan processes T_plan >= T tokens of
+        # zero-padded input — the LSTM kernels stop at each query's own length, so the result does not depend on T_plan.
         T = qvec.shape[1]
-        plan = self._plan_for(B, H, W, T)
+        Tp = 20 if T <= 20 else (50 if T <= 50 else T)
+        plan = self._plan_for(B, H, W, Tp)
         if "h0" in inp:
             h0, c0 = inp["h0"], inp["c0"]
         else:
@@ -1112,7 +1116,11 @@ class _Plan:
         u8 = img.dtype == torch.uint8
         if not u8 and img.dtype != torch.float32:
             img = img.float()
-        self.in_qvec.view(B, self.T, net.emb_dim).copy_(qvec, non_blocking=True)
+        T = qvec.shape[1]
+        qbuf = self.in_qvec.view(B, self.T, net.emb_dim)
+        qbuf[:, :T].copy_(qvec, non_blocking=True)
+        if T < self.T:
+            qbuf[:, T:].zero_()
         self.in_qlens.copy_(qlens.reshape(B), non_blocking=True)
         nd = 2 if net.bid else 1
         self.in_h0.view(nd, B, net.lstm_dim).copy_(h0, non_blocking=True)
