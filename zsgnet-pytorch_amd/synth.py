@@ -20,20 +20,28 @@ def synthetic_batch(B: int, H: int = 300, W: int = 300, T: int = 20, seed: int =
 
 
 class SyntheticLoader:
-    """Iterable with len(): `steps` batches per epoch, deterministic per (seed, rank, epoch, step)."""
+    """Iterable with len(): `steps` batches per epoch, deterministic per (seed, rank, step); a pool of `pool` distinct
+    batches is generated once on the host and kept on the device (generating 16 x 3 x 300 x 300 uniform numbers on the CPU
+    every step costs as much as the GPU training step itself), then cycled with fresh row ids."""
 
-    def __init__(self, cfg, bs: int, steps: int, seed: int = 1234, rank: int = 0, device="cuda"):
+    def __init__(self, cfg, bs: int, steps: int, seed: int = 1234, rank: int = 0, device="cuda", pool: int = 8):
         self.cfg, self.bs, self.steps, self.seed, self.rank, self.device = cfg, bs, steps, seed, rank, device
         self.epoch = 0
+        self.pool, self._cache = pool, {}
 
     def __len__(self):
         return self.steps
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         H, W = self.cfg["resize_img"]
+        dev = torch.device(self.device if torch.cuda.is_available() else "cpu")
         for i in range(self.steps):
-            bt = synthetic_batch(self.bs, H, W, seed=self.seed + 1000003 * self.rank + 7919 * self.epoch + i, emb=self.cfg["emb_dim"])
-            bt["idxs"] += float((self.rank * self.steps + i) * self.bs)          # dataset row ids (dat_loader.py:140), unique per sample
+            k = i % self.pool
+            if k not in self._cache:
+                bt = synthetic_batch(self.bs, H, W, seed=self.seed + 1000003 * self.rank + k, emb=self.cfg["emb_dim"])
+                self._cache[k] = {n: v.to(dev) for n, v in bt.items()}
+            bt = dict(self._cache[k])
+            bt["idxs"] = bt["idxs"] + float((self.rank * self.steps + i) * self.bs)      # dataset row ids (dat_loader.py:140), unique per sample
             yield bt
         self.epoch += 1
 
