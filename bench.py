@@ -141,7 +141,8 @@ def main():
     ips = a.bs * world * a.steps / dt
 
     roof, prof_rows = None, []
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
+        # EVERY rank runs the profiled steps (they contain the data-parallel collectives); rank 0 reports its own kernels
         from zsgnet_pytorch_amd import ops as zops
 
         def profiled(nprof, side):
@@ -168,8 +169,6 @@ def main():
                                  share=e.ms / tot if tot else 0))
             rows.sort(key=lambda x: -x["ms_per_step"])
             return rows, tot / nprof
-        # as timed: weight-gradient kernels run concurrently on the side stream (what rocprofv3 of this command sees);
-        # isolated: every launch alone on the GPU (the kernel's own quality)
         # isolated: every launch alone on the GPU (one stream) — the kernel's own duration, what the roofline fraction is
         # about; as timed: with the weight-gradient kernels co-running on the side stream (the timed region's mode), where
         # kernels time-share the CUs and one kernel's duration is no longer a property of that kernel
@@ -203,7 +202,7 @@ def main():
         else:
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": traffic}
-        if a.prof_out:
+        if a.prof_out and rank == 0:
             with open(a.prof_out, "w") as f:
                 json.dump({"as_timed": prof_rows, "isolated": iso_rows}, f, indent=1)
     cpu = None
