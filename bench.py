@@ -82,11 +82,12 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    local = local % max(1, torch.cuda.device_count())      # (a 1-GPU box can host a 2-rank gloo dry run of the N > 1 control flow)
     torch.cuda.set_device(local)
     from zsgnet_pytorch_amd import config, dist as zdist, evaluator, loss, mdl, optim
     from zsgnet_pytorch_amd._lib import ProfEntry, lib
     if world > 1:
-        zdist.init_process_group_from_env("nccl")
+        zdist.init_process_group_from_env(os.environ.get("ZSG_DIST_BACKEND", "nccl"))       # nccl = RCCL over xGMI
     elif a.force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -1,0 +1,84 @@
+"""Two data-parallel ranks sharing ONE GPU over gloo (RCCL refuses two ranks per device; the code path above the
+collective is the same): the bucketed reducer inside the real backward must leave every rank with the MEAN of the
+per-rank gradients, the parameters / BatchNorm buffers must follow rank 0, and nothing may deadlock."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads_single(seed_batch, sd, cfg_kw):
+    """reference: one process, one rank's batch, no DDP"""
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import config, loss, mdl
+    cfg = config.get_cfg(**cfg_kw)
+    net = mdl.get_default_net(9, cfg)
+    net.load_state_dict(sd)
+    net.to("cuda").train()
+    r, s = config.ratios_scales(cfg)
+    lf = loss.get_default_loss(r, s, cfg)
+    bt = {k: v.cuda() for k, v in O.synthetic_batch(2, 96, 96, seed=seed_batch).items()}
+    bt["h0"], bt["c0"] = torch.zeros(2, 2, 128), torch.zeros(2, 2, 128)
+    lf(net(bt), bt)["loss"].backward()
+    torch.cuda.synchronize()
+    return net.store.grad.clone().cpu()
+
+
+def _worker(rank, world, port, cfg_kw, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import config, dist as zdist, loss, mdl, optim
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = config.get_cfg(**cfg_kw)
+    net = mdl.get_default_net(9, cfg)
+    net.load_state_dict(O.seeded_state_dict("resnet18", 40 + rank))          # ranks start DIFFERENT: C3 must make them rank 0's
+    net.to("cuda").train()
+    ddp = zdist.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=True, bucket_mb=4.0)
+    r, s = config.ratios_scales(cfg)
+    lf = loss.get_default_loss(r, s, cfg)
+    opt = optim.FusedAdam(net, lr=1e-3)
+    bt = {k: v.cuda() for k, v in O.synthetic_batch(2, 96, 96, seed=70 + rank).items()}
+    bt["h0"], bt["c0"] = torch.zeros(2, 2, 128), torch.zeros(2, 2, 128)
+    opt.zero_grad()
+    lf(ddp(bt), bt)["loss"].backward()
+    torch.cuda.synchronize()
+    g1 = net.store.grad.clone().cpu()
+    nb = len(net._plans[list(net._plans)[0]].reducer.buckets)
+    opt.step()
+    opt.zero_grad()
+    lf(ddp(bt), bt)["loss"].backward()                                         # a second step: reducer / plan reuse
+    torch.cuda.synchronize()
+    torch.save(dict(g1=g1, w=net.store.flat.clone().cpu(), rm=net._rm.clone().cpu(), nb=nb), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_on_one_gpu(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import zsg_oracle as O
+    cfg_kw = dict(resnet_arch="resnet18")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29613, cfg_kw, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, "a rank failed or hung"
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert a["nb"] >= 3, "the flat gradient buffer should be reduced in several buckets"
+    assert torch.equal(a["g1"], b["g1"]), "both ranks must hold the same reduced gradients"
+    assert torch.equal(a["w"], b["w"]), "parameters must stay identical across ranks"
+    # (running statistics are per-GPU between syncs, as in the reference: rank 0's are broadcast at the START of a forward)
+    assert not torch.equal(a["rm"], b["rm"])
+    # the reduced gradient is the mean of the two single-rank gradients computed from rank 0's initial weights
+    sd0 = O.seeded_state_dict("resnet18", 40)
+    ref = 0.5 * (_grads_single(70, sd0, cfg_kw) + _grads_single(71, sd0, cfg_kw))
+    err = float((a["g1"].double() - ref.double()).norm() / ref.double().norm())
+    assert err < 2e-3, f"reduced gradient differs from the mean of the per-rank gradients: rel {err:.3g}"

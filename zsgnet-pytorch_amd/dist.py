@@ -44,7 +44,7 @@ def init_process_group_from_env(backend: Optional[str] = None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     dist.init_process_group(backend=backend, init_method="env://")
 
 
