@@ -132,6 +132,11 @@ def test_plan_buckets_cover_flat_buffer_in_readiness_order():
     assert sorted((x.start, x.end) for x in b) == [(0, 160), (160, 560), (560, 608)]
     assert [x.ready for x in b] == sorted(x.ready for x in b)
     assert {(x.start, x.end): x.ready for x in b}[(0, 160)] == 90
+    # the bucket that completes last is split so that only a small all-reduce is exposed at the end of backward
+    enc = [(i * 100, 100, 50 - i) for i in range(12)]            # forward order: the first parameter is written last
+    b = plan_buckets(enc, 600, tail_elems=150)
+    assert sorted((x.start, x.end) for x in b) == [(0, 200), (200, 600), (600, 1200)] and b[-1].start == 0 and b[-1].ready == 50
+    assert sum(x.end - x.start for x in b) == 1200 and [x.ready for x in b] == sorted(x.ready for x in b)
 
 
 def _free_port():

@@ -55,23 +55,31 @@ class Bucket:
     ready: int          # index of the last backward launch that writes into the range (-1: nothing writes)
 
 
-def plan_buckets(spans: Sequence[Tuple[int, int, int]], target_elems: int) -> List[Bucket]:
-    """spans: (offset, size, ready_index) per parameter in flat order.  Adjacent parameters are merged while they
-    become ready together (their ready indices are within the same backward phase) up to ~target_elems; the result
-    covers the flat buffer exactly once and is sorted by readiness so buckets are launched in completion order."""
-    buckets: List[Bucket] = []
-    cur: Optional[Bucket] = None
-    for off, size, ready in sorted(spans):
-        if cur is not None and cur.end == off and (cur.end - cur.start) < target_elems:
-            cur.end = off + size
-            cur.ready = max(cur.ready, ready)
+def plan_buckets(spans: Sequence[Tuple[int, int, int]], target_elems: int, tail_elems: Optional[int] = None) -> List[Bucket]:
+    """spans: (offset, size, ready_index) per parameter in flat order.  Adjacent parameters are merged up to
+    ~target_elems; the result covers the flat buffer exactly once and is sorted by readiness so buckets are launched in
+    completion order.  tail_elems: the bucket that completes LAST (it holds the first layers of the network, whose
+    gradients are written at the very end of backward) cannot overlap with anything, so its latest part is split off
+    into a small bucket of ~tail_elems and only that small all-reduce is exposed."""
+    groups: List[List[Tuple[int, int, int]]] = []
+    for sp in sorted(spans):
+        if groups and groups[-1][-1][0] + groups[-1][-1][1] == sp[0] and sum(x[1] for x in groups[-1]) < target_elems:
+            groups[-1].append(sp)
         else:
-            if cur is not None:
-                buckets.append(cur)
-            cur = Bucket(off, off + size, ready)
-    if cur is not None:
-        buckets.append(cur)
-    return sorted(buckets, key=lambda b: b.ready)
+            groups.append([sp])
+    if tail_elems:
+        gi = max(range(len(groups)), key=lambda i: max(x[2] for x in groups[i]))
+        g = groups[gi]
+        if sum(x[1] for x in g) > 2 * tail_elems and len(g) > 1:
+            k = max(range(len(g)), key=lambda i: g[i][2])           # the parameter written last
+            j, acc = k, 0
+            while j < len(g) and acc < tail_elems:
+                acc += g[j][1]
+                j += 1
+            pieces = [p for p in (g[:k], g[k:j], g[j:]) if p]
+            groups[gi:gi + 1] = pieces
+    buckets = [Bucket(g[0][0], g[-1][0] + g[-1][1], max(x[2] for x in g)) for g in groups]
+    return sorted(buckets, key=lambda b: (b.ready, b.start))
 
 
 class BucketReducer:
@@ -106,12 +114,13 @@ class DistributedDataParallel(nn.Module):
     reducer during backward (C1)."""
 
     def __init__(self, module: nn.Module, device_ids=None, output_device=None, broadcast_buffers: bool = True,
-                 find_unused_parameters: bool = False, bucket_mb: float = 32.0, process_group=None):
+                 find_unused_parameters: bool = False, bucket_mb: float = 32.0, process_group=None, tail_bucket_mb: float = 4.0):
         super().__init__()
         self.module = module
         self.broadcast_buffers = broadcast_buffers
         self.group = process_group
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.tail_elems = int(tail_bucket_mb * (1 << 20) / 4)
         self.world = get_world_size()
         object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a cycle
         if self.world > 1:
@@ -133,7 +142,7 @@ class DistributedDataParallel(nn.Module):
         return self.module(inp)
 
     def make_reducer(self, spans) -> BucketReducer:
-        return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems), self.group)
+        return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems, self.tail_elems), self.group)
 
 
 def reduce_dict(input_dict, average=False):
