@@ -64,8 +64,13 @@ def test_two_rank_gradient_average_on_one_gpu(tmp_path):
         pytest.skip("no GPU")
     from oracle import zsg_oracle as O
     cfg_kw = dict(resnet_arch="resnet18")
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29613, cfg_kw, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_kw, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
