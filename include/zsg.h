@@ -124,6 +124,12 @@ int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* in
                  float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
 int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
                                float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* eval mode, folded: every (conv, BatchNorm) pair of the job list gets W*s and (beta - mean*s), s = gamma/sqrt(var+eps)
+ * per output channel, written to `arena` in ONE launch; the plan then runs conv(+bias, +residual, ReLU) without any
+ * BatchNorm launch.  jobs: device array of { int64 w_off, dst_off, gamma_off, beta_off, bias_off; int32 row0, N, row_len,
+ * bn_index } (element offsets into flat / arena; rows are OHWI output channels, row_len % 4 == 0). */
+int zsg_bn_fold(const float* flat, const float* running_mean, const float* running_var, float eps, const void* jobs,
+                int32_t njobs, int32_t total_rows, float* arena, void* stream);
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
 int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                       float* invstd, void* stream);

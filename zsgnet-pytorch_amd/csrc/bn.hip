@@ -243,6 +243,41 @@ extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks,
     return 0;
 }
 
+// ---- eval mode: fold BatchNorm into the convolution that feeds it ------------------------------------------------------
+// y = gamma*(conv(x,W) - mean)/sqrt(var+eps) + beta  ==  conv(x, W*s) + (beta - mean*s),  s = gamma/sqrt(var+eps) per
+// output channel.  One launch rescales every folded weight row (OHWI: a row = one output channel) into an arena and
+// writes the folded biases; the eval plan then runs conv(+bias, +residual, ReLU) with no BatchNorm launch at all.
+struct ZsgFoldJob {
+    int64_t w_off, dst_off, gamma_off, beta_off, bias_off;   // element offsets: flat parameters / arena
+    int32_t row0, N, row_len, bn_index;                      // first global row, rows (= cout), floats per row, slot in rm / rv
+};
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ flat, const float* __restrict__ rmean,
+                                                      const float* __restrict__ rvar, float eps, const ZsgFoldJob* __restrict__ jobs,
+                                                      int njobs, float* __restrict__ arena) {
+    int lo = 0, hi = njobs - 1;                      // last job whose row0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].row0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ZsgFoldJob jb = jobs[lo];
+    const int n = blockIdx.x - jb.row0;
+    const float sc = flat[jb.gamma_off + n] / sqrtf(rvar[jb.bn_index + n] + eps);
+    const float* src = flat + jb.w_off + (int64_t)n * jb.row_len;
+    float* dst = arena + jb.dst_off + (int64_t)n * jb.row_len;
+    for (int i = threadIdx.x * 4; i < jb.row_len; i += 1024) *(f32x4*)(dst + i) = *(const f32x4*)(src + i) * sc;
+    if (threadIdx.x == 0) arena[jb.bias_off + n] = flat[jb.beta_off + n] - rmean[jb.bn_index + n] * sc;
+}
+extern "C" int zsg_bn_fold(const float* flat, const float* running_mean, const float* running_var, float eps, const void* jobs,
+                           int32_t njobs, int32_t total_rows, float* arena, void* stream) {
+    ZSG_REQUIRE(flat && running_mean && running_var && jobs && arena && njobs > 0 && total_rows > 0, "bn_fold: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_fold", st, 0, 0);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(total_rows), dim3(256), 0, st, flat, running_mean, running_var, eps, (const ZsgFoldJob*)jobs, njobs,
+                       arena);
+    ZSG_CHECK_LAUNCH("bn_fold");
+    return 0;
+}
+
 extern "C" int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                                  float* invstd, void* stream) {
     ZSG_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "bn_eval_stats: bad argument");

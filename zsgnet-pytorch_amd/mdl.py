@@ -420,9 +420,15 @@ class _Plan:
         self.reducer = None
         self.wt_jobs, self.wt_arena_used = [], 0
         self.wt_arena = self._buf(net.store.total + 4096 * len(net.convs)) if training else None
+        self.fold_jobs, self.fold_used, self.fold_rows = [], 0, 0          # eval: BatchNorm folded into the convolutions
+        self.fold_arena = self._buf(net.store.total + 8 * len(net.convs)) if (not training and net.bns) else None
         self._lower()
         if training:
             self._finish_prep()
+        elif self.fold_jobs:
+            import struct
+            blob = b"".join(struct.pack("<qqqqqiiii", *j) for j in self.fold_jobs)
+            self.fold_jobs_dev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.dev)
 
     # ---- allocation helpers --------------------------------------------------------------------------------
     def _buf(self, n, dtype=torch.float32):
@@ -502,6 +508,32 @@ class _Plan:
                          what="stats:" + Lb.name)
         out.needs_mask = relu
         self.tape.append(lambda: self._conv_bwd(L, src, out))
+        return out
+
+    def conv_bn(self, L: ConvL, Lb: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, yname=None) -> Act:
+        """conv -> BatchNorm [-> + residual] [-> ReLU].  Training: the two lowered ops (batch statistics from the conv
+        epilogue).  Eval: ONE convolution with the BatchNorm folded into its weights / bias (zsg_bn_fold refreshes the
+        folded copies at the start of every eval forward), residual add and ReLU in its epilogue."""
+        if self.training:
+            y = self.conv(L, x, name=yname or (L.name + ".y"), bn_fuse=Lb)
+            return self.bn(Lb, y, relu, residual=residual, name=name)
+        net = self.net
+        n_w = L.cout * L.k * L.k * L.cpad
+        w_off = self.fold_used
+        b_off = w_off + (n_w + 3) // 4 * 4
+        self.fold_used = b_off + (L.cout + 3) // 4 * 4
+        assert self.fold_used <= self.fold_arena.numel(), "BN-fold arena too small"
+        ents = net.store.entries
+        self.fold_jobs.append((ents[L.name + ".weight"].offset, w_off, ents[Lb.name + ".weight"].offset, ents[Lb.name + ".bias"].offset,
+                               b_off, self.fold_rows, L.cout, L.k * L.k * L.cpad, Lb.index))
+        self.fold_rows += L.cout
+        lv = x.levels[0]
+        out = self.act(name or Lb.name, x.B, conv_out(lv.H, L.k, L.stride, L.pad, L.dil), conv_out(lv.W, L.k, L.stride, L.pad, L.dil), L.cout)
+        d = fwd_desc(x, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
+        wt, bias = self.fold_arena[w_off:w_off + n_w], self.fold_arena[b_off:b_off + L.cout]
+        args = (x.buf, wt, out.buf, bias, residual.buf if residual is not None else None, None, None)
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr())
+        self.fwd.add(lib.zsg_conv_igemm, d, *args, what=L.name + "+bn")
         return out
 
     def _wt(self, L: ConvL, cred: int) -> torch.Tensor:
@@ -657,8 +689,7 @@ class _Plan:
         if net.backbone_kind == "ssd_vgg":
             feats = self._lower_ssd(x0)
         else:
-            y = self.conv(C[e + "conv1"], x0, name="stem.y", bn_fuse=BN[e + "bn1"])
-            a = self.bn(BN[e + "bn1"], y, relu=True, name="stem.a")
+            a = self.conv_bn(C[e + "conv1"], BN[e + "bn1"], x0, True, name="stem.a", yname="stem.y")
             H2, W2 = conv_out(H1, 3, 2, 1), conv_out(W1, 3, 2, 1)
             x = self.act("pool", B, H2, W2, 64)
             idx = self._buf((B * H2 * W2 * 64 + 3) // 4)      # uint8 indices, stored in a float-sized buffer
@@ -790,23 +821,20 @@ class _Plan:
     def _lower_block(self, blk, x: Act) -> Act:
         net = self.net
         C, BN, q = net.convs, net.bns, blk["prefix"]
+        def shortcut():
+            return self.conv_bn(C[q + "downsample.0"], BN[q + "downsample.1"], x, False, name=q + "rd", yname=q + "yd") if blk["ds"] else x
         if net.block_kind == "bottleneck":
-            y1 = self.conv(C[q + "conv1"], x, name=q + "y1", bn_fuse=BN[q + "bn1"])
-            a1 = self.bn(BN[q + "bn1"], y1, True, name=q + "a1")
+            a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
+            a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2")
+            if self.training:        # (the shortcut is lowered between conv3 and bn3, as in the first builds of this round)
+                y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
+                return self.bn(BN[q + "bn3"], y3, True, residual=shortcut(), name=q + "out")
+            return self.conv_bn(C[q + "conv3"], BN[q + "bn3"], a2, True, residual=shortcut(), name=q + "out", yname=q + "y3")
+        a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
+        if self.training:
             y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
-            a2 = self.bn(BN[q + "bn2"], y2, True, name=q + "a2")
-            y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
-            last_bn, last_y = BN[q + "bn3"], y3
-        else:
-            y1 = self.conv(C[q + "conv1"], x, name=q + "y1", bn_fuse=BN[q + "bn1"])
-            a1 = self.bn(BN[q + "bn1"], y1, True, name=q + "a1")
-            y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
-            last_bn, last_y = BN[q + "bn2"], y2
-        res = x
-        if blk["ds"]:
-            yd = self.conv(C[q + "downsample.0"], x, name=q + "yd", bn_fuse=BN[q + "downsample.1"])
-            res = self.bn(BN[q + "downsample.1"], yd, False, name=q + "rd")
-        return self.bn(last_bn, last_y, True, residual=res, name=q + "out")
+            return self.bn(BN[q + "bn2"], y2, True, residual=shortcut(), name=q + "out")
+        return self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, residual=shortcut(), name=q + "out", yname=q + "y2")
 
     def _pyramid(self, sizes) -> List[Act]:
         """The head's input features: all pyramid levels packed level-major in ONE buffer (so every head convolution is
@@ -1133,6 +1161,9 @@ class _Plan:
         if self.training:
             net._nbt.add_(1)
         assert self.img_slot == 0
+        if not self.training and self.fold_jobs:       # the weights may have changed since the last eval forward: refold (one launch)
+            check(lib.zsg_bn_fold(net.store.flat.data_ptr(), net._rm.data_ptr(), net._rv.data_ptr(), 1e-5, self.fold_jobs_dev.data_ptr(),
+                                  len(self.fold_jobs), self.fold_rows, self.fold_arena.data_ptr(), stream_ptr()), "bn_fold")
         if u8:
             check(lib.zsg_u8hwc_to_nhwc4(img.data_ptr(), B * self.H * self.W, self.fwd.calls[self.img_slot][1][5], stream_ptr()), "u8hwc_to_nhwc4")
         else:
