@@ -393,6 +393,49 @@ def test_batchnorm(Z, rows, Cc):
     assert_close(invstd, 1 / torch.sqrt(rvd.cpu() + 1e-5), 1e-6, 0, "eval invstd")
 
 
+def test_bn_fold_eval(Z):
+    """eval-mode conv + BatchNorm == conv with W*s, bias beta - mean*s (s = gamma / sqrt(var + eps)); rel 1e-6 on the
+    folded parameters (one multiply each), conv output vs F.batch_norm(F.conv2d) rel 2e-4."""
+    import struct
+    L, ops = Z
+    g = torch.Generator().manual_seed(3)
+    specs = [(8, 3, 12), (16, 1, 64)]                      # (cout, k, cin padded to 4)
+    flat, jobs, row0, arena_used = [], [], 0, 0
+    nb = sum(c for c, _, _ in specs)
+    rm, rv = torch.randn(nb, generator=g), torch.rand(nb, generator=g) + 0.5
+    bn_i, off = 0, 0
+    layers = []
+    for co, k, ci in specs:
+        w = torch.randn(co, k, k, ci, generator=g)
+        gam, bet = torch.randn(co, generator=g), torch.randn(co, generator=g)
+        w_off, g_off, b_off = off, off + w.numel(), off + w.numel() + co
+        flat += [w.reshape(-1), gam, bet]
+        off = b_off + co
+        dst, bias_dst = arena_used, arena_used + w.numel()
+        arena_used = bias_dst + co
+        jobs.append(struct.pack("<qqqqqiiii", w_off, dst, g_off, b_off, bias_dst, row0, co, k * k * ci, bn_i))
+        layers.append((w, gam, bet, bn_i, dst, bias_dst, co, k, ci))
+        row0 += co
+        bn_i += co
+    flatd = dev(torch.cat(flat))
+    jd = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8).cuda()
+    arena = torch.full((arena_used,), float("nan"), device="cuda")
+    rmd, rvd = dev(rm), dev(rv)
+    L.check(L.lib.zsg_bn_fold(flatd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, jd.data_ptr(), len(jobs), row0, arena.data_ptr(), L.stream_ptr()),
+            "bn_fold")
+    a = arena.cpu()
+    assert not torch.isnan(a).any()
+    for w, gam, bet, bi, dst, bias_dst, co, k, ci in layers:
+        sc = gam / torch.sqrt(rv[bi:bi + co] + 1e-5)
+        assert_close(a[dst:dst + w.numel()].view_as(w), w * sc.view(-1, 1, 1, 1), 1e-6, 1e-7, "folded weights")
+        assert_close(a[bias_dst:bias_dst + co], bet - rm[bi:bi + co] * sc, 1e-6, 1e-6, "folded bias")
+    w, gam, bet, bi, dst, bias_dst, co, k, ci = layers[0]
+    x = torch.randn(2, ci, 9, 9, generator=g)
+    ref = F.batch_norm(F.conv2d(x, w.permute(0, 3, 1, 2), None, 1, 1), rm[bi:bi + co], rv[bi:bi + co], gam, bet, False, 0.1, 1e-5)
+    got = F.conv2d(x, a[dst:dst + w.numel()].view_as(w).permute(0, 3, 1, 2), a[bias_dst:bias_dst + co], 1, 1)
+    assert_close(got, ref, 2e-4, 2e-4, "folded conv == conv + eval BatchNorm")
+
+
 @pytest.mark.parametrize("k,s,p,ceil,H,W", [(3, 2, 1, False, 37, 40), (2, 2, 0, False, 30, 30), (2, 2, 0, True, 15, 19), (3, 1, 1, False, 9, 9)])
 def test_maxpool(Z, k, s, p, ceil, H, W):
     L, _ = Z
