@@ -35,8 +35,8 @@ PEAK_TF = 157.3                                                         # fp32-i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bs", type=int, default=16, help="per-GPU batch (configs[1]: 16)")
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--backbone", default="retina", choices=["retina", "ssd_vgg"], help="retina = ResNet(--arch)+FPN; ssd_vgg = config 4")
