@@ -490,7 +490,13 @@ class _Plan:
                            conv_out(lv[0].W, L.k, L.stride, L.pad, L.dil), L.cout)
         d = fwd_desc(src, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
         bias = self.P(L.name + ".bias") if L.bias else None
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, None), stream_ptr())
+        # a split-K choice would cost this layer its fused BatchNorm statistics: a statistics pass over the output at
+        # ~4 TB/s plus two more dependent launches
+        pen = 0.0
+        if bn_fuse is not None and self.training and not L.bias and not relu:
+            pen = 0.008 + out.rows() * L.cout * 4 / 4e9
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, None), stream_ptr(),
+                      split_penalty_ms=pen)
         partials = None
         out.bn_chunks = 0
         if bn_fuse is not None and self.training and d.tile_hint and ((d.tile_hint >> 16) & 0xff) <= 1 and not L.bias and not relu:

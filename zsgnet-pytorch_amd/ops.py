@@ -341,13 +341,15 @@ def _time_launch(fn, args, stream, reps=5):
     return a.elapsed_time(b) / reps
 
 
-def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0) -> int:
+def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0, split_penalty_ms: float = 0.0) -> int:
     """Pick d.tile_hint for `fn(d, *args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the real
-    buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic."""
+    buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic.
+    split_penalty_ms: what a split-K choice costs elsewhere (a convolution feeding BatchNorm loses the statistics fused
+    in its epilogue: a separate statistics pass + finalize launch), added to the measured time of split candidates."""
     if os.environ.get("ZSG_AUTOTUNE", "1") == "0" or not torch.cuda.is_available():
         return 0
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
-    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2]))
+    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0))
     if key in _TUNE_CACHE:
         d.tile_hint = _TUNE_CACHE[key]
         return d.tile_hint
@@ -390,6 +392,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     for h in cands:
         d.tile_hint = h
         t = _time_launch(fn, conv, stream)
+        if kind == "igemm" and ((h >> 16) & 0xff) > 1:
+            t += split_penalty_ms
         if t < best_t:
             best, best_t = h, t
     d.tile_hint = best
