@@ -176,8 +176,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
 
     // lane (li, lh): MFMA sub-tile t covers rows m = wm*32*TM + 32*t + li (and columns likewise): contiguous runs of 32,
     // so the epilogue's stores are 128-byte coalesced.
-    const int am = wm * (32 * TM) + li;
-    const int bn = wn * (32 * TN) + li;
+    // MFMA sub-tile t of a wave covers rows m = TM*li + t (columns likewise): a lane's TM (TN) operands are CONSECUTIVE in the
+    // [k][m] LDS tile, so one LDS instruction (ds_read2_b32 / b64) fetches both from adjacent banks.
+    const int am = wm * (32 * TM) + TM * li;
+    const int bn = wn * (32 * TN) + TN * li;
     auto k_step = [&](int it, f32x4 (&cur_a)[NA], f32x4 (&cur_b)[NB], f32x4 (&nxt_a)[NA], f32x4 (&nxt_b)[NB]) {
         const int buf = it & 1;
         load_tile(nxt_a, nxt_b, it + 2 < n_kt);
@@ -187,9 +189,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
             const int k = 2 * kk + lh;
             float fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = As[buf][k][am + 32 * i];
+            for (int i = 0; i < TM; ++i) fa[i] = As[buf][k][am + i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][k][bn + 32 * j];
+            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][k][bn + j];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     // ---- epilogue: D[i][j] -> (n = output channel, q = logical weight column) -------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int qc = n0 + wn * (32 * TN) + 32 * j + li;
+        const int qc = n0 + wn * (32 * TN) + TN * li + j;
         const bool cok = qc < p.ncols;
         size_t coff;
         if (p.ws) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int n = m0 + wm * (32 * TM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int n = m0 + wm * (32 * TM) + TM * ((e & 3) + 8 * (e >> 2) + 4 * lh) + i;
                 if (cok && n < p.N) {
                     float* o = dst + (size_t)n * ld + coff;
                     *o = (!p.ws && p.accumulate) ? *o + acc[i][j][e] : acc[i][j][e];
