@@ -326,7 +326,7 @@ def _sig(kind, d: ConvDesc, extra) -> tuple:
     return (kind, d.B, d.C, d.N, d.src_ld, d.out_ld, d.wR, d.wC, d.wt_ld, d.relu, d.merge_x, segs, extra)
 
 
-def _time_launch(fn, args, stream, reps=5):
+def _time_launch(fn, args, stream, reps=10):
     st = C.c_void_p(stream)
     for _ in range(2):
         rc = fn(*args, st)
