@@ -2,7 +2,7 @@
 B=8): exercises the tile variants the autotuner picks for large launches.  Head gradients agree to ~1e-6; the
 difference grows with depth through the train-mode BatchNorm stack (fp32 vs fp32, see tests/test_gpu_net.py)."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import zsg_oracle as O
 from zsgnet_pytorch_amd import config, loss, mdl
 B = 8
