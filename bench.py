@@ -50,7 +50,7 @@ def parse():
 
 
 def cpu_baseline(arch, img, tokens):
-    """The oracle's training step on the host cores (kind 'port'): B=4, 1 warm-up + 3 timed steps (~10-20 s)."""
+    """The oracle's training step on the host cores (kind 'port'): B=4, 2 warm-up + 5 timed steps (~20 s)."""
     import numpy as np
     from oracle import zsg_oracle as O
     B = 4
@@ -62,14 +62,14 @@ def cpu_baseline(arch, img, tokens):
     r, s = O.default_ratios_scales()
     anc = torch.from_numpy(O.create_anchors(O.feat_sizes_for(img, img), r, s).astype(np.float32))
     times = []
-    for it in range(4):
+    for it in range(7):
         h0, c0 = torch.randn(2, B, 128), torch.randn(2, B, 128)
         t0 = time.perf_counter()
         O.cpu_train_step(params, buffers, opt, bt, h0, c0, anc, arch=arch)
         times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[1]
+    med = sorted(times[2:])[2]
     return {"value": round(B / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle.cpu_train_step, {arch} {img}x{img}, B={B}, 1 warm-up + 3 timed steps, median {med:.3f} s/step"}
+            "sample": f"oracle.cpu_train_step, {arch} {img}x{img}, B={B}, 2 warm-up + 5 timed steps, median {med:.3f} s/step"}
 
 
 def main():
