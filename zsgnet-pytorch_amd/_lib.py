@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: single libamdhip64 in the process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzsg.so")
+LIB_PATH = os.environ.get("ZSG_LIB_PATH") or os.path.join(_HERE, "libzsg.so")      # (override: A/B two builds inside one GPU allocation)
 ZSG_MAX_SEG = 8
 
 
