@@ -98,6 +98,25 @@ size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Winograd F(2x2,3x3) convolution on fp32 MFMA: the 3x3 / stride 1 / pad 1 convolutions (forward and data gradient)
+ * of the same call sites as zsg_conv_igemm — fpn_resnet.py:73-74,92-94 (Bottleneck.conv2), :141-152 (P*_2),
+ * mdl.py:211-219 (the shared head) — at 4 instead of 9 multiply-adds per (pixel, cin, cout), still fp32 throughout
+ * (what cuDNN's fp32 path runs for the reference; tolerances in tests/test_gpu_ops.py).  Same descriptor, epilogue
+ * terms and bn_partials contract as zsg_conv_igemm; `U` is the transformed filter image made by zsg_wino_weights.
+ * tile_hint = tiles_per_block | (BN << 8) | (split_k << 16), both tile sizes in {32, 64}; bn_partials rows =
+ * sum over segments of ceil(B * ceil(H/2) * ceil(W/2) / tiles_per_block).
+ * ------------------------------------------------------------------------------------------------------------- */
+int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
+                  const float* add_src, const float* mask_src, float* bn_partials, void* stream);
+/* elements of the transformed image of a C -> N 3x3 filter: [ceil(C/8)][16][roundup(N,64)][8] */
+int64_t zsg_wino_u_elems(int32_t C, int32_t N);
+/* U = G g G^T for every job in ONE launch.  jobs: device array of { int64 src, dst (absolute device addresses);
+ * int32 N, C, src_row_ld, src_tap_ld, flip, Npad, chunks, blk0 }: source element (n, tap, c) at n*src_row_ld +
+ * tap*src_tap_ld + c (an OHWI weight or a channel window of it; or a zsg_transpose_w image with flip = 1: the filter
+ * rotated by 180 degrees, for the data gradient); blk0 = running sum of ceil(chunks*Npad*8 / 256). */
+int zsg_wino_weights(const void* jobs, int32_t njobs, int32_t total_blocks, void* stream);
+
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */
 int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t dst_ld, void* stream);

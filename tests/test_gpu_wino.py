@@ -1,0 +1,131 @@
+"""GPU parity of the Winograd F(2x2,3x3) convolution (zsg_conv_wino + zsg_wino_weights, called through the C ABI)
+against torch-CPU fp32 conv2d.  Tolerance: rel 3e-4 / abs 3e-4 of the output scale — fp32 throughout; the transforms
+add a handful of roundings per output (constants 0, +-1, +-1/2), same class as the direct kernel's 2e-4."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_ops import Z, assert_close, dev, nhwc, ohwi, pad4, view_of  # noqa: E402,F401
+
+
+def make_u(L, ops, wd, N, Cred, row_ld, tap_ld, flip, wc0=0):
+    U = torch.full((int(L.lib.zsg_wino_u_elems(Cred, N)),), float("nan"), device="cuda")
+    jobs = ops.WinoJobs()
+    jobs.add(wd.data_ptr() + 4 * wc0, U.data_ptr(), N, Cred, row_ld, tap_ld, flip)
+    jobs.finish("cuda")
+    jobs.launch(L.stream_ptr())
+    return U
+
+
+WINO_CASES = [
+    # B, Ci, Co, H, W, bias, relu, TB, BN, splits
+    (2, 64, 64, 19, 19, False, False, 64, 64, 1),
+    (2, 64, 128, 20, 17, True, True, 64, 64, 1),
+    (3, 128, 64, 7, 10, False, False, 32, 64, 1),
+    (2, 48, 256, 10, 10, True, False, 64, 32, 1),
+    (2, 256, 45, 10, 10, True, False, 64, 64, 1),
+    (1, 516, 256, 5, 5, True, True, 32, 32, 1),
+    (2, 256, 256, 1, 1, True, True, 32, 32, 1),
+    (2, 128, 128, 9, 9, False, False, 32, 32, 3),
+    (2, 512, 96, 10, 10, True, False, 64, 64, 4),
+    (16, 64, 64, 38, 38, False, False, 64, 64, 1),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[f"w{i}" for i in range(len(WINO_CASES))])
+def test_wino_fwd_dgrad(Z, case):
+    L, ops = Z
+    B, Ci, Co, H, W, bias, relu, TB, BN, splits = case
+    g = torch.Generator().manual_seed(7 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone()
+    y_ref = F.conv2d(xr, wr, b, 1, 1)
+    if relu:
+        y_ref = F.relu(y_ref)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    cp = pad4(Ci)
+    st = L.stream_ptr()
+    hint = TB | (BN << 8) | (splits << 16)
+    xd, wd = dev(nhwc(x)), dev(ohwi(w))
+    U = make_u(L, ops, wd, Co, cp, 9 * cp, cp, False)
+    out = torch.full((B, H, W, Co), float("nan"), device="cuda")
+    src, ov = view_of(ops, xd, B, H, W, cp), view_of(ops, out, B, H, W, Co)
+    desc = ops.fwd_desc(src, ov, cp, Co, 3, 1, 1, 1, wC=cp, relu=relu and splits == 1, tile_hint=hint)
+    bd = dev(b) if bias else None
+    L.check(L.lib.zsg_conv_wino(C.byref(desc), xd.data_ptr(), U.data_ptr(), out.data_ptr(), bd.data_ptr() if bias else None, None,
+                                None, None, st), "wino")
+    got = F.relu(out) if (relu and splits > 1) else out
+    assert_close(got.permute(0, 3, 1, 2), y_ref, 3e-4, 3e-4, "wino fwd")
+    if not bias and not relu and splits == 1 and Co % 4 == 0:
+        tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+        chunks = (tiles + TB - 1) // TB
+        part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
+        L.check(L.lib.zsg_conv_wino(C.byref(desc), xd.data_ptr(), U.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "wino+stats")
+        yf = y_ref.detach().permute(0, 2, 3, 1).reshape(-1, Co).double()
+        assert_close(part[:, 0].double().sum(0), yf.sum(0), 1e-4, 1e-4 * float(yf.abs().sum(0).max()), "bn partial sums")
+        assert_close(part[:, 1].double().sum(0), (yf * yf).sum(0), 2e-4, 1e-6, "bn partial sums of squares")
+    # data gradient: the same kernel on dy with the rotated, transposed filter image
+    gpre = gy * (y_ref > 0) if relu else gy
+    Cop = pad4(Co)
+    dyd = dev(nhwc(gpre, Cop))
+    dyv = view_of(ops, dyd, B, H, W, Cop)
+    wt = torch.full((cp, 3, 3, Cop), float("nan"), device="cuda")
+    L.check(L.lib.zsg_transpose_w(wd.data_ptr(), wt.data_ptr(), Co, 9, cp, Cop, st), "transpose_w")
+    Ut = make_u(L, ops, wt, cp, Cop, 9 * Cop, Cop, True)
+    dx = torch.full((B, H, W, cp), float("nan"), device="cuda")
+    dxv = view_of(ops, dx, B, H, W, cp)
+    ddesc = ops.dgrad_desc(dyv, dxv, Cop, cp, 3, 1, 1, 1, tile_hint=hint)
+    L.check(L.lib.zsg_conv_wino(C.byref(ddesc), dyd.data_ptr(), Ut.data_ptr(), dx.data_ptr(), None, None, None, None, st), "wino dgrad")
+    assert_close(dx[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), "wino dgrad")
+    if cp > Ci:
+        assert float(dx[..., Ci:].abs().max()) == 0.0
+    # accumulate + relu-mask epilogue: out = (prev + acc) * (mask > 0)
+    prev = torch.randn(B, H, W, cp, generator=g)
+    mask = torch.randn(B, H, W, cp, generator=g)
+    dx2, maskd = dev(prev), dev(mask)
+    L.check(L.lib.zsg_conv_wino(C.byref(ddesc), dyd.data_ptr(), Ut.data_ptr(), dx2.data_ptr(), None, dx2.data_ptr(), maskd.data_ptr(), None, st), "wino dgrad+")
+    ref2 = (prev[..., :Ci] + xr.grad.permute(0, 2, 3, 1)) * (mask[..., :Ci] > 0)
+    assert_close(dx2[..., :Ci], ref2, 5e-4, 5e-4 * float(ref2.abs().max()), "wino dgrad accumulate+mask")
+    torch.cuda.synchronize()
+
+
+def test_wino_multilevel_window(Z):
+    """grouped launch over pyramid levels with a channel window of the weight (head conv0: features only) and an
+    additive map, output scattered into a [B, P, N] buffer"""
+    L, ops = Z
+    g = torch.Generator().manual_seed(11)
+    B, Cf, Cw, Co = 2, 64, 12, 64
+    Ct = Cf + Cw
+    sizes = [(7, 7), (4, 4), (3, 3), (2, 2), (1, 1)]
+    w = torch.randn(Co, Ct, 3, 3, generator=g) / 24
+    b = torch.randn(Co, generator=g)
+    xs = [torch.randn(B, Cf, h, ww, generator=g) for h, ww in sizes]
+    P = sum(h * ww for h, ww in sizes)
+    addm = torch.randn(B, P, Co, generator=g)
+    refs = [F.conv2d(x, w[:, :Cf], b, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Co) for x in xs]
+    ref = F.relu(torch.cat(refs, dim=1) + addm)
+    packed = torch.cat([nhwc(x).reshape(-1) for x in xs]).cuda()
+    lv_in, lv_out, off_in, off_px = [], [], 0, 0
+    for (h, ww) in sizes:
+        lv_in.append(ops.Level(off_in, h, ww, h * ww * Cf))
+        lv_out.append(ops.Level(off_px * Co, h, ww, P * Co))
+        off_in += B * h * ww * Cf
+        off_px += h * ww
+    src = ops.TView(packed, B, Cf, Cf, lv_in)
+    out = torch.full((B, P, Co), float("nan"), device="cuda")
+    ov = ops.TView(out.view(-1), B, Co, Co, lv_out)
+    wd, bd, ad = dev(ohwi(w)), dev(b), dev(addm)
+    U = make_u(L, ops, wd, Co, Cf, 9 * Ct, Ct, False)
+    for TB, BN in ((64, 64), (32, 64), (64, 32), (32, 32)):
+        out.fill_(float("nan"))
+        desc = ops.fwd_desc(src, ov, Cf, Co, 3, 1, 1, 1, wC=Ct, relu=True, tile_hint=TB | (BN << 8) | (1 << 16))
+        L.check(L.lib.zsg_conv_wino(C.byref(desc), packed.data_ptr(), U.data_ptr(), out.data_ptr(), bd.data_ptr(), ad.data_ptr(), None, None,
+                                    L.stream_ptr()), "wino")
+        assert_close(out, ref, 3e-4, 3e-4, f"multi-level wino {TB}x{BN}")

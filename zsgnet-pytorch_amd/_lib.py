@@ -47,6 +47,9 @@ SIGNATURES = {
     "zsg_version": (I32, []),
     "zsg_last_error": (C.c_char_p, []),
     "zsg_conv_igemm": (I32, [DP, P, P, P, P, P, P, P, P]),
+    "zsg_conv_wino": (I32, [DP, P, P, P, P, P, P, P, P]),
+    "zsg_wino_u_elems": (I64, [I32, I32]),
+    "zsg_wino_weights": (I32, [P, I32, I32, P]),
     "zsg_conv_wgrad_workspace_bytes": (SZ, [DP]),
     "zsg_conv_wgrad": (I32, [DP, P, P, P, I32, P, SZ, P]),
     "zsg_transpose_w": (I32, [P, P, I32, I32, I32, I32, P]),

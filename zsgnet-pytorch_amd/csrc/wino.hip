@@ -1,0 +1,465 @@
+// wino.hip — Winograd F(2x2, 3x3) convolution (forward and stride-1 data gradient) on fp32 MFMA, NHWC, gfx950.
+//
+// For the 3x3 / stride 1 / pad 1 convolutions (72 % of the network's multiply-adds: the shared head, the FPN output
+// convolutions, every bottleneck's conv2) the direct implicit GEMM spends 9 MACs per (pixel, cin, cout); the minimal
+// filtering algorithm F(2x2,3x3) spends 16 per 2x2 output tile = 4 per pixel (2.25x fewer) at fp32 (transform constants
+// are 0, +-1, +-1/2: exact scalings, a handful of extra roundings per output).
+//
+//   Y(2x2) = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          d: 4x4 input patch, g: 3x3 filter
+//
+// GEMM view: 16 independent GEMMs ("positions" p = j*4 + i of the 4x4 transformed domain) that share M / N / K:
+//   M = tiles (segment, b, ty, tx)   A_p[tile][c] = (B^T d B)[i][j]      transformed ON THE FLY while staging to LDS
+//   N = output channels              B_p[n][c]    = (G g G^T)[i][j]      pre-transformed once per step (zsg_wino_weights)
+//   K = input channels, 8 per LDS stage
+// Work split: a workgroup owns (32*TM tiles) x (32*TN channels); wave (wm, wn, ph) owns one 32x32 sub-block and the
+// 8 positions with i in {2ph, 2ph+1} (8 x 16 accumulator registers); the two position halves are combined in the
+// epilogue (the output transform is linear), which also undoes the tile -> 2x2 pixel mapping through LDS so that every
+// lane stores 16 contiguous bytes.
+// A loader: lane (tile, 4-channel group g, patch row q) loads the 4 pixels of its patch row (4 x 16 B), applies the row
+// transform in registers and gets the column transform from its quad neighbours with DPP quad_perm (no LDS round trip),
+// then writes V[q][0..3] with four conflict-free ds_write_b128.  B loader: 16-byte copies of the pre-chunked U image
+// [c/8][p][n][8] (contiguous 2 KB runs).  LDS rows are 8 floats; the two 16-byte halves of a row are XOR-swizzled with
+// bit 3 of the row index, which makes the ds_read_b128 fragment reads (lane = row, half = k-group) conflict-free without
+// padding.  K permutation as in igemm.hip: value e of a lane's b128 feeds the e-th of four MFMAs.
+#include "common.h"
+
+#define WN_CK 8
+
+struct WnSegDev {
+    int tiles_y, tiles_x, tiles;   // tile grid per image; tiles = B * tiles_y * tiles_x
+    int blk0;                      // first M block of the segment
+    int H, W;
+    int src_off, src_bstride, out_off, out_bstride;   // elements
+};
+
+struct WnParams {
+    const float* src;
+    const float* U;
+    float* out;
+    const float* bias;
+    const float* add_src;
+    const float* mask_src;
+    float* stats;        // optional BatchNorm partials [m_blocks][2][N]
+    int C, N, Npad, src_ld, out_ld, relu, nseg;
+    int m_blocks, n_blocks, splits, chunks, vec, add_is_out;
+    WnSegDev seg[ZSG_MAX_SEG];
+};
+
+__device__ __forceinline__ float quad_pick(float v, const int ctrl_is_x) {
+    // quad_perm [0,1,2,1] (x operand) / [2,2,1,3] (y operand) of the column transform B^T
+    const int iv = __builtin_bit_cast(int, v);
+    const int r = ctrl_is_x ? __builtin_amdgcn_mov_dpp(iv, 0x64, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(iv, 0xDA, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, r);
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
+    constexpr int NT = 128 * TM * TN;            // 2 position halves x TM x TN waves
+    constexpr int TB = 32 * TM, BN = 32 * TN;
+    constexpr int SA = TB * 8 + 8;               // floats between positions of the A stage (+8: conflict-free quad writes)
+    constexpr int SB = BN * 8;
+    constexpr int IA = TB * 8 / NT;              // A loader items (tile, g, q) per thread
+    constexpr int IB = 32 * BN / NT;             // B loader 16-byte copies per thread
+    static_assert(IA >= 1 && IB >= 1, "tile too small for the thread count");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                            // [2][16][SA]
+    float* Bs = smem + 2 * 16 * SA;              // [2][16][SB]
+    int* rowinfo = (int*)(smem + 2 * 16 * (SA + SB));   // [TB][2]: output offset of pixel (2ty, 2tx) | -1 ; validity bits
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ph = wave / (TM * TN);
+    const int wmn = wave % (TM * TN);
+    const int wm = wmn / TN, wn = wmn % TN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int n_mn = p.m_blocks * p.n_blocks;
+    const int split = blockIdx.x / n_mn;
+    const int bid = xcd_remap(blockIdx.x - split * n_mn, n_mn);
+    const int mb = bid / p.n_blocks, nb = bid % p.n_blocks;
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < ZSG_MAX_SEG; ++s)
+        if (s < p.nseg && mb >= p.seg[s].blk0) si = s;
+    const WnSegDev sg = p.seg[si];
+    const int m0 = (mb - sg.blk0) * TB;
+    const int n0 = nb * BN;
+    const int src_ld = p.src_ld;
+
+    // ---- loader state (fixed over the K loop) ------------------------------------------------------------------------
+    const int q = tid & 3, g = (tid >> 2) & 1;
+    int a_base[IA], a_mask[IA], a_lds[IA];
+#pragma unroll
+    for (int ia = 0; ia < IA; ++ia) {
+        const int t = (tid + NT * ia) >> 3;
+        const int m = m0 + t;
+        const bool ok = m < sg.tiles;
+        const int mm = ok ? m : 0;
+        const int per = sg.tiles_y * sg.tiles_x;
+        const int b = mm / per;
+        const int rem = mm - b * per;
+        const int ty = rem / sg.tiles_x;
+        const int tx = rem - ty * sg.tiles_x;
+        const int y = 2 * ty - 1 + q, x0 = 2 * tx - 1;
+        const bool rok = ok & ((unsigned)y < (unsigned)sg.H);
+        int mask = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mask |= (rok & ((unsigned)(x0 + c) < (unsigned)sg.W)) ? (1 << c) : 0;
+        a_mask[ia] = mask;
+        a_base[ia] = sg.src_off + b * sg.src_bstride + (y * sg.W + x0) * src_ld + 4 * g;
+        a_lds[ia] = q * SA + t * 8 + 4 * (g ^ ((t >> 3) & 1));
+        if (q == 0 && g == 0) {
+            rowinfo[2 * t] = ok ? sg.out_off + b * sg.out_bstride + ((2 * ty) * sg.W + 2 * tx) * p.out_ld : -1;
+            rowinfo[2 * t + 1] = ((2 * tx + 1 < sg.W) ? 1 : 0) | ((2 * ty + 1 < sg.H) ? 2 : 0);
+        }
+    }
+    int b_base[IB], b_lds[IB];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+        const int id = tid + NT * ib;
+        const int gg = id & 1, n = (id >> 1) % BN, pos = id / (2 * BN);
+        b_base[ib] = (pos * p.Npad + n0 + n) * 8 + 4 * gg;
+        b_lds[ib] = pos * SB + n * 8 + 4 * (gg ^ ((n >> 3) & 1));
+    }
+    const rsrc_t rsrc_a = make_rsrc(p.src);
+    const rsrc_t rsrc_b = make_rsrc(p.U);
+    const int ustep = 16 * p.Npad * 8;           // U elements per 8-channel chunk
+
+    int c0 = 0, nc = p.chunks;
+    if (p.splits > 1) {
+        const int per = (p.chunks + p.splits - 1) / p.splits;
+        c0 = min(split * per, p.chunks);
+        nc = min(per, p.chunks - c0);
+    }
+
+    f32x4 ra[IA][4], rb[IB];
+    auto load_chunk = [&](int c, bool live) {
+        const int koff = c * WN_CK + 4 * g;
+        const bool kok = live & (koff < p.C);
+#pragma unroll
+        for (int ia = 0; ia < IA; ++ia)
+#pragma unroll
+            for (int col = 0; col < 4; ++col) {
+                const bool ok = kok & ((a_mask[ia] >> col) & 1);
+                const unsigned off = 4u * (unsigned)(a_base[ia] + col * src_ld + c * WN_CK);
+                ra[ia][col] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
+            }
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib)
+            rb[ib] = buf_load4(rsrc_b, live ? 4u * (unsigned)(b_base[ib] + c * ustep) : ZSG_OOB);
+    };
+    const float sgn = (q == 1) ? 1.f : -1.f;
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * 16 * SA;
+        float* b = Bs + buf * 16 * SB;
+#pragma unroll
+        for (int ia = 0; ia < IA; ++ia) {
+            // row transform (d B): this lane's patch row q
+            f32x4 t[4];
+            t[0] = ra[ia][0] - ra[ia][2];
+            t[1] = ra[ia][1] + ra[ia][2];
+            t[2] = ra[ia][2] - ra[ia][1];
+            t[3] = ra[ia][1] - ra[ia][3];
+            // column transform B^T across the quad: V[q] = t[ra(q)] +- t[rb(q)]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(quad_pick(t[j][e], 0), sgn, quad_pick(t[j][e], 1));
+                *(f32x4*)(a + a_lds[ia] + j * 4 * SA) = v;
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) *(f32x4*)(b + b_lds[ib]) = rb[ib];
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    if (nc > 0) {
+        load_chunk(c0, true);
+        store_chunk(0);
+        load_chunk(c0 + 1, nc > 1);
+    }
+    __syncthreads();
+
+    const int frag_a = (wm * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SA;
+    const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SB;
+    for (int it = 0; it < nc; ++it) {
+        const float* a = As + (it & 1) * 16 * SA + frag_a;
+        const float* b = Bs + (it & 1) * 16 * SB + frag_b;
+#pragma unroll
+        for (int pl = 0; pl < 8; ++pl) {           // position p = j*4 + 2*ph + il, pl = j*2 + il
+            const int po = (pl >> 1) * 4 + (pl & 1);
+            const f32x4 fa = *(const f32x4*)(a + po * SA);
+            const f32x4 fb = *(const f32x4*)(b + po * SB);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
+        }
+        store_chunk((it + 1) & 1);                  // chunk it+1 (after the last chunk: zeros into the idle buffer)
+        load_chunk(c0 + it + 2, it + 2 < nc);
+        __syncthreads();
+    }
+
+    // ---- output transform: this wave's half of Y = A^T M A --------------------------------------------------------------
+    // z[il][b] = sum_j A^T[b][j] M[i][j];  ph 0 (i = 0,1): Y[0] = z0 + z1, Y[1] = z1;  ph 1 (i = 2,3): Y[0] = z0, Y[1] = -z0 - z1
+    constexpr int LDC = BN + 4;
+    float* ct = smem;                               // [TB*4][LDC] — the staging area is no longer needed
+    float* red = smem + TB * 4 * LDC;               // [2][RPP][BN] (statistics)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if (ph == hh) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float z00 = acc[0][e] + acc[2][e] + acc[4][e], z01 = acc[2][e] - acc[4][e] - acc[6][e];
+                const float z10 = acc[1][e] + acc[3][e] + acc[5][e], z11 = acc[3][e] - acc[5][e] - acc[7][e];
+                float y[4];
+                if (hh == 0) {
+                    y[0] = z00 + z10; y[1] = z01 + z11; y[2] = z10; y[3] = z11;
+                } else {
+                    y[0] = z00; y[1] = z01; y[2] = -z00 - z10; y[3] = -z01 - z11;
+                }
+                const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float* o = ct + (tl * 4) * LDC + wn * 32 + li;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    if (hh == 0) o[px * LDC] = y[px];
+                    else o[px * LDC] += y[px];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual / accumulate, relu, relu-mask, BatchNorm partial statistics ---------------------------
+    const bool vec_ok = p.vec && (p.splits == 1);
+    if (vec_ok) {
+        constexpr int CG = BN / 4;
+        constexpr int RPP = NT / CG;
+        const int cg = tid % CG, rr = tid / CG;
+        const int n = n0 + 4 * cg;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll 4
+            for (int row = rr; row < TB * 4; row += RPP) {
+                const int tl = row >> 2, px = row & 3;
+                const int ro = rowinfo[2 * tl], fl = rowinfo[2 * tl + 1];
+                if (ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
+                const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
+                f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
+                s1 += v;
+                s2 += v * v;
+                v += bv;
+                if (p.add_src) v += *(const f32x4*)(p.add_src + o);
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.mask_src) {
+                    const f32x4 m = *(const f32x4*)(p.mask_src + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+                }
+                *(f32x4*)(p.out + o) = v;
+            }
+        }
+        if (p.stats) {                               // fixed-order (deterministic) reduction over the RPP row lanes
+            *(f32x4*)(red + rr * BN + 4 * cg) = s1;
+            *(f32x4*)(red + (RPP + rr) * BN + 4 * cg) = s2;
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < RPP; ++r) {
+                    a1 += red[r * BN + tid];
+                    a2 += red[(RPP + r) * BN + tid];
+                }
+                float* o = p.stats + (size_t)mb * 2 * p.N;
+                o[n0 + tid] = a1;
+                o[p.N + n0 + tid] = a2;
+            }
+        }
+        return;
+    }
+    // scalar path: ragged channel counts (the 45-channel head output) and split-K (fp32 atomics; linear terms only)
+    for (int idx = tid; idx < TB * 4 * BN; idx += NT) {
+        const int row = idx / BN, col = idx - row * BN;
+        const int n = n0 + col;
+        const int tl = row >> 2, px = row & 3;
+        const int ro = rowinfo[2 * tl], fl = rowinfo[2 * tl + 1];
+        if (n >= p.N || ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
+        const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
+        float v = ct[row * LDC + col];
+        if (p.splits > 1) {
+            if (split == 0) {
+                if (p.bias) v += p.bias[n];
+                if (p.add_src && !p.add_is_out) v += p.add_src[o];
+            }
+            if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
+            unsafeAtomicAdd(p.out + o, v);
+        } else {
+            if (p.bias) v += p.bias[n];
+            if (p.add_src) v += p.add_src[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
+            p.out[o] = v;
+        }
+    }
+}
+
+// ---- weight transform U = G g G^T, all layers of a step in one launch -------------------------------------------------
+// job: source rows [N][9 taps][src_tap_ld] with row stride src_row_ld (a channel window of an OHWI weight, or a dgrad weight
+// image), flip = 1 rotates the filter by 180 degrees (data gradient).  dst: [chunks][16][Npad][8], p = j*4 + i.
+struct WnWJob {
+    int64_t src, dst;            // absolute device addresses
+    int32_t N, C, src_row_ld, src_tap_ld, flip, Npad, chunks, blk0;
+};
+
+__global__ __launch_bounds__(256) void wino_weight_kernel(const WnWJob* jobs, int njobs) {
+    int ji = 0;
+    for (int s = 1; s < njobs; ++s)
+        if ((int)blockIdx.x >= jobs[s].blk0) ji = s;
+    const WnWJob jb = jobs[ji];
+    const int id = ((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x;      // (chunk, n, cc), cc fastest
+    const int cc = id & 7;
+    const int n = (id >> 3) % jb.Npad;
+    const int chunk = (id >> 3) / jb.Npad;
+    if (chunk >= jb.chunks) return;
+    const int c = chunk * 8 + cc;
+    float gk[3][3];
+    const bool ok = (n < jb.N) & (c < jb.C);
+    const float* src = (const float*)jb.src + (size_t)n * jb.src_row_ld + c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int tap = jb.flip ? (2 - a) * 3 + (2 - b) : a * 3 + b;
+            gk[a][b] = ok ? src[(size_t)tap * jb.src_tap_ld] : 0.f;
+        }
+    // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+    float tg[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        tg[0][b] = gk[0][b];
+        tg[1][b] = 0.5f * (gk[0][b] + gk[1][b] + gk[2][b]);
+        tg[2][b] = 0.5f * (gk[0][b] - gk[1][b] + gk[2][b]);
+        tg[3][b] = gk[2][b];
+    }
+    float* dst = (float*)jb.dst + ((size_t)chunk * 16 * jb.Npad + n) * 8 + cc;
+    const size_t ps = (size_t)jb.Npad * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u0 = tg[i][0];
+        const float u1 = 0.5f * (tg[i][0] + tg[i][1] + tg[i][2]);
+        const float u2 = 0.5f * (tg[i][0] - tg[i][1] + tg[i][2]);
+        const float u3 = tg[i][2];
+        dst[(0 * 4 + i) * ps] = u0;
+        dst[(1 * 4 + i) * ps] = u1;
+        dst[(2 * 4 + i) * ps] = u2;
+        dst[(3 * 4 + i) * ps] = u3;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+extern "C" int64_t zsg_wino_u_elems(int32_t C, int32_t N) {
+    const int64_t chunks = (C + WN_CK - 1) / WN_CK, npad = (N + 63) / 64 * 64;
+    return chunks * 16 * npad * 8;
+}
+
+extern "C" int zsg_wino_weights(const void* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream) {
+    ZSG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "wino_weights: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("wino_weight_kernel", st, 0, 0);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(total_blocks), dim3(256), 0, st, (const WnWJob*)jobs_dev, njobs);
+    ZSG_CHECK_LAUNCH("wino_weights");
+    return 0;
+}
+
+template <int TM, int TN>
+static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
+    constexpr int TB = 32 * TM, BN = 32 * TN, NT = 128 * TM * TN;
+    constexpr int SA = TB * 8 + 8, SB = BN * 8;
+    size_t lds = (size_t)2 * 16 * (SA + SB) * sizeof(float) + TB * 2 * sizeof(int);
+    const size_t epi = ((size_t)TB * 4 * (BN + 4) + 2 * (NT / (BN / 4)) * BN) * sizeof(float);
+    if (epi > (size_t)2 * 16 * (SA + SB) * sizeof(float)) lds = epi + TB * 2 * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    ZSG_PROF(kname, st, flops, 0);
+    hipLaunchKernelGGL((wino_kernel<TM, TN>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
+    ZSG_CHECK_LAUNCH("conv_wino");
+    return 0;
+}
+
+// tile_hint = TB | (BN << 8) | (split_k << 16), TB (tiles per block) and BN in {32, 64}; 0 = 64x64, no split
+extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
+                             const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
+    ZSG_REQUIRE(d && src && U && out, "conv_wino: null argument");
+    ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wino: nseg=%d", d->nseg);
+    ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0, "conv_wino: C=%d src_ld=%d must be multiples of 4", d->C, d->src_ld);
+    ZSG_REQUIRE(d->wR == 3 && d->wS == 3 && !d->merge_x, "conv_wino: 3x3 filters only");
+    int TB = d->tile_hint & 0xff, BN = (d->tile_hint >> 8) & 0xff, splits = (d->tile_hint >> 16) & 0xff;
+    if (!d->tile_hint) { TB = 64; BN = 64; }
+    if (splits < 1) splits = 1;
+    ZSG_REQUIRE((TB == 32 || TB == 64) && (BN == 32 || BN == 64), "conv_wino: unsupported tile %dx%d", TB, BN);
+    WnParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = src; p.U = U; p.out = out; p.bias = bias; p.add_src = add_src; p.mask_src = mask_src; p.stats = bn_partials;
+    p.C = d->C; p.N = d->N; p.Npad = (d->N + 63) / 64 * 64; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.relu = d->relu;
+    p.nseg = d->nseg; p.chunks = (d->C + WN_CK - 1) / WN_CK; p.splits = splits;
+    p.add_is_out = (add_src == out) ? 1 : 0;
+    int blocks = 0;
+    double fl = 0;
+    bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const zsg_seg& a = d->seg[s];
+        // a centred 3x3 window at unit stride: forward (d0 = -1, step +1) or data gradient (d0 = +1, step -1; U holds
+        // the rotated filter)
+        ZSG_REQUIRE(a.ty.n == 3 && a.tx.n == 3 && a.sy == 1 && a.sx == 1 && a.osy == 1 && a.osx == 1 && a.opy == 0 && a.opx == 0 &&
+                        a.ty.d0 == -a.ty.dstep && a.tx.d0 == -a.tx.dstep && (a.ty.dstep == 1 || a.ty.dstep == -1) && a.tx.dstep == a.ty.dstep,
+                    "conv_wino: seg %d is not a 3x3 / stride 1 / pad 1 convolution", s);
+        ZSG_REQUIRE(a.rows_y == a.src_H && a.rows_x == a.src_W && a.out_W == a.rows_x, "conv_wino: seg %d: output grid must equal the input grid", s);
+        const int64_t tiles = (int64_t)d->B * ((a.src_H + 1) / 2) * ((a.src_W + 1) / 2);
+        ZSG_REQUIRE(tiles > 0 && tiles < (1ll << 28), "conv_wino: seg %d tiles=%lld", s, (long long)tiles);
+        ZSG_REQUIRE(a.src_off + (int64_t)d->B * a.src_bstride < (1ll << 29) && a.out_off + (int64_t)d->B * a.out_bstride < (1ll << 29),
+                    "conv_wino: tensor exceeds 2^29 elements (2 GB window)");
+        ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0, "conv_wino: seg %d source not 16-byte aligned", s);
+        WnSegDev& o = p.seg[s];
+        o.tiles_y = (a.src_H + 1) / 2; o.tiles_x = (a.src_W + 1) / 2; o.tiles = (int)tiles; o.blk0 = blocks;
+        o.H = a.src_H; o.W = a.src_W;
+        o.src_off = (int)a.src_off; o.src_bstride = (int)a.src_bstride; o.out_off = (int)a.out_off; o.out_bstride = (int)a.out_bstride;
+        blocks += cdiv(tiles, TB);
+        fl += 2.0 * d->B * a.src_H * a.src_W * d->N * 9.0 * d->C;
+        v = v && (a.out_off % 4) == 0 && (a.out_bstride % 4) == 0;
+    }
+    ZSG_REQUIRE((int64_t)p.chunks * 16 * p.Npad * 8 < (1ll << 29), "conv_wino: transformed weights exceed 2^29 elements");
+    p.m_blocks = blocks;
+    p.n_blocks = cdiv(d->N, BN);
+    const uintptr_t al = (uintptr_t)out | (uintptr_t)bias | (uintptr_t)add_src | (uintptr_t)mask_src;
+    p.vec = (v && (al & 15) == 0) ? 1 : 0;
+    if (bn_partials)
+        ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu && p.vec, "conv_wino: BN-statistics fusion needs a plain (bias-free, unsplit, 16-byte addressable) convolution");
+    hipStream_t st = (hipStream_t)stream;
+    if (splits > 1) {
+        ZSG_REQUIRE(!d->relu && d->nseg == 1 && d->out_ld == d->N && d->seg[0].out_bstride == (int64_t)d->seg[0].rows_y * d->seg[0].rows_x * d->N,
+                    "conv_wino: split-K needs a single dense segment without ReLU");
+        if (splits > p.chunks) p.splits = splits = p.chunks;
+        if (!p.add_is_out) {
+            hipError_t e = hipMemsetAsync(out + d->seg[0].out_off, 0, (size_t)d->B * d->seg[0].out_bstride * sizeof(float), st);
+            if (e != hipSuccess) ZSG_FAIL(-3, "conv_wino: memset: %s", hipGetErrorString(e));
+        }
+    }
+    if (TB == 64 && BN == 64) return wino_launch<2, 2>(p, st, fl, "wino_kernel<2, 2>");
+    if (TB == 32 && BN == 64) return wino_launch<1, 2>(p, st, fl, "wino_kernel<1, 2>");
+    if (TB == 64 && BN == 32) return wino_launch<2, 1>(p, st, fl, "wino_kernel<2, 1>");
+    return wino_launch<1, 1>(p, st, fl, "wino_kernel<1, 1>");
+}

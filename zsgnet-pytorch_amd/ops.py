@@ -168,6 +168,33 @@ def marshal(fn, args, keep: Optional[list] = None) -> tuple:
     return tuple(conv)
 
 
+class WinoJobs:
+    """Job list of ONE zsg_wino_weights launch: U = G g G^T for every Winograd convolution of a program.
+    A job reads source element (n, tap, c) at src + n*row_ld + tap*tap_ld + c (absolute device addresses)."""
+
+    def __init__(self):
+        self.jobs, self.blocks, self.keep = [], 0, []
+        self.dev_blob = None
+
+    def add(self, src_ptr: int, dst_ptr: int, N: int, Cred: int, row_ld: int, tap_ld: int, flip: bool):
+        chunks, npad = (Cred + 7) // 8, (N + 63) // 64 * 64
+        self.jobs.append((int(src_ptr), int(dst_ptr), N, Cred, row_ld, tap_ld, int(flip), npad, chunks, self.blocks))
+        self.blocks += (chunks * npad * 8 + 255) // 256
+
+    def finish(self, device):
+        import struct
+        blob = b"".join(struct.pack("<qqiiiiiiii", *j) for j in self.jobs)
+        self.dev_blob = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+        return self.dev_blob
+
+    def launch(self, stream: int):
+        check(lib.zsg_wino_weights(self.dev_blob.data_ptr(), len(self.jobs), self.blocks, C.c_void_p(stream)), "wino_weights")
+
+
+def wino_ok(k: int, stride: int, pad: int, dil: int) -> bool:
+    return k == 3 and stride == 1 and pad == 1 and dil == 1
+
+
 SIDE_STREAM = os.environ.get("ZSG_SIDE_STREAM", "1") != "0"
 HIP_GRAPH = os.environ.get("ZSG_HIP_GRAPH", "0")     # replay launch ranges as hipGraphs once they are warm ("0", "1", or program names "fwd,bwd")
 HIP_GRAPH = False if HIP_GRAPH == "0" else (True if HIP_GRAPH == "1" else tuple(HIP_GRAPH.split(",")))
