@@ -45,6 +45,8 @@ struct WnParams {
     WnSegDev seg[ZSG_MAX_SEG];
 };
 
+typedef __attribute__((address_space(3))) float lds_f32;
+
 __device__ __forceinline__ float quad_pick(float v, const int ctrl_is_x) {
     // quad_perm [0,1,2,1] (x operand) / [2,2,1,3] (y operand) of the column transform B^T
     const int iv = __builtin_bit_cast(int, v);
@@ -113,13 +115,16 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
             rowinfo[2 * t + 1] = ((2 * tx + 1 < sg.W) ? 1 : 0) | ((2 * ty + 1 < sg.H) ? 2 : 0);
         }
     }
-    int b_base[IB], b_lds[IB];
+    // B loader: LDS-DMA (buffer_load ... lds): one wave-instruction lands 1 KB = 32 rows of one position, lane-linear, so
+    // the row swizzle is applied on the SOURCE side (lane l fills slot (row l>>1, half l&1) with half (l&1)^swz(row)).
+    int b_src[IB], b_dst[IB];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) {
-        const int id = tid + NT * ib;
-        const int gg = id & 1, n = (id >> 1) % BN, pos = id / (2 * BN);
-        b_base[ib] = (pos * p.Npad + n0 + n) * 8 + 4 * gg;
-        b_lds[ib] = pos * SB + n * 8 + 4 * (gg ^ ((n >> 3) & 1));
+        const int kb = wave + (NT / 64) * ib;          // 1 KB piece index: pos * (BN/32) + row group
+        const int pos = kb / (BN / 32), rg = kb % (BN / 32);
+        const int r = rg * 32 + (lane >> 1);
+        b_src[ib] = (pos * p.Npad + n0 + r) * 8 + 4 * ((lane & 1) ^ ((r >> 3) & 1));
+        b_dst[ib] = pos * SB + rg * 256;               // floats, wave-uniform
     }
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.U);
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
         nc = min(per, p.chunks - c0);
     }
 
-    f32x4 ra[IA][4], rb[IB];
-    auto load_chunk = [&](int c, bool live) {
+    f32x4 ra[IA][4];
+    auto load_a = [&](int c, bool live) {
         const int koff = c * WN_CK + 4 * g;
         const bool kok = live & (koff < p.C);
 #pragma unroll
@@ -144,14 +149,18 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
                 const unsigned off = 4u * (unsigned)(a_base[ia] + col * src_ld + c * WN_CK);
                 ra[ia][col] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
             }
+    };
+    auto load_b = [&](int c, int buf) {              // straight into LDS, no registers
+#if __HIP_DEVICE_COMPILE__      // (the host pass of hipcc cannot type-check the LDS address-space cast; it never runs this body)
+        lds_f32* b = (lds_f32*)(Bs + buf * 16 * SB);
 #pragma unroll
         for (int ib = 0; ib < IB; ++ib)
-            rb[ib] = buf_load4(rsrc_b, live ? 4u * (unsigned)(b_base[ib] + c * ustep) : ZSG_OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, b + b_dst[ib], 16, 4 * (b_src[ib] + c * ustep), 0, 0, 0);
+#endif
     };
     const float sgn = (q == 1) ? 1.f : -1.f;
-    auto store_chunk = [&](int buf) {
+    auto store_a = [&](int buf) {
         float* a = As + buf * 16 * SA;
-        float* b = Bs + buf * 16 * SB;
 #pragma unroll
         for (int ia = 0; ia < IA; ++ia) {
             // row transform (d B): this lane's patch row q
@@ -169,8 +178,6 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
                 *(f32x4*)(a + a_lds[ia] + j * 4 * SA) = v;
             }
         }
-#pragma unroll
-        for (int ib = 0; ib < IB; ++ib) *(f32x4*)(b + b_lds[ib]) = rb[ib];
     };
 
     f32x16 acc[8];
@@ -180,17 +187,23 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     if (nc > 0) {
-        load_chunk(c0, true);
-        store_chunk(0);
-        load_chunk(c0 + 1, nc > 1);
+        load_b(c0, 0);
+        load_a(c0, true);
+        store_a(0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frag_a = (wm * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SA;
     const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SB;
+    // One chunk: the loads of chunk it+1 are issued first (B by LDS-DMA into the idle buffer, A into registers) and have
+    // the whole MFMA phase to land; the A transform + LDS write is interleaved with the last quarter of the MFMAs.
     for (int it = 0; it < nc; ++it) {
         const float* a = As + (it & 1) * 16 * SA + frag_a;
         const float* b = Bs + (it & 1) * 16 * SB + frag_b;
+        if (it + 1 < nc) load_b(c0 + it + 1, (it + 1) & 1);
+        load_a(c0 + it + 1, it + 1 < nc);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pl = 0; pl < 8; ++pl) {           // position p = j*4 + 2*ph + il, pl = j*2 + il
             const int po = (pl >> 1) * 4 + (pl & 1);
@@ -198,9 +211,10 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
             const f32x4 fb = *(const f32x4*)(b + po * SB);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
+            if (pl == 5) __builtin_amdgcn_sched_barrier(0);
         }
-        store_chunk((it + 1) & 1);                  // chunk it+1 (after the last chunk: zeros into the idle buffer)
-        load_chunk(c0 + it + 2, it + 2 < nc);
+        store_a((it + 1) & 1);                     // chunk it+1 (after the last chunk: zeros into the idle buffer)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
