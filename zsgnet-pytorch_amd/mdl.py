@@ -26,7 +26,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import Level, Program, TView, autotune_conv, conv_out, dgrad_desc, fwd_desc
+from .ops import Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, wino_mode, wino_ok
 from .params import ParamStore, pad4, register_named
 
 VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
@@ -422,7 +422,13 @@ class _Plan:
         self.wt_arena = self._buf(net.store.total + 4096 * len(net.convs)) if training else None
         self.fold_jobs, self.fold_used, self.fold_rows = [], 0, 0          # eval: BatchNorm folded into the convolutions
         self.fold_arena = self._buf(net.store.total + 8 * len(net.convs)) if (not training and net.bns) else None
+        self.wino_jobs = {"fwd": WinoJobs(), "bwd": WinoJobs()}     # filter transforms of the Winograd convolutions (one launch each)
         self._lower()
+        wj = self.wino_jobs["fwd"]
+        if wj.jobs:          # U = G g G^T of every Winograd forward convolution: first launch after the image conversion
+            self.fwd.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
+            self.fwd.calls.insert(1, self.fwd.calls.pop())
+            self.fwd.lanes.insert(1, self.fwd.lanes.pop())
         if training:
             self._finish_prep()
         elif self.fold_jobs:
@@ -480,6 +486,22 @@ class _Plan:
         return self.net.store.raw(name, self.net.store.grad)
 
     # ---- op lowering ---------------------------------------------------------------------------------------------
+    def _wino_u(self, src_ptr: int, N: int, Cred: int, row_ld: int, tap_ld: int, flip: int):
+        """Transformed filter image of one 3x3 convolution (+ a one-off transform so that the tuner times real data);
+        the job joins the program's batched transform only if the Winograd kernel wins the tuning."""
+        U = self._buf(lib.zsg_wino_u_elems(Cred, N))
+        job = (src_ptr, U.data_ptr(), N, Cred, row_ld, tap_ld, flip)
+        one = WinoJobs()
+        one.add(*job)
+        one.finish(self.dev)
+        one.launch(stream_ptr())
+        return U, job
+
+    @staticmethod
+    def _wino_chunks(d, B: int) -> int:
+        tb = d.tile_hint & 0xff
+        return sum((B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) + tb - 1) // tb for i in range(d.nseg))
+
     def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None, bn_fuse: Optional[BnL] = None) -> Act:
         """bn_fuse: the output feeds a train-mode BatchNorm — let the epilogue emit the per-tile (sum, sum^2) partials
         (no extra pass over the activation) unless the autotuner chose split-K for this layer."""
@@ -495,16 +517,28 @@ class _Plan:
         pen = 0.0
         if bn_fuse is not None and self.training and not L.bias and not relu:
             pen = 0.008 + out.rows() * L.cout * 4 / 4e9
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, None), stream_ptr(),
-                      split_penalty_ms=pen)
+        wt = self.P(L.name + ".weight")
+        wargs = None
+        if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
+            U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
+            wargs = (src.buf, U, out.buf, bias, None, None, None)
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, wt, out.buf, bias, None, None, None), stream_ptr(),
+                      split_penalty_ms=pen, wino_args=wargs)
+        fn = lib.zsg_conv_igemm
+        if d.use_wino:
+            fn, wt = lib.zsg_conv_wino, U
+            self.wino_jobs["fwd"].add(*job)
         partials = None
         out.bn_chunks = 0
         if bn_fuse is not None and self.training and d.tile_hint and ((d.tile_hint >> 16) & 0xff) <= 1 and not L.bias and not relu:
-            bm = d.tile_hint & 0xff
-            chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
+            if d.use_wino:
+                chunks = self._wino_chunks(d, src.B)
+            else:
+                bm = d.tile_hint & 0xff
+                chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
                 partials, out.bn_chunks = self.ws, chunks
-        self.fwd.add(lib.zsg_conv_igemm, d, src.buf, self.P(L.name + ".weight"), out.buf, bias, None, None, partials, what=L.name)
+        self.fwd.add(fn, d, src.buf, wt, out.buf, bias, None, None, partials, what=L.name)
         if partials is not None:         # finalize at once: the shared workspace is reused by the next launch
             Lb = bn_fuse
             rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
@@ -538,8 +572,16 @@ class _Plan:
         d = fwd_desc(x, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
         wt, bias = self.fold_arena[w_off:w_off + n_w], self.fold_arena[b_off:b_off + L.cout]
         args = (x.buf, wt, out.buf, bias, residual.buf if residual is not None else None, None, None)
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr())
-        self.fwd.add(lib.zsg_conv_igemm, d, *args, what=L.name + "+bn")
+        wargs = None
+        if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
+            U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
+            wargs = (x.buf, U) + args[2:]
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), wino_args=wargs)
+        if d.use_wino:
+            self.wino_jobs["fwd"].add(*job)
+            self.fwd.add(lib.zsg_conv_wino, d, *wargs, what=L.name + "+bn")
+        else:
+            self.fwd.add(lib.zsg_conv_igemm, d, *args, what=L.name + "+bn")
         return out
 
     def _wt(self, L: ConvL, cred: int) -> torch.Tensor:
@@ -567,6 +609,9 @@ class _Plan:
         self.wt_jobs_dev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.dev)
         self.prep.add(lib.zsg_transpose_w_batched, self.net.store.flat, self.wt_arena, self.wt_jobs_dev, len(self.wt_jobs), tile0,
                       what="transpose all dgrad weight images")
+        wj = self.wino_jobs["bwd"]
+        if wj.jobs:          # rotated filter transforms of the Winograd data gradients, from the transposed images
+            self.prep.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino dgrad filter transforms")
 
     def _conv_bwd(self, L: ConvL, src: Act, out: Act, dy: Optional[Act] = None):
         dy = dy or out.grad
@@ -613,8 +658,16 @@ class _Plan:
             mask = src.buf.data_ptr() + 4 * deltas.pop()
             self.bwd.keep.append(src.buf)
         args = (dy.buf, wt[wt_off:], dx.buf, None, dx.buf if dx.gfilled else None, mask, None)
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr())
-        self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
+        wargs = None
+        if wino_ok(L.k, L.stride, L.pad, L.dil) and wino_mode() != "0":
+            U, job = self._wino_u(wt.data_ptr() + 4 * wt_off, n, cred, L.k * L.k * cred, cred, 1)
+            wargs = (dy.buf, U) + args[2:]
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), wino_args=wargs)
+        if d.use_wino:
+            self.wino_jobs["bwd"].add(*job)
+            self.bwd.add(lib.zsg_conv_wino, d, *wargs, what="dgrad:" + L.name)
+        else:
+            self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
         dx.gfilled = True
 
     def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None) -> Act:
@@ -1065,8 +1118,16 @@ class _Plan:
         if Cf:
             d0 = fwd_desc(Fp, h1, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0, relu=True)
             a0 = (Fp.buf, self.P(W0n), h1.buf, self.P(L0.name + ".bias"), lmap.buf if lmap is not None else None, None, None)
-            autotune_conv("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr())
-            self.fwd.add(lib.zsg_conv_igemm, d0, *a0, what=L0.name)
+            wargs = None
+            if wino_mode() != "0":
+                U0, job0 = self._wino_u(self.P(W0n).data_ptr(), 256, Cf, 9 * cp, cp, 0)
+                wargs = (Fp.buf, U0) + a0[2:]
+            autotune_conv("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr(), wino_args=wargs)
+            if d0.use_wino:
+                self.wino_jobs["fwd"].add(*job0)
+                self.fwd.add(lib.zsg_conv_wino, d0, *wargs, what=L0.name)
+            else:
+                self.fwd.add(lib.zsg_conv_igemm, d0, *a0, what=L0.name)
         else:                             # image-blind: h1 = relu(lmap + bias), an affine map with scale 1
             one, zero = self._buf(256) + 1.0, self._buf(256)
             self.fwd.add(lib.zsg_bn_apply, lmap.buf, h1.rows(), 256, zero, one, one, self.P(L0.name + ".bias"), None, 1, h1.buf, None,

@@ -368,18 +368,66 @@ def _time_launch(fn, args, stream, reps=10):
     return a.elapsed_time(b) / reps
 
 
-def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0, split_penalty_ms: float = 0.0) -> int:
+WINO_FLAG = 1 << 30          # tuner result: the Winograd kernel won (its own tile hint in the low bits)
+
+
+def wino_mode() -> str:
+    """ZSG_WINO: '1' (default) the autotuner times the Winograd kernel next to the direct one for every 3x3/s1 convolution
+    and keeps the faster; '0' direct only; 'force' Winograd wherever it applies (parity tests of that path)."""
+    return os.environ.get("ZSG_WINO", "1")
+
+
+def deterministic() -> bool:
+    """ZSG_DETERMINISTIC=1: no launch may combine partial results with fp32 atomics (split-K candidates are not offered),
+    so two processes that use the same tile choices (ZSG_TUNE_CACHE) produce bit-identical results."""
+    return os.environ.get("ZSG_DETERMINISTIC", "0") == "1"
+
+
+def _wino_cands(d: ConvDesc) -> list:
+    tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
+    cands = [tile_hint(64, 64, 1), tile_hint(32, 64, 1), tile_hint(32, 32, 1)]
+    s0 = d.seg[0]
+    dense = (d.nseg == 1 and not d.relu and d.out_ld == d.N and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
+    if dense and not deterministic():
+        for tb, bn in ((64, 64), (32, 64)):
+            blocks = ((tiles + tb - 1) // tb) * ((d.N + bn - 1) // bn)
+            for sp in (2, 4, 8):
+                if blocks * sp <= 1024 and sp * 4 <= (d.C + 7) // 8:
+                    cands.append(tile_hint(tb, bn, sp))
+    return cands
+
+
+def wino_default_hint(d: ConvDesc) -> int:
+    tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
+    blocks = ((tiles + 63) // 64) * ((d.N + 63) // 64)
+    return tile_hint(64, 64, 1) if blocks >= 384 else tile_hint(32, 64, 1)
+
+
+def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0, split_penalty_ms: float = 0.0,
+                  wino_args: Optional[Sequence] = None) -> int:
     """Pick d.tile_hint for `fn(d, *args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the real
     buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic.
     split_penalty_ms: what a split-K choice costs elsewhere (a convolution feeding BatchNorm loses the statistics fused
-    in its epilogue: a separate statistics pass + finalize launch), added to the measured time of split candidates."""
-    if os.environ.get("ZSG_AUTOTUNE", "1") == "0" or not torch.cuda.is_available():
+    in its epilogue: a separate statistics pass + finalize launch), added to the measured time of split candidates.
+    wino_args: the same launch through zsg_conv_wino (args with the transformed filter image in place of the weight):
+    its tile candidates are timed too; the result carries WINO_FLAG and d.use_wino is set when one of them wins."""
+    d.use_wino = False
+    mode = wino_mode() if wino_args is not None else "0"
+    if mode == "0":
+        wino_args = None
+    no_tune = os.environ.get("ZSG_AUTOTUNE", "1") == "0" or not torch.cuda.is_available()
+    if wino_args is not None and (mode == "force" and no_tune):
+        d.tile_hint, d.use_wino = wino_default_hint(d), True
+        return d.tile_hint | WINO_FLAG
+    if no_tune:
         return 0
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
-    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0))
+    key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
+                         mode if wino_args is not None else "", deterministic()))
     if key in _TUNE_CACHE:
-        d.tile_hint = _TUNE_CACHE[key]
-        return d.tile_hint
+        v = _TUNE_CACHE[key]
+        d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
+        return v
     rows = sum(d.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
     cands = []
     if kind == "igemm":
@@ -393,7 +441,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                 cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
-        if dense and blocks64 < 1024:
+        if dense and blocks64 < 1024 and not deterministic():
             for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if sp <= n_it and blocks64 * sp <= 3072:
                     cands.append(tile_hint(64, 64, sp))
@@ -414,16 +462,19 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                             cands.append(tile_hint(bm, bn, sp, 0, 1))
                             cands.append(tile_hint(bm, bn, sp, 1, 0))          # 8-wave workgroup
                             cands.append(tile_hint(bm, bn, sp, 1, 1))
-    conv = marshal(fn, (d,) + tuple(args))
+    trials = [] if mode == "force" else [(fn, marshal(fn, (d,) + tuple(args)), h, 0) for h in cands]
+    if wino_args is not None:
+        wconv = marshal(lib.zsg_conv_wino, (d,) + tuple(wino_args))
+        trials += [(lib.zsg_conv_wino, wconv, h, WINO_FLAG) for h in _wino_cands(d)]
     best, best_t = 0, float("inf")
-    for h in cands:
+    for f, conv, h, flag in trials:
         d.tile_hint = h
-        t = _time_launch(fn, conv, stream)
+        t = _time_launch(f, conv, stream)
         if kind == "igemm" and ((h >> 16) & 0xff) > 1:
             t += split_penalty_ms
         if t < best_t:
-            best, best_t = h, t
-    d.tile_hint = best
+            best, best_t = h | flag, t
+    d.tile_hint, d.use_wino = best & ~WINO_FLAG, bool(best & WINO_FLAG)
     _TUNE_CACHE[key] = best
     global _TUNE_DIRTY
     _TUNE_DIRTY = True
