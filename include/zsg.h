@@ -192,12 +192,8 @@ int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t
 /* uint8 [pixels][3] (HWC, as PIL decodes) -> float [pixels][4] = (r,g,b)/255, 0 — `pil2tensor(img).float().div_(255)`
  * (dat_loader.py:26-33, 134) fused with the stem layout; IEEE division: equal to the host conversion bit for bit. */
 int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out, void* stream);
-/* head input  out[b][y][x][0:ld] = [feat(Cf) | we[b](Cw) | gridy,gridx | 0...]  — BackBone.concat_we, mdl.py:69-104.
- * gy [h], gx [w] are the create_grid centres (anchors.py:47-63).  Cf or Cw may be 0 (ablations mdl.py:363-375). */
-int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, const float* gx, int32_t B, int32_t h,
-                       int32_t w, int32_t Cf, int32_t Cw, int32_t use_grid, int32_t ld, float* out, void* stream);
-
-/* Head conv0 (mdl.py:216, 514 -> 256, 3x3 pad 1) without its spatially-constant input channels: the language vector
+/* Head input BackBone.concat_we (mdl.py:69-104) + head conv0 (mdl.py:216, 514 -> 256, 3x3 pad 1) without ever materialising
+ * the concatenated tensor, and without its spatially-constant input channels: the language vector
  * is constant over the image and the grid channels do not depend on the batch index, so only the 256 feature channels
  * go through the implicit GEMM (half the MACs of the reference's dense conv); their contribution is an additive map
  *   out[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9 + tap],   V = W[:, :, lang] * we[b]  (tiny GEMM),

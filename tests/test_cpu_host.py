@@ -228,3 +228,82 @@ def test_eval_script_prediction_files(tmp_path):
     _, corr_at, _ = E.evaluate(tmp_path / "preds.pkl", tmp_path / "gt.csv", acc_iou_thresh=thr)
     assert corr_at == sum(v > thr for v in ref)
     assert E.main([str(tmp_path / "preds.pkl"), str(tmp_path / "gt.csv"), "--acc_iou_thresh=0.5"])[2] == 12
+
+
+def test_pretrained_encoder_key_mapping(tmp_path):
+    """a13 (reference mdl.py:411, 415-416): torchvision-layout ResNet files and the reduced-fc VGG16 trunk are mapped onto
+    backbone.encoder.* / backbone.encoder.vgg.*; a file that matches nothing raises instead of being ignored."""
+    from zsgnet_pytorch_amd.config import get_cfg
+    from zsgnet_pytorch_amd import mdl
+    g = torch.Generator().manual_seed(0)
+    # torchvision-layout resnet18 file: keys without prefix, plus the unused fc.*
+    ref = O.seeded_state_dict("resnet18", 5)
+    tv = {k[len("backbone.encoder."):]: torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone()
+          for k, v in ref.items() if k.startswith("backbone.encoder.")}
+    tv["fc.weight"], tv["fc.bias"] = torch.randn(1000, 512), torch.randn(1000)
+    f = tmp_path / "resnet18_tv.pth"
+    torch.save(tv, f)
+    net = mdl.get_default_net(9, get_cfg(resnet_arch="resnet18", pretrained_path=str(f)))
+    sd = net.state_dict()
+    for k, v in tv.items():
+        if not k.startswith("fc."):
+            assert torch.equal(sd["backbone.encoder." + k], v), k
+    assert not torch.equal(sd["att_reg_box.0.0.weight"], torch.zeros_like(sd["att_reg_box.0.0.weight"]))     # head untouched (random init)
+    # DDP-wrapped full checkpoint: passes through
+    full = {"model_state_dict": {"module." + k: v.clone() for k, v in ref.items()}}
+    f2 = tmp_path / "full.pth"
+    torch.save(full, f2)
+    net2 = mdl.get_default_net(9, get_cfg(resnet_arch="resnet18", pretrained_path=str(f2)))
+    assert all(torch.equal(net2.state_dict()[k], v) for k, v in ref.items())
+    # vgg16_reducedfc layout: '0.weight', '0.bias', '2.weight', ...
+    ssd = mdl.get_default_net(9, get_cfg(mdl_to_use="ssd_vgg"))
+    own = {k: v for k, v in ssd.state_dict().items() if k.startswith("backbone.encoder.vgg.")}
+    assert "backbone.encoder.vgg.0.weight" in own and "backbone.encoder.vgg.33.bias" in own
+    vgg = {k[len("backbone.encoder.vgg."):]: torch.randn(v.shape, generator=g) for k, v in own.items()}
+    f3 = tmp_path / "vgg16_reducedfc.pth"
+    torch.save(vgg, f3)
+    ssd2 = mdl.get_default_net(9, get_cfg(mdl_to_use="ssd_vgg", pretrained_path=str(f3)))
+    for k, v in vgg.items():
+        assert torch.equal(ssd2.state_dict()["backbone.encoder.vgg." + k], v), k
+    # a resnet file offered to the SSD model matches nothing -> loud failure; so does a wrong shape
+    with pytest.raises(ValueError, match="none of its"):
+        mdl.get_default_net(9, get_cfg(mdl_to_use="ssd_vgg", pretrained_path=str(f)))
+    tv_bad = dict(tv)
+    tv_bad["conv1.weight"] = torch.zeros(64, 3, 3, 3)
+    f4 = tmp_path / "bad.pth"
+    torch.save(tv_bad, f4)
+    with pytest.raises(ValueError, match="has shape"):
+        mdl.get_default_net(9, get_cfg(resnet_arch="resnet18", pretrained_path=str(f4)))
+
+
+def test_optimizer_state_roundtrip_and_resume_rules(tmp_path):
+    """FusedAdam.load_state_dict restores moments, step AND param_groups; a plain torch Adam state is refused;
+    Learner.load_model_dict tolerates a missing file (reference utils.py:443-457) and restores optimizer + scheduler."""
+    from zsgnet_pytorch_amd.config import get_cfg
+    from zsgnet_pytorch_amd import mdl, optim, trainer, loss, evaluator, config
+    cfg = get_cfg(resnet_arch="resnet18", tmp_path=str(tmp_path), resume=True, resume_path=str(tmp_path / "nope.pth"), load_opt=True)
+    net = mdl.get_default_net(9, cfg)
+    opt = optim.FusedAdam(net, lr=1e-4)
+    opt.m.normal_(); opt.v.uniform_(); opt.step_count.fill_(17)
+    opt.param_groups[0]["lr"] = 2.5e-5
+    sd = opt.state_dict()
+    opt2 = optim.FusedAdam(net, lr=1e-4)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v) and int(opt2.step_count) == 17
+    assert opt2.param_groups[0]["lr"] == 2.5e-5
+    with pytest.raises(ValueError, match="not a FusedAdam state"):
+        opt2.load_state_dict(torch.optim.Adam([torch.nn.Parameter(torch.zeros(2))]).state_dict())
+    r, s = config.ratios_scales(cfg)
+    lf, ev = loss.get_default_loss(r, s, cfg), evaluator.get_default_eval(r, s, cfg)
+    lrn = trainer.Learner("t", None, net, lf, cfg, ev, lambda m, lr: optim.FusedAdam(m, lr=lr), device=torch.device("cpu"))
+    assert lrn.num_it == 0 and lrn.optimizer is None          # missing resume file: fresh start, no exception
+    lrn.prepare_optimizer(1e-4)
+    lrn.optimizer.m.fill_(0.5); lrn.optimizer.step_count.fill_(9); lrn.optimizer.param_groups[0]["lr"] = 1e-5
+    lrn.num_it, lrn.num_epoch, lrn.best_met = 40, 2, 0.3
+    lrn.lr_scheduler.step(0.3)
+    lrn.save_model_dict()
+    cfg2 = get_cfg(resnet_arch="resnet18", tmp_path=str(tmp_path), resume=True, resume_path=str(lrn.model_file), load_opt=True)
+    lrn2 = trainer.Learner("t2", None, mdl.get_default_net(9, cfg2), lf, cfg2, ev, lambda m, lr: optim.FusedAdam(m, lr=lr), device=torch.device("cpu"))
+    assert lrn2.num_it == 40 and lrn2.num_epoch == 2 and lrn2.best_met == 0.3
+    assert lrn2.optimizer is not None and int(lrn2.optimizer.step_count) == 9 and lrn2.optimizer.param_groups[0]["lr"] == 1e-5
+    assert float(lrn2.optimizer.m[0]) == 0.5 and lrn2.lr_scheduler.state_dict()["best"] == lrn.lr_scheduler.state_dict()["best"]

@@ -507,15 +507,6 @@ def test_small_ops(Z):
     imgd = dev(img)
     L.check(L.lib.zsg_nchw_to_nhwc4(imgd.data_ptr(), 2, 3, 13, 11, n4.data_ptr(), st), "nhwc4")
     assert torch.equal(n4.cpu()[..., :3], img.permute(0, 2, 3, 1)) and float(n4[..., 3].abs().max()) == 0
-    # fuse_lang_grid == oracle.fuse_lang_grid (channel order feat | we | y | x)
-    feat, we = torch.randn(2, 256, 5, 3, generator=g), torch.randn(2, 256, generator=g)
-    ref = O.fuse_lang_grid(feat, we).permute(0, 2, 3, 1)
-    grid = O.create_grid(5, 3).reshape(5, 3, 2)
-    out = torch.full((2, 5, 3, 516), float("nan"), device="cuda")
-    fd, wed = dev(feat.permute(0, 2, 3, 1)), dev(we)
-    gyd, gxd = dev(torch.from_numpy(grid[:, 0, 0].copy())), dev(torch.from_numpy(grid[0, :, 1].copy()))
-    L.check(L.lib.zsg_fuse_lang_grid(fd.data_ptr(), wed.data_ptr(), gyd.data_ptr(), gxd.data_ptr(), 2, 5, 3, 256, 256, 1, 516, out.data_ptr(), st), "fuse")
-    assert torch.equal(out.cpu()[..., :514], ref) and float(out[..., 514:].abs().max()) == 0
     # pad_rows / colsum per group
     src = torch.randn(7, 45, generator=g)
     dst = torch.full((7, 48), float("nan"), device="cuda")

@@ -312,44 +312,6 @@ extern "C" int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out
     return 0;
 }
 
-// ---- head input: [feat | we | grid | 0-pad] -----------------------------------------------------------------------
-__global__ void fuse_lang_grid_kernel(const float* __restrict__ feat, const float* __restrict__ we, const float* __restrict__ gy,
-                                      const float* __restrict__ gx, int B, int h, int w, int Cf, int Cw, int use_grid, int ld,
-                                      float* __restrict__ out) {
-    const int ld4 = ld / 4;
-    const int64_t total = (int64_t)B * h * w * ld4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % ld4) * 4;
-        const int64_t pix = i / ld4;
-        const int x = (int)(pix % w);
-        const int y = (int)((pix / w) % h);
-        const int b = (int)(pix / ((int64_t)w * h));
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ch = c + e;
-            float t = 0.f;
-            if (ch < Cf) t = feat[pix * Cf + ch];
-            else if (ch < Cf + Cw) t = we[b * Cw + (ch - Cf)];
-            else if (use_grid && ch == Cf + Cw) t = gy[y];
-            else if (use_grid && ch == Cf + Cw + 1) t = gx[x];
-            v[e] = t;
-        }
-        *(f32x4*)(out + i * 4) = v;
-    }
-}
-extern "C" int zsg_fuse_lang_grid(const float* feat, const float* we, const float* gy, const float* gx, int32_t B, int32_t h, int32_t w,
-                                  int32_t Cf, int32_t Cw, int32_t use_grid, int32_t ld, float* out, void* stream) {
-    ZSG_REQUIRE(out && (ld % 4) == 0 && ld >= Cf + Cw + (use_grid ? 2 : 0) && (Cf == 0 || feat) && (Cw == 0 || we) && (!use_grid || (gy && gx)),
-                "fuse_lang_grid: bad argument");
-    const int64_t n = (int64_t)B * h * w * (ld / 4);
-    hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("fuse_lang_grid", st, 0, (double)B * h * w * (ld + Cf) * 4);
-    hipLaunchKernelGGL(fuse_lang_grid_kernel, dim3(grid_for(n)), dim3(256), 0, st, feat, we, gy, gx, B, h, w, Cf, Cw, use_grid, ld, out);
-    ZSG_CHECK_LAUNCH("fuse_lang_grid");
-    return 0;
-}
-
 // ---- weight transpose [N][T][C] -> [C][T][dst_ld >= N] (pad columns zeroed) ------------------------------------------
 __global__ void transpose_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int T, int C, int dst_ld) {
     __shared__ float tile[32][33];

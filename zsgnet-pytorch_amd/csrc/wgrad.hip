@@ -34,7 +34,6 @@ struct WgParams {
     int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, nseg;
     int ncols, txn;
     int m_tiles, n_tiles, splits, kt_total, kt_chunk, bk;
-    int dbg;          // experiment switches (ZSG_WG_DEBUG): 1 = trivial row decode, 2 = skip the atomic epilogue
     zsg_taps ty, tx;
     WgSegDev seg[ZSG_MAX_SEG];
 };
@@ -122,7 +121,6 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
             int rem = rr - b * per;
             int y = fdiv(rem, sg.rows_x, sg.inv_rx);
             int x = rem - y * sg.rows_x;
-            if (p.dbg & 1) { b = 0; y = 0; x = rr & 31; }
             const unsigned off = 4u * (unsigned)(sg.out_off + b * sg.out_bstride +
                                                   ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld + na);
             if (AVEC) {
@@ -143,7 +141,6 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
             int rem = rr - b * per;
             int y = fdiv(rem, sg.rows_x, sg.inv_rx);
             int x = rem - y * sg.rows_x;
-            if (p.dbg & 1) { b = 0; y = 0; x = rr & 31; }
             const int yy = y * sg.sy + b_dy, xx = x * sg.sx + b_dx;
             const bool ok = rok & b_colok & ((unsigned)yy < (unsigned)sg.src_H) & ((unsigned)xx < (unsigned)sg.src_W);
             const unsigned off = 4u * (unsigned)(sg.src_off + b * sg.src_bstride + (yy * sg.src_W + xx) * p.src_ld + b_c);
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
         k_step(it, ra0, rb0, ra1, rb1);
         if (it + 1 < n_kt) k_step(it + 1, ra1, rb1, ra0, rb0);
     }
-    if (kt_begin >= kt_end || (p.dbg & 2)) return;
+    if (kt_begin >= kt_end) return;
 
     // ---- epilogue: D[i][j] -> (n = output channel, q = logical weight column) -------------------------------------
 #pragma unroll
@@ -326,7 +323,6 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
         rows_all += (double)rows;
     }
     p.kt_total = kt;
-    { const char* e = getenv("ZSG_WG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     // tile_hint = BM | (BN << 8) | (splits << 16) (BM over output channels, BN over weight columns); 0 = heuristic
     int TM = (d->N > 64) ? 2 : 1;
     int TN = (p.ncols > 64) ? 2 : 1;

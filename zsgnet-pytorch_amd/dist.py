@@ -145,15 +145,21 @@ class DistributedDataParallel(nn.Module):
         return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems, self.tail_elems), self.group)
 
 
-def reduce_dict(input_dict, average=False):
-    """utils.py:62-91: stack the scalar values and reduce them to rank 0 (C4)."""
+def reduce_dict(input_dict, average=False, all_ranks: bool = True):
+    """utils.py:62-91: stack the scalar values and reduce them (C4).  The reference reduces to rank 0 only
+    (dist.reduce(dst=0)) and then lets EVERY rank step ReduceLROnPlateau / gate checkpoints on its own buffer, so the
+    learning rates of the replicas can drift apart; here every rank receives the global sums (all_reduce) unless
+    all_ranks=False asks for the reference's rank-0-only behaviour."""
     world = get_world_size()
     if world < 2:
         return input_dict
     with torch.no_grad():
         names = sorted(input_dict.keys())
         values = torch.stack([input_dict[k].detach().float().reshape(()) for k in names], dim=0)
-        dist.reduce(values, dst=0)
-        if dist.get_rank() == 0 and average:
+        if all_ranks:
+            dist.all_reduce(values, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(values, dst=0)
+        if average and (all_ranks or dist.get_rank() == 0):
             values /= world
         return {k: v for k, v in zip(names, values)}

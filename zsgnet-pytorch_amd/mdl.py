@@ -395,10 +395,16 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, plan, img, qvec, qlens, h0, c0, anchor):
         ctx.net, ctx.plan = net, plan
-        return plan.run_forward(img, qvec, qlens, h0, c0)
+        out = plan.run_forward(img, qvec, qlens, h0, c0)
+        ctx.fwd_id = plan.fwd_id
+        return out
 
     @staticmethod
     def backward(ctx, g5):
+        # a plan owns ONE set of activation buffers: the backward must belong to the plan's latest forward
+        if ctx.fwd_id != ctx.plan.fwd_id:
+            raise RuntimeError("backward of a forward whose activations were overwritten: this geometry's plan ran another "
+                               "forward since (one backward per forward per input geometry)")
         ctx.plan.run_backward(g5)
         return (None,) * 8
 
@@ -418,6 +424,7 @@ class _Plan:
         self.wt: Dict[str, torch.Tensor] = {}
         self.grad_ready: Dict[str, int] = {}
         self.reducer = None
+        self.fwd_id = 0
         self.wt_jobs, self.wt_arena_used = [], 0
         self.wt_arena = self._buf(net.store.total + 4096 * len(net.convs)) if training else None
         self.fold_jobs, self.fold_used, self.fold_rows = [], 0, 0          # eval: BatchNorm folded into the convolutions
@@ -1225,6 +1232,7 @@ class _Plan:
         import ctypes as C_
         self.fwd.calls[self.img_slot] = (fn, (C_.c_void_p(img.data_ptr()),) + args[1:], what)
         self._img_keepalive = img
+        self.fwd_id += 1
         if self.training:
             net._nbt.add_(1)
         assert self.img_slot == 0
@@ -1247,6 +1255,7 @@ class _Plan:
         params = net._ordered_params()
         st = stream_ptr()
         if any(p.grad is None for p in params):
+            net._grad_reduced = False
             lib.zsg_memset_f32(net.store.grad.data_ptr(), net.store.grad.numel(), 0.0, st)
             for n, p in zip(net._param_names, params):
                 p.grad = net.store.view(n, net.store.grad)
@@ -1254,6 +1263,12 @@ class _Plan:
         ddp = getattr(net, "_ddp", None)
         self.prep.run(st)
         if ddp is not None and ddp.world > 1:
+            # The reducer SUM-all-reduces the whole (accumulating) gradient buffer: a second backward before zero_grad would
+            # reduce the first one's gradients again.  FusedAdam.zero_grad / dropping the p.grad clears the flag.
+            if getattr(net, "_grad_reduced", False):
+                raise RuntimeError("DDP: second backward without zero_grad() — gradient accumulation is not supported by the "
+                                   "flat-buffer reducer (reduced gradients would be all-reduced again)")
+            net._grad_reduced = True
             # average over ranks: pre-scale the incoming gradient (backward is linear), then SUM-all-reduce buckets as
             # soon as the launches that fill them are enqueued; the optimizer waits through wait_gradients().
             self.g5_in.mul_(1.0 / ddp.world)
@@ -1267,15 +1282,53 @@ class _Plan:
             self.bwd.run(st)
 
 
+def map_pretrained_keys(net: "ZSGNet", sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Key mapping of the two encoder initialisations of the reference's get_default_net (mdl.py:406-422):
+      * 'retina'  (mdl.py:411 `tvm.resnet50(True)`): a torchvision ResNet state dict — `conv1.weight`, `bn1.*`,
+        `layer1.0.conv1.weight`, ..., `fc.*` — becomes `backbone.encoder.<key>` (the unused `fc.*` is dropped);
+      * 'ssd_vgg' (mdl.py:415-416 `encoder.vgg.load_state_dict(torch.load('./weights/vgg16_reducedfc.pth'))`): the
+        reduced-fc VGG16 trunk — `0.weight`, `0.bias`, `2.weight`, ..., `33.bias` — becomes `backbone.encoder.vgg.<key>`.
+    Full ZSGNet checkpoints (keys already `backbone.` / `att_reg_box.` / `lstm.`-prefixed, optionally under DDP's
+    `module.`) pass through unchanged."""
+    own = set(net.state_dict().keys())
+    keys = [k[7:] if k.startswith("module.") else k for k in sd]
+    if any(k in own for k in keys):
+        return {k2: v for k2, v in zip(keys, sd.values())}
+    prefix = "backbone.encoder.vgg." if net.backbone_kind == "ssd_vgg" else "backbone.encoder."
+    return {prefix + k: v for k, v in zip(keys, sd.values()) if not k.startswith("fc.")}
+
+
+def load_pretrained_encoder(net: "ZSGNet", path: str) -> int:
+    """Loads an encoder / full-model checkpoint into `net`; returns the number of tensors taken.  Raises when the file
+    matches NOTHING of the model (a silent no-op here would train from random weights while the log says 'pretrained')
+    or when a matched tensor has the wrong shape."""
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "model_state_dict" in sd:
+        sd = sd["model_state_dict"]
+    mapped = map_pretrained_keys(net, sd)
+    own = net.state_dict()
+    hit = {k: v for k, v in mapped.items() if k in own}
+    if not hit:
+        raise ValueError(f"pretrained_path={path!r}: none of its {len(sd)} tensors matches a parameter of the "
+                         f"{net.backbone_kind} model (first keys: {list(sd)[:4]})")
+    for k, v in hit.items():
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise ValueError(f"pretrained_path={path!r}: {k} has shape {tuple(v.shape)}, the model expects {tuple(own[k].shape)}")
+    net.load_state_dict(hit, strict=False)
+    return len(hit)
+
+
 def get_default_net(num_anchors=1, cfg=None):
     """Constructs the network based on the config (reference mdl.py:406-422).  'retina' = ResNet + FPN; the encoder
-    depth comes from the optional cfg key `resnet_arch` (default resnet50, the reference's hard-coded choice)."""
+    depth comes from the optional cfg key `resnet_arch` (default resnet50, the reference's hard-coded choice).
+    The reference initialises the encoder from torchvision's ImageNet ResNet-50 (mdl.py:411) / `vgg16_reducedfc.pth`
+    (mdl.py:415-416); with no network access the same files are taken from cfg `pretrained_path` (torchvision / SSD key
+    layouts are mapped by map_pretrained_keys), else the encoder is randomly initialised."""
     kind = cfg["mdl_to_use"]
     arch = cfg["resnet_arch"] if "resnet_arch" in cfg else "resnet50"
     net = ZSGNet(kind, num_anchors, cfg=cfg, arch=arch)
     path = cfg["pretrained_path"] if "pretrained_path" in cfg else ""
     if path:
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("model_state_dict", sd)
-        net.load_state_dict(sd, strict=False)
+        n = load_pretrained_encoder(net, path)
+        print(f"loaded {n} pretrained tensors from {path}")
     return net

@@ -26,6 +26,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = None
             return
         st = self.net.store
+        self.net._grad_reduced = False          # (DDP: one reduced backward per zero_grad, see _Plan.run_backward)
         if st.grad is not None and st.grad.is_cuda:
             check(lib.zsg_memset_f32(st.grad.data_ptr(), st.grad.numel(), 0.0, stream_ptr()), "zero_grad")
 
@@ -44,6 +45,17 @@ class FusedAdam(torch.optim.Optimizer):
         return d
 
     def load_state_dict(self, sd):
+        """Restores the moments / step counter AND the param_groups (lr as left by the scheduler, betas, eps, weight decay).
+        A plain torch.optim.Adam state dict (a reference checkpoint) has per-parameter OIHW moments that do not map onto
+        the flat OHWI buffer: refuse it loudly instead of silently restarting the moments."""
         z = sd.get("zsg")
-        if z is not None:
-            self.m.copy_(z["m"]); self.v.copy_(z["v"]); self.step_count.copy_(z["step"])
+        if z is None:
+            raise ValueError("FusedAdam.load_state_dict: no 'zsg' entry — this is not a FusedAdam state (a torch.optim.Adam "
+                             "state of the reference cannot be mapped onto the flat parameter buffer); resume with load_opt=False")
+        self.m.copy_(z["m"])
+        self.v.copy_(z["v"])
+        self.step_count.copy_(z["step"].to(self.step_count.dtype))
+        for g, gs in zip(self.param_groups, sd.get("param_groups", [])):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in gs:
+                    g[k] = gs[k]

@@ -65,12 +65,25 @@ class Learner:
         torch.save(ckpt, self.model_file)
 
     def load_model_dict(self, resume_path: str, load_opt: bool = False):
+        """utils.py:440-497.  A missing file is not an error: the reference logs it and starts from scratch (:443-457).
+        load_opt: optimizer moments / step, param_groups and the LR scheduler are restored too — the optimizer is created
+        here if needed (fit() keeps an existing one), so a resumed run continues bias correction and the reduced LR."""
+        if not resume_path or not Path(resume_path).exists():
+            self.logger.info("No checkpoint at %r: starting from scratch", resume_path)
+            if self.rank == 0:
+                print(f"resume: no checkpoint at {resume_path!r}, starting from scratch", flush=True)
+            return False
         ckpt = torch.load(resume_path, map_location="cpu")
         net = self.mdl.module if hasattr(self.mdl, "module") else self.mdl
         net.load_state_dict(ckpt["model_state_dict"], strict=self.cfg["strict_load"])
         self.num_it, self.num_epoch, self.best_met = ckpt.get("num_it", 0), ckpt.get("num_epoch", 0), ckpt.get("best_met", 0.0)
-        if load_opt and self.optimizer is not None and ckpt.get("optimizer_state_dict"):
+        if load_opt and ckpt.get("optimizer_state_dict"):
+            if self.optimizer is None:
+                self.prepare_optimizer(self.cfg["lr"])
             self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+            if self.lr_scheduler is not None and ckpt.get("scheduler_state_dict"):
+                self.lr_scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        return True
 
     # ---- loops ----------------------------------------------------------------------------------------------------------
     def _to_device(self, batch):
@@ -106,7 +119,9 @@ class Learner:
 
     @torch.no_grad()
     def validate(self, dl=None, with_predictions: bool = False):
-        """utils.py:353-391 (eval mode; losses / metrics averaged over batches weighted by batch size, reduced to rank 0).
+        """utils.py:353-391 (eval mode; losses / metrics averaged over batches weighted by batch size).  The sums are
+        ALL-reduced: every rank steps ReduceLROnPlateau and gates best_met / checkpoints on the same global numbers (the
+        reference reduces to rank 0 only, so its replicas' learning rates can drift apart).
         with_predictions: also return the per-sample records the reference pickles — a list of
         {'id': idxs, 'pred_boxes': [x1,y1,x2,y2] pixels, 'pred_scores': float} (utils.py:377-383, README 'Evaluation')."""
         self.mdl.eval()
