@@ -99,9 +99,8 @@ def main():
     torch.manual_seed(1234)                       # identical initial weights on every rank (and C3 broadcasts anyway)
     net = mdl.get_default_net(9, cfg).to("cuda")
     net.train()
-    model = zdist.DistributedDataParallel(net, device_ids=[local], broadcast_buffers=True) if (world > 1 or a.force_ddp) else net
-    if a.force_ddp and world == 1:
-        model.world = 2                  # exercise broadcast / bucketed all-reduce code paths (a 1-rank group: values unchanged)
+    model = (zdist.DistributedDataParallel(net, device_ids=[local], broadcast_buffers=True, force_collectives=a.force_ddp)
+             if (world > 1 or a.force_ddp) else net)       # --force-ddp: every collective also in a 1-rank group (values unchanged)
 
     r, s = config.ratios_scales(cfg)
     lf, ev = loss.get_default_loss(r, s, cfg), evaluator.get_default_eval(r, s, cfg)

@@ -13,7 +13,7 @@
  *   - activations are NHWC ("pixel-major"): element (b,y,x,c) at  off + b*bstride + (y*W + x)*ld + c.
  *     weights are OHWI: element (co,r,s,ci) at ((co*R + r)*S + s)*C + ci   (== torch channels_last of an OIHW tensor).
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and never synchronises.
- *   - return 0 on success, <0 on error: -1 bad argument/shape, -2 workspace too small, -3 HIP error.
+ *   - return 0 on success, <0 on error: -1 bad argument/shape, -2 workspace too small, -3 HIP error, -4 RCCL error.
  *     zsg_last_error() returns a thread-local message.  Nothing throws across the ABI.
  */
 #ifndef ZSG_H
@@ -31,6 +31,11 @@ extern "C" {
 
 int zsg_version(void);
 const char* zsg_last_error(void);
+/* on != 0: the column-sum kernels (bias gradients, the head's border sums) use one block per output element group
+ * instead of combining block partials with fp32 atomics, so every kernel of the library sums in a fixed order
+ * (convolution split-K with atomics is only ever requested through tile_hint: the host tuner does not offer it in this
+ * mode).  Process-global; the Python binding sets it from ZSG_DETERMINISTIC=1. */
+int zsg_set_deterministic(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution family (fp32 MFMA v_mfma_f32_32x32x2_f32).
@@ -263,6 +268,26 @@ int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float eps, float weight_decay, float grad_scale, int32_t* step_count, void* stream);
 
 int zsg_memset_f32(float* p, int64_t n, float value, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Gradient exchange over RCCL (xGMI) — the NCCL collectives torch DistributedDataParallel issues for the reference
+ * (main_dist.py:36-40, utils.py:395-414): C1 bucketed gradient all-reduce during backward, C2 BatchNorm-buffer
+ * broadcast per training forward, C3 parameter broadcast at wrap time.  One process per GPU, one communicator per
+ * process; the collectives run on the communicator's own non-blocking HIP stream, fenced against the caller's compute
+ * stream with events (no host synchronisation).  librccl is bound with dlopen on first use (the copy PyTorch loaded).
+ *   rank 0: zsg_comm_unique_id(id) -> share the 128 bytes with every rank (TCPStore / torch.distributed) ->
+ *   every rank, on its own device: zsg_comm_init(&c, id, nranks, rank).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct zsg_comm zsg_comm;
+int zsg_comm_unique_id(void* id128 /* out: 128 bytes */);
+int zsg_comm_init(zsg_comm** out, const void* id128, int32_t nranks, int32_t rank);
+/* in-place SUM all-reduce of buf[0:count], ordered after everything already enqueued on compute_stream; returns at once */
+int zsg_comm_allreduce_bucket(zsg_comm* c, float* buf, int64_t count, void* compute_stream);
+/* buf[0:count] of `root` to all ranks; compute_stream waits for it on the device */
+int zsg_comm_broadcast(zsg_comm* c, float* buf, int64_t count, int32_t root, void* compute_stream);
+/* compute_stream waits (device-side) for every bucket enqueued so far — call before the optimizer step */
+int zsg_comm_wait(zsg_comm* c, void* compute_stream);
+int zsg_comm_destroy(zsg_comm* c);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Per-launch timing (HIP events on the launch stream) used by bench.py's roofline leg.  Not used in timed steps.

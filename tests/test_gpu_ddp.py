@@ -87,3 +87,98 @@ def test_two_rank_gradient_average_on_one_gpu(tmp_path):
     ref = 0.5 * (_grads_single(70, sd0, cfg_kw) + _grads_single(71, sd0, cfg_kw))
     err = float((a["g1"].double() - ref.double()).norm() / ref.double().norm())
     assert err < 2e-3, f"reduced gradient differs from the mean of the per-rank gradients: rel {err:.3g}"
+
+
+def test_comm_cabi_single_rank():
+    """zsg_comm_* through the raw C ABI in a 1-rank communicator: RCCL really initialises, the all-reduce / broadcast run
+    on the communicator's stream fenced by events, a bad root comes back as error -4 with RCCL's message."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from zsgnet_pytorch_amd._lib import lib, stream_ptr
+    torch.cuda.set_device(0)
+    ident = C.create_string_buffer(128)
+    assert lib.zsg_comm_unique_id(ident) == 0, lib.zsg_last_error()
+    assert any(ident.raw), "ncclGetUniqueId left the id empty"
+    h = C.c_void_p()
+    assert lib.zsg_comm_init(C.byref(h), ident.raw, 1, 0) == 0, lib.zsg_last_error()
+    x = torch.randn(3_000_001, device="cuda")
+    ref = (x * 2 + 1).clone()
+    y = x * 2 + 1                                            # producer on the compute stream; the bucket must be ordered after it
+    for lo, hi in ((0, 1 << 20), (1 << 20, 3_000_001)):
+        assert lib.zsg_comm_allreduce_bucket(h, y.data_ptr() + 4 * lo, hi - lo, stream_ptr()) == 0, lib.zsg_last_error()
+    assert lib.zsg_comm_wait(h, stream_ptr()) == 0
+    z = y + 0                                                # consumer on the compute stream, after the wait
+    torch.cuda.synchronize()
+    assert torch.equal(z, ref), "a 1-rank SUM all-reduce must be the identity"
+    assert lib.zsg_comm_broadcast(h, y.data_ptr(), 1000, 0, stream_ptr()) == 0, lib.zsg_last_error()
+    assert lib.zsg_comm_broadcast(h, y.data_ptr(), 1000, 5, stream_ptr()) == -4
+    assert b"RCCL error" in lib.zsg_last_error()
+    assert lib.zsg_comm_init(C.byref(C.c_void_p()), ident.raw, 2, 7) == -1            # rank outside the group: argument error
+    torch.cuda.synchronize()
+    assert lib.zsg_comm_destroy(h) == 0
+
+
+@pytest.mark.parametrize("comm", ["torch", "native"])
+def test_ddp_wrapper_on_the_nccl_backend_world1(comm, tmp_path):
+    """The shipping configuration of main_dist.py:36-40 — backend 'nccl' (= RCCL) — in a 1-rank group with every
+    collective forced: C3 parameter broadcast, C2 buffer broadcast per forward, bucketed gradient all-reduce overlapped with
+    backward, through torch's ProcessGroupNCCL ('torch') and through zsg_comm_* ('native').  The gradients must equal the
+    un-wrapped model's bit for bit (a 1-rank sum, pre-scale 1/1)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    p = ctx.Process(target=_nccl_worker, args=(port, comm, str(tmp_path)))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, "the nccl-backend rank failed or hung"
+    r = torch.load(tmp_path / "nccl.pt")
+    assert r["nb"] >= 3
+    assert torch.equal(r["g_ddp"], r["g_plain"]), "1-rank reduced gradients must equal the plain backward's"
+    assert r["finite"]
+
+
+def _nccl_worker(port, comm, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", ZSG_DETERMINISTIC="1")
+    import torch.distributed as dist
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import config, dist as zdist, loss, mdl, optim
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    cfg = config.get_cfg(resnet_arch="resnet18")
+    sd = O.seeded_state_dict("resnet18", 41)
+    r, s = config.ratios_scales(cfg)
+    lf = loss.get_default_loss(r, s, cfg)
+    bt = {k: v.cuda() for k, v in O.synthetic_batch(2, 96, 96, seed=72).items()}
+    bt["h0"], bt["c0"] = torch.zeros(2, 2, 128), torch.zeros(2, 2, 128)
+
+    def run(wrap):
+        net = mdl.get_default_net(9, cfg)
+        net.load_state_dict(sd)
+        net.to("cuda").train()
+        model = zdist.DistributedDataParallel(net, device_ids=[0], bucket_mb=4.0, comm=comm, force_collectives=True) if wrap else net
+        opt = optim.FusedAdam(net, lr=1e-3)
+        opt.zero_grad()
+        lf(model(bt), bt)["loss"].backward()
+        torch.cuda.synchronize()
+        g = net.store.grad.clone().cpu()
+        nb = len(net._plans[list(net._plans)[0]].reducer.buckets) if wrap else 0
+        opt.step()
+        opt.zero_grad()
+        ls = lf(model(bt), bt)["loss"]
+        ls.backward()                        # second step: reducer / communicator reuse
+        torch.cuda.synchronize()
+        if wrap and model.comm is not None:
+            model.comm.close()
+        return g, nb, bool(torch.isfinite(ls)) and bool(torch.isfinite(net.store.grad).all())
+    g_plain, _, _ = run(False)
+    g_ddp, nb, fin = run(True)
+    torch.save(dict(g_plain=g_plain, g_ddp=g_ddp, nb=nb, finite=fin), os.path.join(out_dir, "nccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

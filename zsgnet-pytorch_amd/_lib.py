@@ -46,7 +46,14 @@ DP = C.POINTER(ConvDesc)
 SIGNATURES = {
     "zsg_version": (I32, []),
     "zsg_last_error": (C.c_char_p, []),
+    "zsg_set_deterministic": (I32, [I32]),
     "zsg_conv_igemm": (I32, [DP, P, P, P, P, P, P, P, P]),
+    "zsg_comm_unique_id": (I32, [P]),
+    "zsg_comm_init": (I32, [C.POINTER(P), P, I32, I32]),
+    "zsg_comm_allreduce_bucket": (I32, [P, P, I64, P]),
+    "zsg_comm_broadcast": (I32, [P, P, I64, I32, P]),
+    "zsg_comm_wait": (I32, [P, P]),
+    "zsg_comm_destroy": (I32, [P]),
     "zsg_conv_wino": (I32, [DP, P, P, P, P, P, P, P, P]),
     "zsg_wino_u_elems": (I64, [I32, I32]),
     "zsg_wino_weights": (I32, [P, I32, I32, P]),
@@ -110,6 +117,7 @@ def _load():
 
 
 lib = _load()
+lib.zsg_set_deterministic(1 if os.environ.get("ZSG_DETERMINISTIC", "0") == "1" else 0)
 
 
 class ZsgError(RuntimeError):

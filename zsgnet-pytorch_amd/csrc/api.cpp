@@ -17,6 +17,11 @@ void zsg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int g_zsg_deterministic = 0;
+extern "C" int zsg_set_deterministic(int32_t on) {
+    g_zsg_deterministic = on ? 1 : 0;
+    return 0;
+}
 extern "C" int zsg_version(void) { return ZSG_VERSION; }
 extern "C" const char* zsg_last_error(void) { return g_err; }
 

@@ -39,6 +39,7 @@ struct ZsgProfScope {
     ~ZsgProfScope();
 };
 extern int g_zsg_prof_on;
+extern int g_zsg_deterministic;     // zsg_set_deterministic: reductions never combine partial sums with fp32 atomics
 #define ZSG_PROF(name, stream, flops, bytes) ZsgProfScope prof__(name, (hipStream_t)(stream), (flops), (bytes))
 
 // ---- device helpers -------------------------------------------------------------------------------------------

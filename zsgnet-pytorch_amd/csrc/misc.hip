@@ -463,9 +463,19 @@ extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32
         const int c4 = C / 4;
         const int CL = c4 >= 16 ? 16 : (c4 >= 8 ? 8 : 4);     // 64 columns (256 B runs) x 16 row lanes per block
         const int cb4 = cdiv(c4, CL);
+        int CLd = CL;
         int sp = cdiv(rows, 8 * (256 / CL));                  // >= 8 rows per thread ...
         if (sp > 64) sp = 64;                                 // ... and at most 64 atomic adds per output element
+        if (g_zsg_deterministic) {                            // one block per column group: a single add per element, fixed order
+            sp = 1;
+            CLd = 4;                                          // (narrow column groups keep some parallelism: C/16 blocks per group)
+        }
         const int rpb4 = cdiv(rows, sp);
+        if (g_zsg_deterministic) {
+            hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(c4, CLd), 1, groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CLd);
+            ZSG_CHECK_LAUNCH("colsum");
+            return 0;
+        }
         hipLaunchKernelGGL(colsum4_kernel, dim3(cb4, cdiv(rows, rpb4), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CL);
         ZSG_CHECK_LAUNCH("colsum");
         return 0;
@@ -473,6 +483,7 @@ extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32
     int splits = cdiv(rows, 256);
     const int cb = cdiv(C, 64);
     while (splits > 1 && (int64_t)splits * cb * groups > 2048) splits = (splits + 1) / 2;
+    if (g_zsg_deterministic) splits = 1;
     const int rpb = cdiv(rows, splits);
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, cdiv(rows, rpb), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb);
     ZSG_CHECK_LAUNCH("colsum");
@@ -631,9 +642,10 @@ extern "C" int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("head_border_sums", st, 0, (double)B * h * w * N * 4);
     const int rows = h * w, c4 = N / 4;
-    const int CL = c4 >= 16 ? 16 : (c4 >= 8 ? 8 : 4);
+    const int CL = g_zsg_deterministic ? 4 : (c4 >= 16 ? 16 : (c4 >= 8 ? 8 : 4));
     int sp = cdiv(rows, 4 * (256 / CL));
     if (sp > 32) sp = 32;
+    if (g_zsg_deterministic) sp = 1;                          // one block per (image, column group): one add per element
     const int rpb = cdiv(rows, sp);
     hipLaunchKernelGGL(head_image_sums_kernel, dim3(cdiv(c4, CL), cdiv(rows, rpb), B), dim3(256), 0, st, dy, rows, N, rpb, Q, CL);
     hipLaunchKernelGGL(head_border_lines_kernel, dim3(B, 4), dim3(256), 0, st, dy, B, h, w, N, Q);

@@ -82,11 +82,52 @@ def plan_buckets(spans: Sequence[Tuple[int, int, int]], target_elems: int, tail_
     return sorted(buckets, key=lambda b: (b.ready, b.start))
 
 
-class BucketReducer:
-    """Sum-all-reduce of a flat buffer in buckets, interleaved with a list of launches."""
+class NativeComm:
+    """The C-ABI communicator (include/zsg.h zsg_comm_*): RCCL bound inside libzsg.so, its own HIP stream and events.
+    Rank 0 creates the ncclUniqueId; it travels over the already-initialised torch.distributed group (the rendezvous
+    store of torchrun), then every rank calls ncclCommInitRank on its own device."""
 
-    def __init__(self, flat: torch.Tensor, buckets: List[Bucket], group=None):
-        self.flat, self.buckets, self.group = flat, buckets, group
+    def __init__(self, group=None):
+        import ctypes as C
+        from ._lib import check, lib
+        self._lib, self._check, self._C = lib, check, C
+        world, rank = get_world_size(), get_rank()
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            check(lib.zsg_comm_unique_id(ident), "zsg_comm_unique_id")
+        ids = [ident.raw]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=group)
+        self.handle = C.c_void_p()
+        check(lib.zsg_comm_init(C.byref(self.handle), ids[0], world, rank), "zsg_comm_init")
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def all_reduce(self, t: torch.Tensor):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._check(self._lib.zsg_comm_allreduce_bucket(self.handle, t.data_ptr(), t.numel(), self._C.c_void_p(self._stream())), "zsg_comm_allreduce_bucket")
+
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._check(self._lib.zsg_comm_broadcast(self.handle, t.data_ptr(), t.numel(), src, self._C.c_void_p(self._stream())), "zsg_comm_broadcast")
+
+    def wait(self):
+        self._check(self._lib.zsg_comm_wait(self.handle, self._C.c_void_p(self._stream())), "zsg_comm_wait")
+
+    def close(self):
+        if self.handle:
+            self._check(self._lib.zsg_comm_destroy(self.handle), "zsg_comm_destroy")
+            self.handle = None
+
+
+class BucketReducer:
+    """Sum-all-reduce of a flat buffer in buckets, interleaved with a list of launches.  comm: a NativeComm (RCCL
+    through the C ABI) or None (torch.distributed.all_reduce on `group`: nccl = RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, flat: torch.Tensor, buckets: List[Bucket], group=None, comm: Optional["NativeComm"] = None):
+        self.flat, self.buckets, self.group, self.comm = flat, buckets, group, comm
         self.pending = []
 
     def run(self, n_launches: int, launch_range: Callable[[int, int], None]):
@@ -97,11 +138,16 @@ class BucketReducer:
             if upto > done:
                 launch_range(done, upto)
                 done = upto
-            self.pending.append(dist.all_reduce(self.flat[b.start:b.end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.comm is not None:
+                self.comm.all_reduce(self.flat[b.start:b.end])
+            else:
+                self.pending.append(dist.all_reduce(self.flat[b.start:b.end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         if done < n_launches:
             launch_range(done, n_launches)
 
     def wait(self):
+        if self.comm is not None:
+            self.comm.wait()
         for w in self.pending:
             w.wait()
         self.pending = []
@@ -114,7 +160,11 @@ class DistributedDataParallel(nn.Module):
     reducer during backward (C1)."""
 
     def __init__(self, module: nn.Module, device_ids=None, output_device=None, broadcast_buffers: bool = True,
-                 find_unused_parameters: bool = False, bucket_mb: float = 32.0, process_group=None, tail_bucket_mb: float = 4.0):
+                 find_unused_parameters: bool = False, bucket_mb: float = 32.0, process_group=None, tail_bucket_mb: float = 4.0,
+                 comm: Optional[str] = None, force_collectives: bool = False):
+        """comm: 'torch' (torch.distributed.all_reduce / broadcast on the process group: ProcessGroupNCCL = RCCL) or
+        'native' (zsg_comm_* of the C ABI: RCCL bound inside libzsg.so on its own stream); default from ZSG_COMM, else
+        'torch'.  force_collectives: issue every collective even in a 1-rank group (tests / smoke runs of the RCCL path)."""
         super().__init__()
         self.module = module
         self.broadcast_buffers = broadcast_buffers
@@ -122,27 +172,38 @@ class DistributedDataParallel(nn.Module):
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.tail_elems = int(tail_bucket_mb * (1 << 20) / 4)
         self.world = get_world_size()
+        self.active = self.world > 1 or force_collectives
+        kind = comm or os.environ.get("ZSG_COMM", "torch")
+        if kind not in ("torch", "native"):
+            raise ValueError(f"comm={kind!r}: expected 'torch' or 'native'")
+        self.comm = NativeComm(process_group) if (kind == "native" and self.active) else None
         object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a cycle
-        if self.world > 1:
-            dist.broadcast(module.store.flat, src=0, group=self.group)
+        if self.active:
+            self._bcast(module.store.flat)
             self._sync_buffers(counters=True)
+
+    def _bcast(self, t: torch.Tensor):
+        if self.comm is not None and t.dtype == torch.float32:
+            self.comm.broadcast(t, 0)
+        else:
+            dist.broadcast(t, src=0, group=self.group)
 
     def _sync_buffers(self, counters: bool = False):
         """C2 of the reference's DDP (broadcast_buffers=True): rank 0's BatchNorm running statistics before every training
         forward — all 53 layers' means and variances live in one buffer, so this is ONE broadcast (~0.2 MB).  The
         num_batches_tracked counters advance identically on every rank; they are sent once, at wrap time."""
         m = self.module
-        dist.broadcast(m._rmv, src=0, group=self.group)
+        self._bcast(m._rmv)
         if counters:
             dist.broadcast(m._nbt, src=0, group=self.group)
 
     def forward(self, inp):
-        if self.world > 1 and self.broadcast_buffers and self.module.training:
+        if self.active and self.broadcast_buffers and self.module.training:
             self._sync_buffers()
         return self.module(inp)
 
     def make_reducer(self, spans) -> BucketReducer:
-        return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems, self.tail_elems), self.group)
+        return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems, self.tail_elems), self.group, self.comm)
 
 
 def reduce_dict(input_dict, average=False, all_ranks: bool = True):

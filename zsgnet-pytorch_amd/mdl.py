@@ -1262,7 +1262,7 @@ class _Plan:
         self.g5_in.view_as(g5).copy_(g5)
         ddp = getattr(net, "_ddp", None)
         self.prep.run(st)
-        if ddp is not None and ddp.world > 1:
+        if ddp is not None and ddp.active:
             # The reducer SUM-all-reduces the whole (accumulating) gradient buffer: a second backward before zero_grad would
             # reduce the first one's gradients again.  FusedAdam.zero_grad / dropping the p.grad clears the flag.
             if getattr(net, "_grad_reduced", False):
