@@ -17,7 +17,7 @@
 // lane stores 16 contiguous bytes.
 // A loader: lane (tile, 4-channel group g, patch row q) loads the 4 pixels of its patch row (4 x 16 B), applies the row
 // transform in registers and gets the column transform from its quad neighbours with DPP quad_perm (no LDS round trip),
-// then writes V[q][0..3] with four conflict-free ds_write_b128.  B loader: 16-byte copies of the pre-chunked U image
+// (one v_fmac with a DPP operand per value), then writes V[q][0..3] with four conflict-free ds_write_b128.  B loader: 16-byte copies of the pre-chunked U image
 // [c/8][p][n][8] (contiguous 2 KB runs).  LDS rows are 8 floats; the two 16-byte halves of a row are XOR-swizzled with
 // bit 3 of the row index, which makes the ds_read_b128 fragment reads (lane = row, half = k-group) conflict-free without
 // padding.  K permutation as in igemm.hip: value e of a lane's b128 feeds the e-th of four MFMAs.
@@ -47,11 +47,9 @@ struct WnParams {
 
 typedef __attribute__((address_space(3))) float lds_f32;
 
-__device__ __forceinline__ float quad_pick(float v, const int ctrl_is_x) {
-    // quad_perm [0,1,2,1] (x operand) / [2,2,1,3] (y operand) of the column transform B^T
-    const int iv = __builtin_bit_cast(int, v);
-    const int r = ctrl_is_x ? __builtin_amdgcn_mov_dpp(iv, 0x64, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(iv, 0xDA, 0xf, 0xf, true);
-    return __builtin_bit_cast(float, r);
+__device__ __forceinline__ float quad_other(float v) {
+    // quad_perm [2,2,1,1]: the patch row this lane's column transform combines its own row with
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
 }
 
 template <int TM, int TN>
@@ -158,23 +156,24 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, b + b_dst[ib], 16, 4 * (b_src[ib] + c * ustep), 0, 0, 0);
 #endif
     };
+    // Column transform B^T across the quad (lane q holds row q of d B): V[0] = t0 - t2, V[1] = t1 + t2, V[2] = t2 - t1 and
+    // V'[3] = t3 - t1 = -V[3] (zsg_wino_weights negates row 3 of U to match): every lane computes own + sgn * other with
+    // ONE cross-lane operand, i.e. one v_fmac_f32 with a DPP source per value.
     const float sgn = (q == 1) ? 1.f : -1.f;
     auto store_a = [&](int buf) {
         float* a = As + buf * 16 * SA;
 #pragma unroll
         for (int ia = 0; ia < IA; ++ia) {
-            // row transform (d B): this lane's patch row q
-            f32x4 t[4];
+            f32x4 t[4];                            // row transform (d B): this lane's patch row q
             t[0] = ra[ia][0] - ra[ia][2];
             t[1] = ra[ia][1] + ra[ia][2];
             t[2] = ra[ia][2] - ra[ia][1];
             t[3] = ra[ia][1] - ra[ia][3];
-            // column transform B^T across the quad: V[q] = t[ra(q)] +- t[rb(q)]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(quad_pick(t[j][e], 0), sgn, quad_pick(t[j][e], 1));
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(quad_other(t[j][e]), sgn, t[j][e]);
                 *(f32x4*)(a + a_lds[ia] + j * 4 * SA) = v;
             }
         }
@@ -190,32 +189,54 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
         load_b(c0, 0);
         load_a(c0, true);
         store_a(0);
+        if (ph == 1) load_a(c0 + 1, nc > 1);       // the late half transforms FIRST in every chunk: its next chunk is prefetched here
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frag_a = (wm * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SA;
     const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SB;
-    // One chunk: the loads of chunk it+1 are issued first (B by LDS-DMA into the idle buffer, A into registers) and have
-    // the whole MFMA phase to land; the A transform + LDS write is interleaved with the last quarter of the MFMAs.
-    for (int it = 0; it < nc; ++it) {
-        const float* a = As + (it & 1) * 16 * SA + frag_a;
-        const float* b = Bs + (it & 1) * 16 * SB + frag_b;
-        if (it + 1 < nc) load_b(c0 + it + 1, (it + 1) & 1);
-        load_a(c0 + it + 1, it + 1 < nc);
-        __builtin_amdgcn_sched_barrier(0);
+    auto mfma_pos = [&](const float* a, const float* b, int pl) {       // position p = j*4 + 2*ph + il, pl = j*2 + il
+        const int po = (pl >> 1) * 4 + (pl & 1);
+        const f32x4 fa = *(const f32x4*)(a + po * SA);
+        const f32x4 fb = *(const f32x4*)(b + po * SB);
 #pragma unroll
-        for (int pl = 0; pl < 8; ++pl) {           // position p = j*4 + 2*ph + il, pl = j*2 + il
-            const int po = (pl >> 1) * 4 + (pl & 1);
-            const f32x4 fa = *(const f32x4*)(a + po * SA);
-            const f32x4 fb = *(const f32x4*)(b + po * SB);
+        for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
+    };
+    // One chunk = MFMAs on buffer it&1 + (A transform, B LDS-DMA) of chunk it+1 into the other buffer; the two are
+    // independent between two barriers, so the two position halves — whose waves share the SIMDs pairwise (wave w and
+    // w + TM*TN) — run them in OPPOSITE order: while one half transforms (VALU / LDS writes) its partner issues MFMAs.
+    //   early half (ph 0): loads of chunk it+1 | 32 MFMAs | transform it+1        (load -> use: the MFMA phase)
+    //   late  half (ph 1): transform it+1 (loaded one chunk ago) | loads of chunk it+2 | 32 MFMAs
+    if (ph == 0) {
+        for (int it = 0; it < nc; ++it) {
+            const float* a = As + (it & 1) * 16 * SA + frag_a;
+            const float* b = Bs + (it & 1) * 16 * SB + frag_b;
+            if (it + 1 < nc) load_b(c0 + it + 1, (it + 1) & 1);
+            load_a(c0 + it + 1, it + 1 < nc);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
-            if (pl == 5) __builtin_amdgcn_sched_barrier(0);
+            for (int pl = 0; pl < 6; ++pl) mfma_pos(a, b, pl);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_pos(a, b, 6);
+            mfma_pos(a, b, 7);
+            store_a((it + 1) & 1);                 // (after the last chunk: zeros into the idle buffer)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        store_a((it + 1) & 1);                     // chunk it+1 (after the last chunk: zeros into the idle buffer)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    } else {
+        for (int it = 0; it < nc; ++it) {
+            const float* a = As + (it & 1) * 16 * SA + frag_a;
+            const float* b = Bs + (it & 1) * 16 * SB + frag_b;
+            if (it + 1 < nc) load_b(c0 + it + 1, (it + 1) & 1);
+            store_a((it + 1) & 1);
+            load_a(c0 + it + 2, it + 2 < nc);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pl = 0; pl < 8; ++pl) mfma_pos(a, b, pl);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     // ---- output transform: this wave's half of Y = A^T M A --------------------------------------------------------------
@@ -372,10 +393,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const WnWJob* jobs, in
         const float u1 = 0.5f * (tg[i][0] + tg[i][1] + tg[i][2]);
         const float u2 = 0.5f * (tg[i][0] - tg[i][1] + tg[i][2]);
         const float u3 = tg[i][2];
-        dst[(0 * 4 + i) * ps] = u0;
-        dst[(1 * 4 + i) * ps] = u1;
-        dst[(2 * 4 + i) * ps] = u2;
-        dst[(3 * 4 + i) * ps] = u3;
+        const float sg = (i == 3) ? -1.f : 1.f;      // the kernel's input transform produces -V for row 3 (see store_a)
+        dst[(0 * 4 + i) * ps] = sg * u0;
+        dst[(1 * 4 + i) * ps] = sg * u1;
+        dst[(2 * 4 + i) * ps] = sg * u2;
+        dst[(3 * 4 + i) * ps] = sg * u3;
     }
 }
 
