@@ -122,6 +122,13 @@ int64_t zsg_wino_u_elems(int32_t C, int32_t N);
  * rotated by 180 degrees, for the data gradient); blk0 = running sum of ceil(chunks*Npad*8 / 256). */
 int zsg_wino_weights(const void* jobs, int32_t njobs, int32_t total_blocks, void* stream);
 
+/* Winograd F(3x3,2x2) weight gradient of a 3x3 / stride 1 / pad 1 convolution: same contract as zsg_conv_wgrad (forward
+ * descriptor, accumulate flag, split-K workspace [splits][N][9*C] with the deterministic slab reduction), 16 instead of
+ * 36 multiply-adds per 2x2 output tile.  tile_hint: split_k << 16 (0: heuristic). */
+size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d);
+int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */
 int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t dst_ld, void* stream);

@@ -131,3 +131,75 @@ def test_wino_multilevel_window(Z):
         L.check(L.lib.zsg_conv_wino(C.byref(desc), packed.data_ptr(), U.data_ptr(), out.data_ptr(), bd.data_ptr(), ad.data_ptr(), None, None,
                                     L.stream_ptr()), "wino")
         assert_close(out, ref, 3e-4, 3e-4, f"multi-level wino {TB}x{BN}")
+
+
+WG_CASES = [
+    # B, Ci, Co, H, W, splits, accumulate
+    (2, 64, 64, 19, 19, 0, 0),
+    (2, 64, 128, 20, 17, 3, 1),
+    (3, 128, 64, 7, 10, 1, 0),
+    (2, 48, 256, 10, 10, 4, 0),
+    (2, 256, 45, 10, 10, 2, 1),
+    (2, 256, 256, 1, 1, 1, 0),
+    (16, 64, 64, 38, 38, 24, 0),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[f"g{i}" for i in range(len(WG_CASES))])
+def test_wino_wgrad(Z, case):
+    """zsg_conv_wgrad_wino (F(3x3,2x2)) vs autograd's conv2d weight gradient: rel 5e-4 of the gradient's max (the direct
+    kernel's bound)."""
+    L, ops = Z
+    from test_gpu_ops import WS
+    B, Ci, Co, H, W, splits, acc = case
+    g = torch.Generator().manual_seed(31 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).requires_grad_()
+    gy = torch.randn(B, Co, H, W, generator=g)
+    F.conv2d(x, w, None, 1, 1).backward(gy)
+    cp, Cop = pad4(Ci), pad4(Co)
+    xd, dyd = dev(nhwc(x)), dev(nhwc(gy, Cop))
+    src, dyv = view_of(ops, xd, B, H, W, cp), view_of(ops, dyd, B, H, W, Cop)
+    d = ops.fwd_desc(src, dyv, cp, Co, 3, 1, 1, 1, wC=cp, tile_hint=ops.tile_hint(64, 64, splits))
+    dw = torch.full((Co, 3, 3, cp), float(acc), device="cuda")
+    L.check(L.lib.zsg_conv_wgrad_wino(C.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad_wino")
+    assert_close(dw[..., :Ci].permute(0, 3, 1, 2) - acc, w.grad, 5e-4, 5e-4 * float(w.grad.abs().max()), "wino wgrad")
+    if cp > Ci:
+        assert float((dw[..., Ci:] - acc).abs().max()) == 0.0
+
+
+def test_wino_wgrad_multilevel_window(Z):
+    """all pyramid levels reduced in one launch into a channel window of a wider weight (head conv0: features only)"""
+    L, ops = Z
+    from test_gpu_ops import WS
+    g = torch.Generator().manual_seed(12)
+    B, Cf, Cw, Co = 2, 64, 12, 64
+    Ct = Cf + Cw
+    sizes = [(7, 7), (4, 4), (3, 3), (2, 2), (1, 1)]
+    xs = [torch.randn(B, Cf, h, ww, generator=g) for h, ww in sizes]
+    P = sum(h * ww for h, ww in sizes)
+    gy = torch.randn(B, P, Co, generator=g)
+    wr = (torch.randn(Co, Cf, 3, 3, generator=g) / 24).requires_grad_()
+    offs, o = [], 0
+    for h, ww in sizes:
+        offs.append(o)
+        o += h * ww
+    tot = sum((F.conv2d(x, wr, None, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Co) * gy[:, o:o + x.shape[2] * x.shape[3]]).sum() for x, o in zip(xs, offs))
+    tot.backward()
+    packed = torch.cat([nhwc(x).reshape(-1) for x in xs]).cuda()
+    lv_in, lv_dy, off_in, off_px = [], [], 0, 0
+    for (h, ww) in sizes:
+        lv_in.append(ops.Level(off_in, h, ww, h * ww * Cf))
+        lv_dy.append(ops.Level(off_px * Co, h, ww, P * Co))
+        off_in += B * h * ww * Cf
+        off_px += h * ww
+    src = ops.TView(packed, B, Cf, Cf, lv_in)
+    gyd = dev(gy)
+    dyv = ops.TView(gyd.view(-1), B, Co, Co, lv_dy)
+    dw = torch.zeros(Co, 3, 3, Ct, device="cuda")
+    for splits in (1, 2, 0):
+        dw.fill_(2.0)
+        d = ops.fwd_desc(src, dyv, Cf, Co, 3, 1, 1, 1, wC=Ct, wc0=0, tile_hint=ops.tile_hint(64, 64, splits))
+        L.check(L.lib.zsg_conv_wgrad_wino(C.byref(d), packed.data_ptr(), gyd.data_ptr(), dw.data_ptr(), 1, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad_wino")
+        assert_close(dw[..., :Cf].permute(0, 3, 1, 2) - 2.0, wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), f"multi-level wino wgrad splits={splits}")
+        assert float((dw[..., Cf:] - 2.0).abs().max()) == 0.0, "channels outside the window must stay untouched"

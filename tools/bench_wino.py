@@ -23,6 +23,9 @@ SHAPES = [
 ]
 
 
+WS = torch.empty(64 << 20, device="cuda") if torch.cuda.is_available() else None
+
+
 def timeit(fn, n=20):
     for _ in range(3):
         fn()
@@ -71,6 +74,24 @@ def main():
             d = ops.fwd_desc(src, out, Ci, Co, 3, 1, 1, 1, wC=Ci, tile_hint=TB | (BN << 8) | (sp << 16))
             t = timeit(lambda: check(lib.zsg_conv_wino(C.byref(d), x.data_ptr(), U.data_ptr(), y.data_ptr(), None, None, None, None, st), "wino"))
             line += f" wn[{TB}x{BN}/{sp}] {t * 1e3:6.1f}us {gf / t:6.1f}"
+        # weight gradient: direct (heuristic / a few splits) vs Winograd F(3x3,2x2)
+        dy = torch.randn(oo, device="cuda")
+        dw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        dyv = ops.TView(dy, B, Co, Co, lv_out)
+        if Co % 4 == 0:
+            line += " || wgrad"
+            best = 1e9
+            for hint in (0, ops.tile_hint(128, 128, 4, 1, 0), ops.tile_hint(128, 128, 8, 1, 0), ops.tile_hint(64, 64, 32), ops.tile_hint(128, 64, 16)):
+                d = ops.fwd_desc(src, dyv, Ci, Co, 3, 1, 1, 1, wC=Ci, tile_hint=hint)
+                t = timeit(lambda: check(lib.zsg_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wg"))
+                best = min(best, t)
+            line += f" direct-best {best * 1e3:6.1f}us {gf / best:6.1f} |"
+            nmn = ((Co + 63) // 64) * ((Ci + 63) // 64)
+            for target in (128, 256, 384, 512):
+                sp = max(1, min(target // nmn, 255))
+                d = ops.fwd_desc(src, dyv, Ci, Co, 3, 1, 1, 1, wC=Ci, tile_hint=ops.tile_hint(64, 64, sp))
+                t = timeit(lambda: check(lib.zsg_conv_wgrad_wino(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, st), "wgw"))
+                line += f" ww[/{sp}] {t * 1e3:6.1f}us {gf / t:6.1f}"
         print(line, flush=True)
 
 

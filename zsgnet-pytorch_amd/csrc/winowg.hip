@@ -1,0 +1,325 @@
+// winowg.hip — Winograd F(3x3, 2x2) weight gradient of the 3x3 / stride 1 / pad 1 convolutions on fp32 MFMA, gfx950.
+//
+// dW[n][c][u][v] = sum_{b,y,x} dY[b][y][x][n] * X[b][y+u-1][x+v-1][c]  is, per 2x2 tile of dY and the 4x4 input patch
+// around it, a correlation of a 4x4 signal with a 2x2 "filter" producing 3x3 outputs — the transposed form of the forward
+// F(2x2,3x3) algorithm (same 4x4 transformed domain, 16 multiplies per tile instead of 36):
+//
+//   dW = G^T [ sum_tiles (A dy A^T) .* (B^T d B) ] G        A = [[1,0],[1,1],[1,-1],[0,-1]],  G, B^T as in wino.hip
+//
+// GEMM view: 16 independent GEMMs (positions p = j*4 + i) with M = output channels n, N = input channels c and
+// K = tiles, 8 tiles per LDS stage; both operands are transformed ON THE FLY while staging (lane (tile, 4-channel
+// group, row q): the dY transform is in-lane, the input transform gets its column step from the quad neighbours with
+// DPP, as in wino.hip; row 3 of both transforms is produced negated, which cancels in the product).  Operands are
+// "MN-contiguous" ([k][m] LDS tiles, ds_read_b32 fragments, like wgrad.hip).  A 512-thread workgroup owns a 64 x 64
+// (n, c) block of all 16 positions for its slice of the tiles (split-K over tiles, deterministic slab reduction with
+// wgrad_reduce_kernel); wave (ph, wm, wn) holds the 8 positions with i in {2ph, 2ph+1} of one 32x32 sub-block; the
+// output transform is linear, so each position half transforms its own share and the two are added through LDS.
+#include "wgrad_common.h"
+
+#define WW_KT 8                       // tiles per stage
+#define WW_SP (WW_KT * 64 + 8)        // floats between positions (+8: conflict-free quad writes)
+
+struct WwSegDev {
+    int tiles_y, tiles_x, tiles, st0;
+    int H, W;
+    int src_off, src_bstride, dy_off, dy_bstride;
+    float inv_per, inv_tx;
+};
+
+struct WwParams {
+    const float* src;
+    const float* dy;
+    float* dw;
+    float* ws;
+    int accumulate;
+    int C, N, src_ld, dy_ld, wC, wc0, wt_ld, nseg;
+    int m_tiles, n_tiles, splits, st_total, st_chunk;
+    WwSegDev seg[ZSG_MAX_SEG];
+};
+
+__device__ __forceinline__ float ww_quad_other(float v) {      // quad_perm [2,2,1,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
+    constexpr int SP = WW_SP;
+    extern __shared__ __attribute__((aligned(16))) float ww_smem[];
+    float* Ps = ww_smem;                       // [2][16][SP]   transformed dY   [pos][tile][n]
+    float* Vs = ww_smem + 2 * 16 * SP;         // [2][16][SP]   transformed input [pos][tile][c]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nmn = p.m_tiles * p.n_tiles;
+    const int split = blockIdx.x / nmn;
+    const int mn = xcd_remap(blockIdx.x % nmn, nmn);
+    const int mt = mn / p.n_tiles, nt = mn % p.n_tiles;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const int st_begin = split * p.st_chunk;
+    const int st_end = min(p.st_total, st_begin + p.st_chunk);
+    const int n_st = st_end - st_begin;
+
+    // ---- loader: this wave stages tile `wave` of every stage; lane = (4-channel group g, patch row q) ----------------
+    const int q = lane & 3, g = lane >> 2;
+    const int a_col = m0 + 4 * g, b_col = n0 + 4 * g;
+    const bool a_colok = a_col < p.N, b_colok = b_col < p.C;
+    const rsrc_t rs_a = make_rsrc(p.dy);
+    const rsrc_t rs_b = make_rsrc(p.src);
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < ZSG_MAX_SEG; ++s)
+        if (s < p.nseg && st_begin >= p.seg[s].st0) si = s;
+    WwSegDev sg = p.seg[si];
+    int st_next = st_begin;
+
+    f32x4 rd[4], rx[4];
+    auto load_stage = [&](bool live) {
+        if (si + 1 < p.nseg && st_next >= p.seg[si + 1].st0) {     // wave-uniform segment switch
+            ++si;
+            sg = p.seg[si];
+        }
+        const int t = (st_next - sg.st0) * WW_KT + wave;
+        const bool tok = live & (t < sg.tiles);
+        const int tt = tok ? t : 0;
+        const int per = sg.tiles_y * sg.tiles_x;
+        const int b = fdiv(tt, per, sg.inv_per);
+        const int rem = tt - b * per;
+        const int ty = fdiv(rem, sg.tiles_x, sg.inv_tx);
+        const int tx = rem - ty * sg.tiles_x;
+        // dY tile: pixels (2ty + a, 2tx + bb)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int y = 2 * ty + a, x = 2 * tx + bb;
+                const bool ok = tok & a_colok & (y < sg.H) & (x < sg.W);
+                const unsigned off = 4u * (unsigned)(sg.dy_off + b * sg.dy_bstride + (y * sg.W + x) * p.dy_ld + a_col);
+                rd[a * 2 + bb] = buf_load4(rs_a, ok ? off : ZSG_OOB);
+            }
+        // input patch row q: pixels (2ty - 1 + q, 2tx - 1 + col)
+        const int y = 2 * ty - 1 + q;
+        const bool rok = tok & b_colok & ((unsigned)y < (unsigned)sg.H);
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const int x = 2 * tx - 1 + col;
+            const bool ok = rok & ((unsigned)x < (unsigned)sg.W);
+            const unsigned off = 4u * (unsigned)(sg.src_off + b * sg.src_bstride + (y * sg.W + x) * p.src_ld + b_col);
+            rx[col] = buf_load4(rs_b, ok ? off : ZSG_OOB);
+        }
+        ++st_next;
+    };
+    // dY transform A dy A^T, row q in-lane: rows (dy0, dy0 + dy1, dy0 - dy1, +dy1 [negated]) = alpha*dy0 + beta*dy1
+    const float alpha = (q == 3) ? 0.f : 1.f;
+    const float beta = (q == 0) ? 0.f : ((q == 2) ? -1.f : 1.f);
+    const float sgn = (q == 1) ? 1.f : -1.f;     // input transform: V[q] = own + sgn * other (row 3 negated), see wino.hip
+    const int lds_w = q * SP + wave * 64 + 4 * g;
+    auto store_stage = [&](int buf) {
+        float* ps = Ps + buf * 16 * SP + lds_w;
+        float* vs = Vs + buf * 16 * SP + lds_w;
+        f32x4 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r0[e] = fmaf(beta, rd[2][e], alpha * rd[0][e]);
+            r1[e] = fmaf(beta, rd[3][e], alpha * rd[1][e]);
+        }
+        *(f32x4*)(ps) = r0;                      // j = 0
+        *(f32x4*)(ps + 4 * SP) = r0 + r1;        // j = 1
+        *(f32x4*)(ps + 8 * SP) = r0 - r1;        // j = 2
+        *(f32x4*)(ps + 12 * SP) = -r1;           // j = 3
+        f32x4 t[4];
+        t[0] = rx[0] - rx[2];
+        t[1] = rx[1] + rx[2];
+        t[2] = rx[2] - rx[1];
+        t[3] = rx[1] - rx[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(ww_quad_other(t[j][e]), sgn, t[j][e]);
+            *(f32x4*)(vs + j * 4 * SP) = v;
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    if (n_st > 0) {
+        load_stage(true);
+        store_stage(0);
+    }
+    __syncthreads();
+
+    const int frag_a = 2 * ph * SP + lh * 64 + wm * 32 + li;
+    const int frag_b = 2 * ph * SP + lh * 64 + wn * 32 + li;
+    auto mfma_pos = [&](const float* a, const float* b, int pl) {       // position p = j*4 + 2*ph + il, pl = j*2 + il
+        const int po = ((pl >> 1) * 4 + (pl & 1)) * SP;
+#pragma unroll
+        for (int ks = 0; ks < WW_KT / 2; ++ks)
+            acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[po + ks * 128], b[po + ks * 128], acc[pl], 0, 0, 0);
+    };
+    for (int it = 0; it < n_st; ++it) {
+        const float* a = Ps + (it & 1) * 16 * SP + frag_a;
+        const float* b = Vs + (it & 1) * 16 * SP + frag_b;
+        load_stage(it + 1 < n_st);                 // (past the end: out-of-range offsets, zeros)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl) mfma_pos(a, b, pl);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pos(a, b, 6);
+        mfma_pos(a, b, 7);
+        store_stage((it + 1) & 1);
+        __syncthreads();
+    }
+    if (n_st <= 0) return;
+
+    // ---- output transform dW = G^T M G, this wave's rows i of M; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] ----------------
+    // z[il][v] = sum_j M[i][j] G[j][v];  partial dW[u][v] = sum_il G[2ph+il][u] z[il][v]
+    float* xch = ww_smem;                           // [4 sub-blocks][48][64 lanes] exchange buffer (3 taps x 16 elements)
+    const int sub = wave & 3;
+    float* dst = p.ws ? p.ws + (size_t)split * p.N * (9 * p.C) : p.dw;
+    const int ld = p.ws ? 9 * p.C : p.wt_ld;
+    const int tap_ld = p.ws ? p.C : p.wC;
+    const int c = n0 + wn * 32 + li;
+    const bool cok = c < p.C;
+    const int col0 = p.ws ? c : (p.wc0 + c);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        float part[3][16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float z0[3], z1[3];
+            {
+                const float m0_ = acc[0][e], m1 = acc[2][e], m2 = acc[4][e], m3 = acc[6][e];
+                const float h = 0.5f * (m1 + m2);
+                z0[0] = m0_ + h; z0[1] = 0.5f * (m1 - m2); z0[2] = h + m3;
+            }
+            {
+                const float m0_ = acc[1][e], m1 = acc[3][e], m2 = acc[5][e], m3 = acc[7][e];
+                const float h = 0.5f * (m1 + m2);
+                z1[0] = m0_ + h; z1[1] = 0.5f * (m1 - m2); z1[2] = h + m3;
+            }
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                float y;
+                if (ph == 0) y = (u == 0) ? z0[v] + 0.5f * z1[v] : 0.5f * z1[v];                       // rows i = 0, 1
+                else y = (u == 0) ? 0.5f * z0[v] : ((u == 1) ? -0.5f * z0[v] : 0.5f * z0[v] + z1[v]);  // rows i = 2, 3
+                part[v][e] = y;
+            }
+        }
+        if (ph == 1) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xch[(sub * 48 + v * 16 + e) * 64 + lane] = part[v][e];
+        }
+        __syncthreads();
+        if (ph == 0) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float val = part[v][e] + xch[(sub * 48 + v * 16 + e) * 64 + lane];
+                    if (cok && n < p.N) {
+                        float* o = dst + (size_t)n * ld + (u * 3 + v) * tap_ld + col0;
+                        *o = (!p.ws && p.accumulate) ? *o + val : val;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d) {
+    if (!d) return 0;
+    int splits = (d->tile_hint >> 16) & 0xff;
+    if (splits <= 0) splits = 64;
+    return (size_t)splits * d->N * 9 * d->C * sizeof(float);
+}
+
+// Same contract as zsg_conv_wgrad (forward descriptor, dy in the "out" geometry, accumulate flag, split-K workspace,
+// deterministic slab reduction); 3x3 / stride 1 / pad 1 only.  tile_hint: split_k << 16 (0: heuristic).
+extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad_wino: null argument");
+    ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad_wino: nseg=%d", d->nseg);
+    ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0 && (d->out_ld % 4) == 0,
+                "conv_wgrad_wino: C=%d src_ld=%d wC=%d wc0=%d out_ld=%d must be multiples of 4", d->C, d->src_ld, d->wC, d->wc0, d->out_ld);
+    ZSG_REQUIRE(d->wR == 3 && d->wS == 3 && !d->merge_x, "conv_wgrad_wino: 3x3 filters only");
+    WwParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = src; p.dy = dy; p.dw = dw; p.accumulate = accumulate ? 1 : 0;
+    p.C = d->C; p.N = d->N; p.src_ld = d->src_ld; p.dy_ld = d->out_ld; p.wC = d->wC; p.wc0 = d->wc0; p.wt_ld = d->wt_ld; p.nseg = d->nseg;
+    int st = 0;
+    double rows_all = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const zsg_seg& a = d->seg[s];
+        ZSG_REQUIRE(a.ty.n == 3 && a.tx.n == 3 && a.sy == 1 && a.sx == 1 && a.osy == 1 && a.osx == 1 && a.opy == 0 && a.opx == 0 &&
+                        a.ty.d0 == -1 && a.tx.d0 == -1 && a.ty.dstep == 1 && a.tx.dstep == 1 && a.ty.w0 == 0 && a.tx.w0 == 0 &&
+                        a.ty.wstep == 1 && a.tx.wstep == 1,
+                    "conv_wgrad_wino: seg %d is not a 3x3 / stride 1 / pad 1 forward descriptor", s);
+        ZSG_REQUIRE(a.rows_y == a.src_H && a.rows_x == a.src_W && a.out_W == a.rows_x, "conv_wgrad_wino: seg %d: dy grid must equal the input grid", s);
+        const int64_t tiles = (int64_t)d->B * ((a.src_H + 1) / 2) * ((a.src_W + 1) / 2);
+        ZSG_REQUIRE(tiles > 0 && tiles < (1ll << 24), "conv_wgrad_wino: seg %d tiles=%lld (must be < 2^24)", s, (long long)tiles);
+        ZSG_REQUIRE(a.src_off + (int64_t)d->B * a.src_bstride < (1ll << 29) && a.out_off + (int64_t)d->B * a.out_bstride < (1ll << 29),
+                    "conv_wgrad_wino: tensor exceeds 2^29 elements (2 GB window)");
+        ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0 && (a.out_off % 4) == 0 && (a.out_bstride % 4) == 0,
+                    "conv_wgrad_wino: seg %d operands not 16-byte aligned", s);
+        WwSegDev& o = p.seg[s];
+        o.tiles_y = (a.src_H + 1) / 2; o.tiles_x = (a.src_W + 1) / 2; o.tiles = (int)tiles; o.st0 = st;
+        o.H = a.src_H; o.W = a.src_W;
+        o.src_off = (int)a.src_off; o.src_bstride = (int)a.src_bstride; o.dy_off = (int)a.out_off; o.dy_bstride = (int)a.out_bstride;
+        o.inv_per = 1.0f / (float)(o.tiles_y * o.tiles_x);
+        o.inv_tx = 1.0f / (float)o.tiles_x;
+        st += cdiv(tiles, WW_KT);
+        rows_all += (double)d->B * a.src_H * a.src_W;
+    }
+    p.st_total = st;
+    p.m_tiles = cdiv(d->N, 64);
+    p.n_tiles = cdiv(d->C, 64);
+    const int nmn = p.m_tiles * p.n_tiles;
+    int splits = (d->tile_hint >> 16) & 0xff;
+    if (splits <= 0) splits = (ZSG_NUM_CU + nmn - 1) / nmn;
+    if (splits > st / 2) splits = st / 2;
+    if (splits < 1) splits = 1;
+    p.st_chunk = cdiv(st, splits);
+    p.splits = cdiv(st, p.st_chunk);
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * d->N * 9 * d->C * sizeof(float);
+        if (!ws || ws_bytes < need) ZSG_FAIL(-2, "conv_wgrad_wino: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+        p.ws = (float*)ws;
+    }
+    hipStream_t stq = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * 16 * WW_SP * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) ZSG_FAIL(-3, "wgrad_wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    {
+        ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, 0);
+        hipLaunchKernelGGL(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
+    }
+    if (p.splits > 1) {        // fixed-order slab sum -> dw (shared with the direct kernel)
+        WgParams r;
+        memset(&r, 0, sizeof(r));
+        r.dw = dw; r.ws = p.ws; r.accumulate = p.accumulate;
+        r.C = d->C; r.N = d->N; r.wS = 3; r.wC = d->wC; r.wc0 = d->wc0; r.wt_ld = d->wt_ld;
+        r.ncols = 9 * d->C; r.txn = 3; r.splits = p.splits;
+        r.ty = d->seg[0].ty; r.tx = d->seg[0].tx;
+        const int64_t total4 = (int64_t)d->N * (r.ncols / 4);
+        ZSG_PROF("wgrad_reduce_kernel", stq, 0, (double)(p.splits + 1) * d->N * r.ncols * 4);
+        if (p.splits >= 32 || total4 < 65536)
+            hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((int)cdiv(total4, 16)), dim3(256), 0, stq, r);
+        else
+            hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((int)cdiv(total4, 64)), dim3(256), 0, stq, r);
+    }
+    ZSG_CHECK_LAUNCH("conv_wgrad_wino");
+    return 0;
+}

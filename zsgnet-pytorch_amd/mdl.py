@@ -639,11 +639,12 @@ class _Plan:
         trial launches write a scratch image, never the gradient buffer."""
         gw = self.G(pname)
         args = (src.buf, dy.buf, gw, 1, self.wg_ws, self.wg_ws_bytes)
-        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, (src.buf, dy.buf, self.tune_dw, 0, self.wg_ws, self.wg_ws_bytes), stream_ptr(),
-                      self.wg_ws_bytes)
-        if not d.tile_hint:          # autotune disabled: make sure the heuristic's slabs fit
-            assert lib.zsg_conv_wgrad_workspace_bytes(d) <= self.wg_ws_bytes or True
-        self.bwd.add(lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
+        targs = (src.buf, dy.buf, self.tune_dw, 0, self.wg_ws, self.wg_ws_bytes)
+        s0 = d.seg[0]
+        wino = (d.wR == 3 and d.wS == 3 and s0.sy == 1 and s0.ty.d0 == -1 and s0.ty.dstep == 1 and not d.merge_x
+                and dy.ld % 4 == 0 and wino_mode() != "0")       # 3x3 / stride 1 / pad 1: Winograd F(3x3,2x2) candidates
+        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
+        self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""

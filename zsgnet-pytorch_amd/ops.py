@@ -417,7 +417,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         wino_args = None
     no_tune = os.environ.get("ZSG_AUTOTUNE", "1") == "0" or not torch.cuda.is_available()
     if wino_args is not None and (mode == "force" and no_tune):
-        d.tile_hint, d.use_wino = wino_default_hint(d), True
+        d.tile_hint, d.use_wino = (wino_default_hint(d) if kind == "igemm" else 0), True
         return d.tile_hint | WINO_FLAG
     if no_tune:
         return 0
@@ -463,9 +463,19 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                             cands.append(tile_hint(bm, bn, sp, 1, 0))          # 8-wave workgroup
                             cands.append(tile_hint(bm, bn, sp, 1, 1))
     trials = [] if mode == "force" else [(fn, marshal(fn, (d,) + tuple(args)), h, 0) for h in cands]
-    if wino_args is not None:
+    if wino_args is not None and kind == "igemm":
         wconv = marshal(lib.zsg_conv_wino, (d,) + tuple(wino_args))
         trials += [(lib.zsg_conv_wino, wconv, h, WINO_FLAG) for h in _wino_cands(d)]
+    elif wino_args is not None:           # weight gradient: zsg_conv_wgrad_wino, split-K over 8-tile stages
+        wconv = marshal(lib.zsg_conv_wgrad_wino, (d,) + tuple(wino_args))
+        tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
+        nmn = ((d.N + 63) // 64) * ((d.C + 63) // 64)
+        seen = set()
+        for target in (128, 192, 256, 384, 512, 768):
+            sp = max(1, min(target // nmn, tiles // 16, 255))
+            if sp not in seen and sp * d.N * 9 * d.C * 4 <= ws_bytes:
+                seen.add(sp)
+                trials.append((lib.zsg_conv_wgrad_wino, wconv, tile_hint(64, 64, sp), WINO_FLAG))
     best, best_t = 0, float("inf")
     for f, conv, h, flag in trials:
         d.tile_hint = h
