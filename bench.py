@@ -9,10 +9,18 @@ A "step" is the reference's hot loop body, utils.py:407-414: zero_grad -> ZSGNet
 img ~ U[0,1) 300x300, 20-token queries, per-GPU batch 16 = BASELINE configs[1]).  W warm-up steps, then exactly K timed
 steps between barrier + torch.cuda.synchronize(); MAX over ranks; rank 0 prints ONE JSON line.
 
+`median_ms_per_step` comes from HIP events recorded at the step boundaries INSIDE the timed region (no extra sync).
+
 Extra legs (rank 0, outside the timed region):
   roofline     — per-launch HIP-event timing of every kernel (zsg_prof_*, entries named as rocprofv3 names them); the
-                 kernel with the largest share is reported as achieved TFLOP/s = algorithmic 2*MAC / event time against the
-                 157.3 TFLOP/s fp32-MFMA peak: with every launch alone on the GPU (primary) and as timed (side stream on).
+                 kernel with the largest share is reported as achieved TFLOP/s = ALGORITHMIC 2*MAC (direct convolution) /
+                 event time against the 157.3 TFLOP/s fp32-MFMA peak: with every launch alone on the GPU (primary) and as
+                 timed (side stream on).  The Winograd kernels (wino_kernel, wino_wgrad_kernel) execute 4/9 of the
+                 algorithmic multiply-adds on the MFMA pipe, so their algorithmic fraction can exceed 1; `mfma_executed`
+                 gives the pipe's own utilisation (algorithmic x 4/9).  `traffic` (HBM bytes per launch, rocprofv3 --pmc
+                 FETCH_SIZE x2 + WRITE_SIZE) is read from profiles/<round>_hbm_traffic.json ONLY when that file was
+                 produced from the same kernel sources (sha256 stamp), else null.
+  forward      — train-mode forward only (the north_star's ">= 70 % on the ResNet-50+FPN forward"): HIP-event median.
   cpu_baseline — the CPU oracle's same step (torch-CPU fp32, B=4) on the host cores ("port"); N=1 only.
 """
 import argparse
@@ -30,6 +38,24 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GF = {"resnet50": 32.569, "resnet101": None, "resnet18": None, "ssd_vgg": 75.003}     # BASELINE.md §3 (conv 2*MAC per image @300^2)
 PEAK_TF = 157.3                                                         # fp32-input MFMA, MI355X_MICROARCH.md
+ROUND = "r02"
+
+
+def exec_ratio(kernel: str) -> float:
+    """MFMA multiply-adds executed / algorithmic (direct-convolution) multiply-adds"""
+    return 4.0 / 9.0 if kernel.startswith(("wino_kernel", "wino_wgrad_kernel")) else 1.0
+
+
+def source_stamp() -> str:
+    """sha256 over the kernel sources: ties a committed rocprof summary to the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "zsgnet-pytorch_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -127,12 +153,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         ls, em = step()
+        marks[i + 1].record()               # (an event record is ~1 us of host time and no synchronisation)
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    median_ms = per_step[len(per_step) // 2]
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,19 +207,29 @@ def main():
         prof_rows, tot = profiled(2, zops.SIDE_STREAM)
         dom = iso_rows[0]
         timed = next((r for r in prof_rows if r["kernel"] == dom["kernel"]), None)
-        traffic, rp_avg, rp_ser = None, None, None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")       # written by tools/rocprof_round.sh
+        traffic, rp_avg, rp_ser, tnote = None, None, None, None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        tfile = os.path.join(ROOT, "profiles", f"{ROUND}_hbm_traffic.json")       # written by tools/rocprof_round.sh at the same sources
         if os.path.exists(tfile):
             try:
-                ent = json.load(open(tfile)).get(dom["kernel"], {})
-                traffic, rp_avg, rp_ser = ent.get("hbm_bytes_per_launch"), ent.get("rocprof_avg_ms"), ent.get("rocprof_avg_ms_serial")
-            except Exception:
-                traffic = None
+                tj = json.load(open(tfile))
+                if tj.get("_source_stamp") == source_stamp():
+                    ent = tj.get(dom["kernel"], {})
+                    traffic, rp_avg, rp_ser = ent.get("hbm_bytes_per_launch"), ent.get("rocprof_avg_ms"), ent.get("rocprof_avg_ms_serial")
+                else:
+                    tnote = f"{os.path.basename(tfile)} was measured on other kernel sources (stamp {tj.get('_source_stamp')} != {source_stamp()}): not used"
+            except Exception as e:
+                tnote = f"unreadable traffic file: {e}"
+        else:
+            tnote = "no rocprofv3 --pmc summary for this round (tools/rocprof_round.sh)"
         flops_all = sum((r["tflops"] or 0) * r["ms_per_step"] for r in iso_rows)         # GFLOP per step over all MFMA kernels
         mfma_ms = sum(r["ms_per_step"] for r in iso_rows if r["tflops"])
+        exe_all = sum((r["tflops"] or 0) * r["ms_per_step"] * exec_ratio(r["kernel"]) for r in iso_rows)
         if dom["tflops"]:
+            er = exec_ratio(dom["kernel"])
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": traffic,
+                    "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": traffic, "traffic_note": tnote,
+                    "flops": "algorithmic 2*MAC of the direct convolution" + (" (Winograd F(2x2,3x3): 4/9 of them are executed)" if er < 1 else ""),
+                    "mfma_executed": {"achieved": round(dom["tflops"] * er, 2), "frac": round(dom["tflops"] * er / PEAK_TF, 4)},
                     "avg_launch_ms": round(dom["ms_per_step"] / dom["launches_per_step"], 5), "launches_per_step": dom["launches_per_step"],
                     "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(iso_tot, 3),
                     "rocprof_avg_launch_ms": rp_ser, "mode": "one stream (ZSG_SIDE_STREAM=0): every launch alone on the GPU",
@@ -198,13 +239,33 @@ def main():
                                  "mode": "weight-gradient kernels co-running on the side stream"} if timed and timed["tflops"] else None,
                     "all_mfma_kernels": {"achieved": round(flops_all / mfma_ms, 2) if mfma_ms else None,
                                          "frac": round(flops_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
-                                         "ms_per_step": round(mfma_ms, 3)}}
+                                         "mfma_executed_frac": round(exe_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
+                                         "ms_per_step": round(mfma_ms, 3)},
+                    "top_kernels": [{"kernel": r["kernel"], "ms_per_step": round(r["ms_per_step"], 3), "launches_per_step": r["launches_per_step"],
+                                     "tflops": round(r["tflops"], 1) if r["tflops"] else None, "gbps": round(r["gbps"], 0) if r["gbps"] else None}
+                                    for r in iso_rows[:8]]}
         else:
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": traffic}
         if a.prof_out and rank == 0:
             with open(a.prof_out, "w") as f:
                 json.dump({"as_timed": prof_rows, "isolated": iso_rows}, f, indent=1)
+    fwd = None
+    if not a.no_roofline:          # every rank (the training forward of a DDP model broadcasts the BatchNorm buffers)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        with torch.no_grad():
+            model(batch)
+            torch.cuda.synchronize()
+            evs[0].record()
+            for i in range(20):
+                model(batch)
+                evs[i + 1].record()
+        torch.cuda.synchronize()
+        fm = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))[10]
+        fgf = FWD_GF.get(a.arch) if a.img == 300 else None
+        fwd = {"median_ms": round(fm, 3), "images_per_s": round(a.bs / fm * 1e3, 1),
+               "mfma_frac": round(a.bs * fgf * 1e9 / (fm * 1e-3) / (PEAK_TF * 1e12), 4) if fgf else None,
+               "what": "train-mode ZSGNet.forward only (batch-statistics BatchNorm), algorithmic conv FLOPs / fp32-MFMA peak"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.arch, a.img, a.tokens)
@@ -214,13 +275,14 @@ def main():
         step_frac = (ips / world) * (3 * fwd_gf) * 1e9 / (PEAK_TF * 1e12) if fwd_gf else None
         out = {
             "metric": "train images/sec", "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "median_ms_per_step": round(median_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (img~U[0,1), qvec~N(0,.35), random boxes; random-init weights)",
             "config": {"workload": f"ZSGNet train step, {a.arch + '+FPN' if a.backbone == 'retina' else 'SSD-VGG16'}, {a.img}x{a.img}, per-GPU bs={a.bs}, {a.tokens}-token queries "
                                    f"(BASELINE configs[{3 if a.backbone == 'ssd_vgg' else (1 if world == 1 else 2)}] shape)", "global_batch": a.bs * world,
                        "parallelism": f"dp{world}", "step": "zero_grad+fwd+loss+bwd(+allreduce)+adam+eval"},
             "step_mfma_frac": round(step_frac, 4) if step_frac else None,
             "final_loss": round(loss_val, 4), "final_acc": acc,
+            "forward": fwd, "source_stamp": source_stamp(),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

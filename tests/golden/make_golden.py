@@ -284,6 +284,54 @@ def main():
          g_conv2=blk.conv2.weight.grad.numpy()[::2, ::2], g_bn3_w=blk.bn3.weight.grad.numpy(), g_bn3_b=blk.bn3.bias.grad.numpy(),
          g_ds=blk.downsample[0].weight.grad.numpy()[::4, ::4], rm_bn2=blk.bn2.running_mean.numpy(), rv_bn2=blk.bn2.running_var.numpy())
 
+    # ---- G8b FPN 600x600 branch (fpn_resnet.py:173-174: p3 is computed and dropped, four levels) -----------------------
+    cfg600 = type(fpn.cfg)(dict(fpn.cfg)) if not isinstance(fpn.cfg, dict) else dict(fpn.cfg)
+    cfg600["resize_img"] = [600, 600]
+    keep_cfg = fpn.cfg
+    fpn.cfg = cfg600
+    g6 = torch.Generator().manual_seed(23)
+    c3b = torch.randn(1, 512, 75, 75, generator=g6)
+    c4b = torch.randn(1, 1024, 38, 38, generator=g6)
+    c5b = torch.randn(1, 2048, 19, 19, generator=g6)
+    with torch.no_grad():
+        outs6 = fpn([c3b, c4b, c5b])
+    fpn.cfg = keep_cfg
+    assert len(outs6) == 4
+    save("g8_fpn600", seed=np.array([3]), in_seed=np.array([23]), sizes=np.array([list(o.shape[2:]) for o in outs6]),
+         **{f"p{i}": (o.numpy() if o.numel() < 40000 else o.numpy()[:, ::8, ::3, ::3]) for i, o in enumerate(outs6)})
+
+    # ---- G8c BasicBlock encoder (fpn_resnet.py:26-58; ResNet(1, BasicBlock, [2,2,2,2]) = the resnet18 stand-in) ---------
+    sd18 = O.seeded_state_dict("resnet18", seed=9)
+    enc18 = FR.ResNet(1, FR.BasicBlock, [2, 2, 2, 2])
+    pre18 = "backbone.encoder."
+    res18 = enc18.load_state_dict({k[len(pre18):]: v for k, v in sd18.items() if k.startswith(pre18)}, strict=False)
+    assert not res18.unexpected_keys and all(k.startswith("fpn.") or k.startswith("fc.") for k in res18.missing_keys), res18
+    enc18.train()
+    g8 = torch.Generator().manual_seed(29)
+    blk18 = enc18.layer2[0]                   # stride-2 BasicBlock with downsample
+    xk = torch.randn(2, 64, 14, 14, generator=g8).requires_grad_()
+    yk = blk18(xk)
+    gyk = torch.randn(yk.shape, generator=g8)
+    enc18.zero_grad()
+    (yk * gyk).sum().backward()
+    d18 = dict(seed=np.array([9]), x=xk.detach().numpy(), gy=gyk.numpy(), y=yk.detach().numpy(), gx=xk.grad.numpy(),
+               g_conv1=blk18.conv1.weight.grad.numpy()[::2, ::2], g_conv2=blk18.conv2.weight.grad.numpy()[::2, ::2],
+               g_bn2_w=blk18.bn2.weight.grad.numpy(), g_ds=blk18.downsample[0].weight.grad.numpy(),
+               rm_bn1=blk18.bn1.running_mean.numpy().copy(), rv_bn1=blk18.bn1.running_var.numpy().copy())
+    # the whole BasicBlock trunk on a small image: stem -> layer1..4 (train-mode BN), the taps the FPN reads
+    enc18b = FR.ResNet(1, FR.BasicBlock, [2, 2, 2, 2])
+    enc18b.load_state_dict({k[len(pre18):]: v for k, v in sd18.items() if k.startswith(pre18)}, strict=False)
+    enc18b.train()
+    img18 = torch.rand(2, 3, 96, 80, generator=g8)
+    with torch.no_grad():
+        t = enc18b.maxpool(enc18b.relu(enc18b.bn1(enc18b.conv1(img18))))
+        t1 = enc18b.layer1(t)
+        t2 = enc18b.layer2(t1)
+        t3 = enc18b.layer3(t2)
+        t4 = enc18b.layer4(t3)
+    d18.update(img=img18.numpy(), c3=t2.numpy()[:, ::4], c4=t3.numpy()[:, ::8], c5=t4.numpy()[:, ::16])
+    save("g8_basicblock", **d18)
+
     # ---- G9 head ordering on a 5x5 level ----------------------------------------------------
     xh = torch.randn(2, 514, 5, 5, generator=gf)
     with torch.no_grad():
@@ -337,6 +385,49 @@ def main():
         for k in keep:
             d["grad__" + k] = grads[k].numpy()
         save("g10_" + tag, **d)
+    # ---- G10b end-to-end at the BENCHMARK batch (configs[1]: B=16, 300x300): outputs sub-sampled, every gradient norm -----
+    if not ONLY or any("g10_e2e_300_b16".startswith(o) for o in ONLY):
+        sd = O.seeded_state_dict("resnet50", seed=7)
+        net = M.get_default_net(num_anchors=9, cfg=cfg)
+        net.load_state_dict(sd, strict=False)
+        net.train()
+        bt = O.synthetic_batch(16, 300, 300, seed=4321)
+        gq = torch.Generator().manual_seed(56)
+        h0 = torch.randn(2, 16, 128, generator=gq)
+        c0 = torch.randn(2, 16, 128, generator=gq)
+        net.lstm_init_hidden = lambda bs: (h0, c0)
+        out = net(bt)
+        fs = [tuple(int(v) for v in r) for r in out["feat_sizes"].tolist()]
+        anc = A.create_anchors(fs, ratios, scales, device=cpu).float()
+        lf = L.get_default_loss(ratios, scales, cfg)
+        ev = E.get_default_eval(ratios, scales, cfg)
+        lf.anchs = anc
+        ev.anchs = anc
+        ls = lf(out, bt)
+        net.zero_grad()
+        ls["loss"].backward()
+        em = ev(out, bt)
+        grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        names = sorted(grads)
+        keep = ["backbone.encoder.conv1.weight", "backbone.encoder.bn1.weight", "backbone.encoder.layer1.0.conv1.weight",
+                "backbone.encoder.layer2.1.conv2.weight", "backbone.encoder.layer3.3.conv2.weight", "backbone.encoder.layer4.2.bn3.weight",
+                "backbone.fpn.P3_2.weight", "backbone.fpn.P6.bias", "att_reg_box.5.bias", "att_reg_box.5.weight", "att_reg_box.2.0.weight",
+                "att_reg_box.0.0.bias", "lstm.bias_ih_l0", "lstm.weight_hh_l0_reverse"]
+        ao, bo = out["att_out"].detach().numpy(), out["bbx_out"].detach().numpy()
+        sc = torch.sigmoid(out["att_out"].detach().squeeze(-1))
+        top2 = sc.topk(2, dim=1)
+        d = dict(feat_sizes=np.array(fs), seed=np.array([7]), batch_seed=np.array([4321]), h0=h0.numpy(), c0=c0.numpy(),
+                 loss=np.float64(ls["loss"].item()), cls_ls=np.float64(ls["cls_ls"].item()), box_ls=np.float64(ls["box_ls"].item()),
+                 Acc=em["Acc"].detach().numpy(), MaxPos=em["MaxPos"].detach().numpy(), pred_boxes=em["pred_boxes"].detach().numpy(),
+                 pred_scores=em["pred_scores"].detach().numpy(), top1_idx=top2.indices[:, 0].numpy(), top2_gap=(top2.values[:, 0] - top2.values[:, 1]).numpy(),
+                 att_out_s=ao[:, ::37], bbx_out_s=bo[:, ::37],
+                 att_abs_sum=np.float64(np.abs(ao).astype(np.float64).sum()), bbx_abs_sum=np.float64(np.abs(bo).astype(np.float64).sum()),
+                 rm_bn1=net.backbone.encoder.bn1.running_mean.numpy(), rv_l4=net.backbone.encoder.layer4[2].bn3.running_var.numpy(),
+                 grad_names=np.array(names), grad_norms=np.array([grads[k].double().norm().item() for k in names]))
+        for k in keep:
+            g_ = grads[k].numpy()
+            d["grad__" + k] = g_ if g_.size <= 20000 else g_.reshape(-1)[::max(1, g_.size // 20000)]
+        save("g10_e2e_300_b16", **d)
     # ---- G11 SSD-VGG16 backbone (config 4): SSD.forward + ZSGNet head/loss, B=1, seeded weights -------------------
     S = R["ssd_vgg"]
     sd = O.seeded_ssd_state_dict(seed=5)

@@ -296,3 +296,51 @@ def test_ablation_variants(gold, tag):
             np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
     # the encoder runs (and updates its BatchNorm running statistics) even when the head never sees the image
     np.testing.assert_allclose(sd["backbone.encoder.bn1.running_mean"].numpy(), g["rm_bn1"], rtol=1e-5, atol=1e-7)
+
+
+def test_fpn_600_branch(gold):
+    """fpn_resnet.py:173-174: resize_img == [600, 600] drops p3 and the global-pool level (pins the oracle's 600 path)"""
+    g = gold("g8_fpn600")
+    sd = O.seeded_state_dict("resnet50", int(g["seed"][0]))
+    gf = torch.Generator().manual_seed(int(g["in_seed"][0]))
+    c3 = torch.randn(1, 512, 75, 75, generator=gf)
+    c4 = torch.randn(1, 1024, 38, 38, generator=gf)
+    c5 = torch.randn(1, 2048, 19, 19, generator=gf)
+    outs = O.fpn_forward(sd, c3, c4, c5, six_hundred=True)
+    assert [list(o.shape[2:]) for o in outs] == g["sizes"].tolist() == [list(s) for s in O.feat_sizes_for(600, 600, six_hundred=True)]
+    for i, o in enumerate(outs):
+        o = o.numpy()
+        ref = g[f"p{i}"]
+        if o.shape != ref.shape:
+            o = o[:, ::8, ::3, ::3]
+        np.testing.assert_allclose(o, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_basicblock_stage_and_trunk(gold):
+    """fpn_resnet.py:26-58 BasicBlock (ResNet(1, BasicBlock, [2,2,2,2])): one stride-2 block fwd/bwd in train-mode BN and the
+    whole trunk's FPN taps (pins the oracle's resnet18/34 path)"""
+    g = gold("g8_basicblock")
+    full = O.seeded_state_dict("resnet18", int(g["seed"][0]))
+    pre = "backbone.encoder.layer2.0."
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in full.items() if k.startswith(pre)}
+    x = torch.from_numpy(g["x"]).requires_grad_()
+    bn = O.BNState(sd, True)
+    Fn = torch.nn.functional
+    o = torch.relu(bn(Fn.conv2d(x, sd[pre + "conv1.weight"], None, 2, 1), pre + "bn1"))
+    o = bn(Fn.conv2d(o, sd[pre + "conv2.weight"], None, 1, 1), pre + "bn2")
+    idt = bn(Fn.conv2d(x, sd[pre + "downsample.0.weight"], None, 2), pre + "downsample.1")
+    y = torch.relu(o + idt)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    (y * torch.from_numpy(g["gy"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd[pre + "conv1.weight"].grad.numpy()[::2, ::2], g["g_conv1"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd[pre + "conv2.weight"].grad.numpy()[::2, ::2], g["g_conv2"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd[pre + "bn2.weight"].grad.numpy(), g["g_bn2_w"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd[pre + "downsample.0.weight"].grad.numpy(), g["g_ds"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd[pre + "bn1.running_mean"].numpy(), g["rm_bn1"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sd[pre + "bn1.running_var"].numpy(), g["rv_bn1"], rtol=1e-5, atol=1e-7)
+    sd2 = {k: v.clone() for k, v in full.items()}
+    c3, c4, c5 = O.encoder_forward(sd2, torch.from_numpy(g["img"]), "resnet18", O.BNState(sd2, True))
+    np.testing.assert_allclose(c3.numpy()[:, ::4], g["c3"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(c4.numpy()[:, ::8], g["c4"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(c5.numpy()[:, ::16], g["c5"], rtol=5e-4, atol=5e-5)

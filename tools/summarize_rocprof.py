@@ -49,9 +49,12 @@ if kser:
     shutil.copy(kser[0], os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))
     for r in csv.DictReader(open(kser[0])):
         res.setdefault(klass(r["Name"]), {})["rocprof_avg_ms_serial"] = float(r["AverageNs"]) / 1e6
+sys.path.insert(0, root)
+import bench  # noqa: E402  (source_stamp: ties this summary to the kernel sources it was measured on)
+res["_source_stamp"] = bench.source_stamp()
 json.dump(res, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(res):
-    if k.startswith(("igemm_kernel", "wgrad_kernel")):
+    if k.startswith(("igemm_kernel", "wgrad_kernel", "wino")):
         print(k, {a: round(b, 4) for a, b in res[k].items()})
 if ks:
     print(open(ks[0]).read()[:3000])
