@@ -504,6 +504,33 @@ class _Plan:
         one.launch(stream_ptr())
         return U, job
 
+    def _ws_now(self):
+        """BatchNorm / statistics workspace of the lane being lowered (forward launches on the side stream run concurrently
+        with the main stream's, so they get their own)"""
+        return self.ws if self._lane == 0 else self.ws_side
+
+    def _join_side(self):
+        """the main stream waits for everything lowered on the side stream so far (an empty lane-2 launch)"""
+        if self.training:
+            self.fwd.add(lib.zsg_memset_f32, self.ws, 0, 0.0, what="join side stream", lane=2)
+
+    def on_side_stream(self):
+        """context: forward launches lowered inside go to the side HIP stream (lane 1: each waits for everything enqueued
+        on the main stream before it); the consumer of their results must be lowered with join=True (lane 2)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if not self.training:          # (eval plans are short chains of folded convolutions: keep one stream)
+                yield
+                return
+            keep, self._lane = self._lane, 1
+            try:
+                yield
+            finally:
+                self._lane = keep
+        return cm()
+
     @staticmethod
     def _wino_chunks(d, B: int) -> int:
         tb = d.tile_hint & 0xff
@@ -544,15 +571,15 @@ class _Plan:
                 bm = d.tile_hint & 0xff
                 chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
-                partials, out.bn_chunks = self.ws, chunks
-        self.fwd.add(fn, d, src.buf, wt, out.buf, bias, None, None, partials, what=L.name)
+                partials, out.bn_chunks = self._ws_now(), chunks
+        self.fwd.add(fn, d, src.buf, wt, out.buf, bias, None, None, partials, what=L.name, lane=self._lane)
         if partials is not None:         # finalize at once: the shared workspace is reused by the next launch
             Lb = bn_fuse
             rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
             out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
             rm, rv = self.net._rm[Lb.index:Lb.index + Lb.c], self.net._rv[Lb.index:Lb.index + Lb.c]
-            self.fwd.add(lib.zsg_bn_stats_from_partials, self.ws, out.bn_chunks, rows, Lb.c, out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5,
-                         what="stats:" + Lb.name)
+            self.fwd.add(lib.zsg_bn_stats_from_partials, partials, out.bn_chunks, rows, Lb.c, out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5,
+                         what="stats:" + Lb.name, lane=self._lane)
         out.needs_mask = relu
         self.tape.append(lambda: self._conv_bwd(L, src, out))
         return out
@@ -678,7 +705,8 @@ class _Plan:
             self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
         dx.gfilled = True
 
-    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None) -> Act:
+    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False) -> Act:
+        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2)"""
         net = self.net
         lv = x.levels[0]
         out = self.act(name or L.name, x.B, lv.H, lv.W, L.c)
@@ -691,12 +719,12 @@ class _Plan:
         if fused:
             pass                          # statistics were finalized right after the producing convolution
         elif self.training:
-            self.fwd.add(lib.zsg_bn_stats, x.buf, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, self.ws, self.ws_bytes, what=L.name)
+            self.fwd.add(lib.zsg_bn_stats, x.buf, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, self._ws_now(), self.ws_bytes, what=L.name, lane=self._lane)
         else:
-            self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name)
+            self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name, lane=self._lane)
         rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
         self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
-                     int(relu), out.buf, rmask, what=L.name)
+                     int(relu), out.buf, rmask, what=L.name, lane=(2 if (join and self.training) else self._lane))
 
         def back():
             if out.grad is None:
@@ -725,6 +753,8 @@ class _Plan:
         H1, W1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
         self.ws_bytes = 32 << 20         # BN partials: >= zsg_bn_workspace_bytes for every layer, and the conv-epilogue partials
         self.ws = self._buf(self.ws_bytes // 4)
+        self.ws_side = self._buf(self.ws_bytes // 4)     # the same for forward launches on the side stream (they run concurrently)
+        self._lane = 0
         self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
         self.tune_dw = self._buf(max(e.size for e in net.store.entries.values()) + 64)
@@ -886,22 +916,28 @@ class _Plan:
         return outs[1:] if net.six_hundred else outs
 
     def _lower_block(self, blk, x: Act) -> Act:
+        """fpn_resnet.py:26-58 (BasicBlock), :61-100 (Bottleneck).  Training: a projection shortcut (downsample conv +
+        BatchNorm) only depends on the block input, so it is lowered FIRST, on the side stream, and runs concurrently with
+        the block's main branch; the last BatchNorm (which adds it) joins."""
         net = self.net
         C, BN, q = net.convs, net.bns, blk["prefix"]
-        def shortcut():
-            return self.conv_bn(C[q + "downsample.0"], BN[q + "downsample.1"], x, False, name=q + "rd", yname=q + "yd") if blk["ds"] else x
+        rd = x
+        if blk["ds"]:
+            with self.on_side_stream():
+                rd = self.conv_bn(C[q + "downsample.0"], BN[q + "downsample.1"], x, False, name=q + "rd", yname=q + "yd")
+        join = blk["ds"]
         if net.block_kind == "bottleneck":
             a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
             a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2")
-            if self.training:        # (the shortcut is lowered between conv3 and bn3, as in the first builds of this round)
+            if self.training:
                 y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
-                return self.bn(BN[q + "bn3"], y3, True, residual=shortcut(), name=q + "out")
-            return self.conv_bn(C[q + "conv3"], BN[q + "bn3"], a2, True, residual=shortcut(), name=q + "out", yname=q + "y3")
+                return self.bn(BN[q + "bn3"], y3, True, residual=rd, name=q + "out", join=join)
+            return self.conv_bn(C[q + "conv3"], BN[q + "bn3"], a2, True, residual=rd, name=q + "out", yname=q + "y3")
         a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
         if self.training:
             y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
-            return self.bn(BN[q + "bn2"], y2, True, residual=shortcut(), name=q + "out")
-        return self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, residual=shortcut(), name=q + "out", yname=q + "y2")
+            return self.bn(BN[q + "bn2"], y2, True, residual=rd, name=q + "out", join=join)
+        return self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, residual=rd, name=q + "out", yname=q + "y2")
 
     def _pyramid(self, sizes) -> List[Act]:
         """The head's input features: all pyramid levels packed level-major in ONE buffer (so every head convolution is
@@ -926,18 +962,24 @@ class _Plan:
         else:
             fl = self._pyramid([hw(c3), hw(c4), hw(c5), s6, s7, (1, 1)])
             o3, o4, o5, o6, o7, o8 = fl
+        # The pyramid's output convolutions P5_2 / P4_2 and the whole P6 -> P7 (-> P8) chain are leaves that only the head reads:
+        # in training they run on the side stream, concurrently with the lateral / top-down path and the large P3_2.
         p51 = self.conv(C[f + "P5_1"], c5, name="p51")
-        p5 = self.conv(C[f + "P5_2"], p51, out=o5)
+        with self.on_side_stream():
+            p5 = self.conv(C[f + "P5_2"], p51, out=o5)
         t4 = self.conv(C[f + "P4_1"], c4, name="t4")
         p41 = self._upsample_add(t4, p51, "p41")
-        p4 = self.conv(C[f + "P4_2"], p41, out=o4)
+        with self.on_side_stream():
+            p4 = self.conv(C[f + "P4_2"], p41, out=o4)
         t3 = self.conv(C[f + "P3_1"], c3, name="t3")
         p31 = self._upsample_add(t3, p41, "p31")
         p3 = self.conv(C[f + "P3_2"], p31, out=o3, name="p3")
+        side = self.on_side_stream()
+        side.__enter__()
         p6 = self.conv(C[f + "P6"], c5, out=o6)
         r6 = self.act("r6", B, p6.levels[0].H, p6.levels[0].W, 256)
         n6 = r6.buf.numel()
-        self.fwd.add(lib.zsg_relu_fwd, self.base(p6), n6, r6.buf, what="relu(p6)")
+        self.fwd.add(lib.zsg_relu_fwd, self.base(p6), n6, r6.buf, what="relu(p6)", lane=self._lane)
 
         def relu_back():
             if r6.grad is None:
@@ -948,10 +990,14 @@ class _Plan:
         self.tape.append(relu_back)
         p7 = self.conv(C[f + "P7_2"], r6, out=o7)
         if net.six_hundred:
+            side.__exit__(None, None, None)
+            self._join_side()
             return [p4, p5, p6, p7]           # p3 is computed and dropped, as the reference does (fpn_resnet.py:173-174)
         l7 = p7.levels[0]
         p8 = o8
-        self.fwd.add(lib.zsg_avgpool_fwd, self.base(p7), B, l7.H * l7.W, 256, self.base(p8), what="avgpool")
+        self.fwd.add(lib.zsg_avgpool_fwd, self.base(p7), B, l7.H * l7.W, 256, self.base(p8), what="avgpool", lane=self._lane)
+        side.__exit__(None, None, None)
+        self._join_side()
 
         def avg_back():
             if p8.grad is None:
