@@ -82,8 +82,7 @@ typedef struct {
     int32_t relu;         /* epilogue: max(.,0)                                                             */
     int32_t merge_x;      /* 1: C==4 and all x-taps of a row are one contiguous run (stem / RGB input)       */
     int32_t nseg;
-    int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16) | variant bits 24-26; chosen by the host autotuner;
-                             bit 27: BatchNorm statistics are atomically added to 16 group rows (zsg_bn_apply_acc)  */
+    int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16); chosen by the host autotuner     */
     zsg_seg seg[ZSG_MAX_SEG];
 } zsg_conv_desc;
 
@@ -156,20 +155,6 @@ int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* in
                  float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
 int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
                                float* running_mean, float* running_var, float momentum, float eps, void* stream);
-/* Finalize-free variants (one dependent launch less per BatchNorm and direction).  acc: zsg_bn_acc_bytes(C) bytes, zero before
- * first use: 16 group rows [16][2][C] that the producer ADDS its partial (sum, sum^2) to with fp32 atomics — a convolution
- * launched with tile_hint bit 27 set adds tile mt's column sums to row mt % 16 of bn_partials instead of storing row mt —
- * plus a ticket word.  zsg_bn_apply_acc reduces the rows per channel in fp64 inside every block, publishes mean / invstd /
- * running statistics, applies the normalisation and leaves acc zeroed (last block).  zsg_bn_backward_acc does the same
- * for (sum g, sum g*xhat) in two launches.  The atomic summation order is not fixed: deterministic plans use the
- * functions above. */
-size_t zsg_bn_acc_bytes(int32_t C);
-int zsg_bn_apply_acc(const float* x, int64_t rows, int32_t C, float* acc, const float* gamma, const float* beta,
-                     const float* residual, int32_t relu, float* out, uint8_t* relu_mask, float* mean, float* invstd,
-                     float* running_mean, float* running_var, float momentum, float eps, void* stream);
-int zsg_bn_backward_acc(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,
-                        const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
-                        float* dgamma, float* dbeta, int32_t accumulate, float* acc, void* stream);
 /* eval mode, folded: every (conv, BatchNorm) pair of the job list gets W*s and (beta - mean*s), s = gamma/sqrt(var+eps)
  * per output channel, written to `arena` in ONE launch; the plan then runs conv(+bias, +residual, ReLU) without any
  * BatchNorm launch.  jobs: device array of { int64 w_off, dst_off, gamma_off, beta_off, bias_off; int32 row0, N, row_len,

@@ -215,222 +215,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-// ---- finalize-free variants ---------------------------------------------------------------------------------------------
-// The (sum, sum^2) / (sum g, sum g*xhat) partials are accumulated with fp32 atomics into BN_G group rows
-// acc[BN_G][2][C] (+ a ticket word) by the producer (convolution epilogue / bn_partial_acc_kernel); every block of the
-// streaming pass then reduces the BN_G rows for its own channels in fp64 — no finalize launch, i.e. one dependent launch
-// and one launch gap less per BatchNorm and direction (106 per step).  The accumulator is self-cleaning: the last block of
-// the streaming pass to finish (ticket) zeroes it for the next user.  Summation order of the atomics is not fixed:
-// ZSG_DETERMINISTIC=1 plans use the finalize kernels above instead.
-#define BN_G 16
-
-__device__ __forceinline__ void bn_acc_release(float* acc, int C, int total_blocks) {
-    __shared__ int last;
-    __syncthreads();                                   // every thread of this block has read its accumulator rows
-    if (threadIdx.x == 0) {
-        __threadfence();
-        int* ticket = (int*)(acc + BN_G * 2 * C);
-        last = (atomicAdd(ticket, 1) == total_blocks - 1);
-    }
-    __syncthreads();
-    if (last) {                                        // all blocks have read: clean up for the next user
-        for (int i = threadIdx.x; i < BN_G * 2 * C; i += blockDim.x) acc[i] = 0.f;
-        if (threadIdx.x == 0) *(int*)(acc + BN_G * 2 * C) = 0;
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_apply_acc_kernel(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ acc,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ residual, int relu, float* __restrict__ out,
-                                                           uint8_t* __restrict__ relu_mask, float* __restrict__ mean_out,
-                                                           float* __restrict__ invstd_out, float* rmean, float* rvar, float momentum,
-                                                           float eps, int lanes, int rpb) {
-    const int rowlanes = 256 / lanes;
-    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
-    const int c = (blockIdx.y * lanes + l) * 4;
-    const bool cok = c < C;
-    f32x4 mu = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, be = {0, 0, 0, 0};
-    if (cok) {
-        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int g = 0; g < BN_G; ++g) {
-            const f32x4 a = *(const f32x4*)(acc + (size_t)g * 2 * C + c);
-            const f32x4 b = *(const f32x4*)(acc + (size_t)g * 2 * C + C + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] += (double)a[e];
-                ss[e] += (double)b[e];
-            }
-        }
-        const double n = (double)rows;
-        f32x4 is;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double m = s[e] / n;
-            double var = ss[e] / n - m * m;
-            if (var < 0) var = 0;
-            mu[e] = (float)m;
-            is[e] = (float)(1.0 / sqrt(var + (double)eps));
-            if (blockIdx.x == 0 && rl == 0) {          // one thread per channel publishes the statistics (backward needs them)
-                mean_out[c + e] = mu[e];
-                invstd_out[c + e] = is[e];
-                if (rmean) rmean[c + e] = (1.f - momentum) * rmean[c + e] + momentum * (float)m;
-                if (rvar) rvar[c + e] = (1.f - momentum) * rvar[c + e] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
-            }
-        }
-        sc = is * *(const f32x4*)(gamma + c);
-        be = *(const f32x4*)(beta + c);
-        const int64_t r_begin = (int64_t)blockIdx.x * rpb;
-        const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
-        for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-            f32x4 v = (*(const f32x4*)(x + r * C + c) - mu) * sc + be;
-            if (residual) v += *(const f32x4*)(residual + r * C + c);
-            if (relu) {
-                if (relu_mask)
-                    relu_mask[(r * C + c) >> 2] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            *(f32x4*)(out + r * C + c) = v;
-        }
-    }
-    bn_acc_release(acc, C, gridDim.x * gridDim.y);
-}
-
-// backward pass 1: (sum g, sum g*xhat) of this block's rows, added to group row blockIdx.x % BN_G
-__global__ __launch_bounds__(256) void bn_partial_acc_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                             const float* __restrict__ relu_out, const uint8_t* __restrict__ relu_mask,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                             int64_t rows, int C, int lanes, int rpb, float* __restrict__ acc) {
-    __shared__ f32x4 red[2][256];
-    const int rowlanes = 256 / lanes;
-    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
-    const int c = (blockIdx.y * lanes + l) * 4;
-    const bool cok = c < C;
-    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
-    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
-    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-    if (cok) {
-        const f32x4 mu = *(const f32x4*)(mean + c);
-        const f32x4 is = *(const f32x4*)(invstd + c);
-        for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-            const f32x4 v = *(const f32x4*)(x + r * C + c);
-            f32x4 g = *(const f32x4*)(dout + r * C + c);
-            if (relu_mask) {
-                const unsigned m = relu_mask[(r * C + c) >> 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
-            } else if (relu_out) {
-                const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-            }
-            s0 += g;
-            s1 += g * ((v - mu) * is);
-        }
-    }
-    red[0][threadIdx.x] = s0;
-    red[1][threadIdx.x] = s1;
-    __syncthreads();
-    if (rl == 0 && cok) {
-        for (int k = 1; k < rowlanes; ++k) {
-            s0 += red[0][k * lanes + l];
-            s1 += red[1][k * lanes + l];
-        }
-        float* o = acc + (size_t)(blockIdx.x % BN_G) * 2 * C;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            unsafeAtomicAdd(o + c + e, s0[e]);
-            unsafeAtomicAdd(o + C + c + e, s1[e]);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const float* __restrict__ dout, const float* __restrict__ relu_out,
-                                                               const uint8_t* __restrict__ relu_mask, const float* __restrict__ x,
-                                                               int64_t rows, int C, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                               float* __restrict__ acc, float* __restrict__ dx, float* __restrict__ g_out,
-                                                               float* dgamma, float* dbeta, int accumulate, int lanes, int rpb) {
-    const int rowlanes = 256 / lanes;
-    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
-    const int c = (blockIdx.y * lanes + l) * 4;
-    if (c < C) {
-        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int g = 0; g < BN_G; ++g) {
-            const f32x4 a = *(const f32x4*)(acc + (size_t)g * 2 * C + c);
-            const f32x4 b = *(const f32x4*)(acc + (size_t)g * 2 * C + C + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] += (double)a[e];
-                ss[e] += (double)b[e];
-            }
-        }
-        f32x4 c1, c2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            c1[e] = (float)(s[e] / (double)rows);
-            c2[e] = (float)(ss[e] / (double)rows);
-            if (blockIdx.x == 0 && rl == 0) {
-                if (dbeta) dbeta[c + e] = (accumulate ? dbeta[c + e] : 0.f) + (float)s[e];
-                if (dgamma) dgamma[c + e] = (accumulate ? dgamma[c + e] : 0.f) + (float)ss[e];
-            }
-        }
-        const f32x4 mu = *(const f32x4*)(mean + c);
-        const f32x4 is = *(const f32x4*)(invstd + c);
-        const f32x4 sc = is * *(const f32x4*)(gamma + c);
-        const int64_t r_begin = (int64_t)blockIdx.x * rpb;
-        const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
-        for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-            f32x4 g = *(const f32x4*)(dout + r * C + c);
-            if (relu_mask) {
-                const unsigned m = relu_mask[(r * C + c) >> 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
-            } else if (relu_out) {
-                const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-            }
-            const f32x4 xh = (*(const f32x4*)(x + r * C + c) - mu) * is;
-            if (g_out) *(f32x4*)(g_out + r * C + c) = g;
-            *(f32x4*)(dx + r * C + c) = sc * (g - c1 - xh * c2);
-        }
-    }
-    bn_acc_release(acc, C, gridDim.x * gridDim.y);
-}
-
-extern "C" size_t zsg_bn_acc_bytes(int32_t C) { return ((size_t)BN_G * 2 * C + 4) * sizeof(float); }
-
-extern "C" int zsg_bn_apply_acc(const float* x, int64_t rows, int32_t C, float* acc, const float* gamma, const float* beta,
-                                const float* residual, int32_t relu, float* out, uint8_t* relu_mask, float* mean, float* invstd,
-                                float* running_mean, float* running_var, float momentum, float eps, void* stream) {
-    ZSG_REQUIRE(x && acc && gamma && beta && out && mean && invstd && rows > 0 && C > 0 && (C % 4) == 0, "bn_apply_acc: bad argument");
-    BnGeom g = bn_geom(rows, C);
-    hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("bn_apply", st, 0, (double)rows * C * (4 * (residual ? 3 : 2) + (relu_mask && relu ? 0.25 : 0)));
-    hipLaunchKernelGGL(bn_apply_acc_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, acc, gamma, beta, residual, relu, out,
-                       relu_mask, mean, invstd, running_mean, running_var, momentum, eps, g.lanes, g.rpb);
-    ZSG_CHECK_LAUNCH("bn_apply_acc");
-    return 0;
-}
-
-extern "C" int zsg_bn_backward_acc(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows,
-                                   int32_t C, const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
-                                   float* dgamma, float* dbeta, int32_t accumulate, float* acc, void* stream) {
-    ZSG_REQUIRE(dout && x && mean && invstd && gamma && dx && acc && rows > 0 && C > 0 && (C % 4) == 0, "bn_backward_acc: bad argument");
-    BnGeom g = bn_geom(rows, C);
-    hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * ((relu_out && !relu_mask ? 3 : 2) * 2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.5 : 0)));
-    hipLaunchKernelGGL(bn_partial_acc_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd, rows, C,
-                       g.lanes, g.rpb, acc);
-    hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
-                       gamma, acc, dx, g_out, dgamma, dbeta, accumulate, g.lanes, g.rpb);
-    ZSG_CHECK_LAUNCH("bn_backward_acc");
-    return 0;
-}
-
 extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* invstd, float* running_mean,
                             float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream) {
     ZSG_REQUIRE(x && mean && invstd && ws && rows > 0 && C > 0 && (C % 4) == 0, "bn_stats: bad argument (C=%d rows=%lld)", C, (long long)rows);

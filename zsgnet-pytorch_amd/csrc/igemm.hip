@@ -37,7 +37,6 @@ struct IgParams {
     int splits;       // split-K factor (1: plain stores; >1: fp32 atomic accumulation into a zeroed / pre-filled output)
     int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
-    int stat_groups;  // > 0: the statistics are ADDED (fp32 atomics) to group row (m tile % stat_groups) instead of stored per tile
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     IgSegDev seg[ZSG_MAX_SEG];
 };
@@ -284,15 +283,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                 s1 += red[w * BN + tid];
                 s2 += red[(WM + w) * BN + tid];
             }
-            if (p.stat_groups) {
-                float* o = p.stats + (size_t)(mt % p.stat_groups) * 2 * p.N;
-                unsafeAtomicAdd(o + n0 + tid, s1);
-                unsafeAtomicAdd(o + p.N + n0 + tid, s2);
-            } else {
-                float* o = p.stats + (size_t)mt * 2 * p.N;
-                o[n0 + tid] = s1;
-                o[p.N + n0 + tid] = s2;
-            }
+            float* o = p.stats + (size_t)mt * 2 * p.N;
+            o[n0 + tid] = s1;
+            o[p.N + n0 + tid] = s2;
         }
     }
 
@@ -487,7 +480,6 @@ extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const fl
     p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
     p.stats = bn_partials;
-    p.stat_groups = ((d->tile_hint >> 27) & 1) ? 16 : 0;       // tile_hint bit 27: accumulate the statistics into 16 group rows (zsg_bn_apply_acc)
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
         for (int s = 0; s < d->nseg; ++s) v = v && (d->seg[s].out_off % 4) == 0 && (d->seg[s].out_bstride % 4) == 0;

@@ -41,7 +41,7 @@ struct WnParams {
     const float* mask_src;
     float* stats;        // optional BatchNorm partials [m_blocks][2][N]
     int C, N, Npad, src_ld, out_ld, relu, nseg;
-    int m_blocks, n_blocks, splits, chunks, vec, add_is_out, stat_groups;
+    int m_blocks, n_blocks, splits, chunks, vec, add_is_out;
     WnSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -314,15 +314,9 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
                     a1 += red[r * BN + tid];
                     a2 += red[(RPP + r) * BN + tid];
                 }
-                if (p.stat_groups) {             // accumulate into group rows (zsg_bn_apply_acc), see igemm.hip
-                    float* o = p.stats + (size_t)(mb % p.stat_groups) * 2 * p.N;
-                    unsafeAtomicAdd(o + n0 + tid, a1);
-                    unsafeAtomicAdd(o + p.N + n0 + tid, a2);
-                } else {
-                    float* o = p.stats + (size_t)mb * 2 * p.N;
-                    o[n0 + tid] = a1;
-                    o[p.N + n0 + tid] = a2;
-                }
+                float* o = p.stats + (size_t)mb * 2 * p.N;
+                o[n0 + tid] = a1;
+                o[p.N + n0 + tid] = a2;
             }
         }
         return;
@@ -459,7 +453,6 @@ extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const flo
     p.C = d->C; p.N = d->N; p.Npad = (d->N + 63) / 64 * 64; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.relu = d->relu;
     p.nseg = d->nseg; p.chunks = (d->C + WN_CK - 1) / WN_CK; p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
-    p.stat_groups = ((d->tile_hint >> 27) & 1) ? 16 : 0;
     int blocks = 0;
     double fl = 0;
     bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;

@@ -26,7 +26,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import Level, Program, TView, WinoJobs, autotune_conv, conv_out, deterministic, dgrad_desc, fwd_desc, wino_mode, wino_ok
+from .ops import Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, wino_mode, wino_ok
 from .params import ParamStore, pad4, register_named
 
 VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
@@ -572,15 +572,8 @@ class _Plan:
                 chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
                 partials, out.bn_chunks = self._ws_now(), chunks
-        out.bn_acc = None
-        if partials is not None and self.bn_acc_mode and L.cout <= 2048:
-            # the epilogue ADDS its column sums to 16 group rows of a self-cleaning accumulator; the BatchNorm apply launch
-            # reduces them itself: no finalize launch between the convolution and the normalisation
-            d.tile_hint |= 1 << 27
-            partials = out.bn_acc = (self.acc_main if self._lane == 0 else self.acc_side)
-            out.bn_mean, out.bn_invstd = self._buf(bn_fuse.c), self._buf(bn_fuse.c)
         self.fwd.add(fn, d, src.buf, wt, out.buf, bias, None, None, partials, what=L.name, lane=self._lane)
-        if partials is not None and out.bn_acc is None:         # finalize at once: the shared workspace is reused by the next launch
+        if partials is not None:         # finalize at once: the shared workspace is reused by the next launch
             Lb = bn_fuse
             rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
             out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
@@ -723,21 +716,15 @@ class _Plan:
         rm, rv = net._rm[L.index:L.index + L.c], net._rv[L.index:L.index + L.c]
         self.ws_need = max(getattr(self, "ws_need", 0), lib.zsg_bn_workspace_bytes(rows, L.c))
         gam, bet = self.P(L.name + ".weight"), self.P(L.name + ".bias")
-        acc = getattr(x, "bn_acc", None) if self.training else None
         if fused:
-            pass                          # statistics were finalized right after the producing convolution (or come with bn_acc)
+            pass                          # statistics were finalized right after the producing convolution
         elif self.training:
             self.fwd.add(lib.zsg_bn_stats, x.buf, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, self._ws_now(), self.ws_bytes, what=L.name, lane=self._lane)
         else:
             self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name, lane=self._lane)
         rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
-        lane = 2 if (join and self.training) else self._lane
-        if acc is not None:
-            self.fwd.add(lib.zsg_bn_apply_acc, x.buf, rows, L.c, acc, gam, bet, residual.buf if residual is not None else None, int(relu),
-                         out.buf, rmask, mean, invstd, rm, rv, 0.1, 1e-5, what=L.name, lane=lane)
-        else:
-            self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
-                         int(relu), out.buf, rmask, what=L.name, lane=lane)
+        self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
+                     int(relu), out.buf, rmask, what=L.name, lane=(2 if (join and self.training) else self._lane))
 
         def back():
             if out.grad is None:
@@ -749,13 +736,9 @@ class _Plan:
                 assert not rg.gfilled, "residual gradient must be produced first (tape order)"
                 g_out = rg.buf
                 rg.gfilled = True
-            if self.bn_acc_mode and L.c <= 2048:
-                self.bwd.add(lib.zsg_bn_backward_acc, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
-                             dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.acc_bwd, what="bnbwd:" + L.name)
-            else:
-                self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
-                             dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,
-                             what="bnbwd:" + L.name)
+            self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
+                         dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,
+                         what="bnbwd:" + L.name)
             dx.gfilled = True
         self.tape.append(back)
         return out
@@ -772,11 +755,6 @@ class _Plan:
         self.ws = self._buf(self.ws_bytes // 4)
         self.ws_side = self._buf(self.ws_bytes // 4)     # the same for forward launches on the side stream (they run concurrently)
         self._lane = 0
-        # finalize-free BatchNorm (zsg_bn_apply_acc / zsg_bn_backward_acc): self-cleaning atomic accumulators, one per stream
-        # that uses them; never written by anything else (they must be zero between uses)
-        self.bn_acc_mode = self.training and not deterministic()
-        nacc = lib.zsg_bn_acc_bytes(2048) // 4
-        self.acc_main, self.acc_side, self.acc_bwd = (self._buf(nacc) for _ in range(3))
         self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
         self.tune_dw = self._buf(max(e.size for e in net.store.entries.values()) + 64)

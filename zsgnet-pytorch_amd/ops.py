@@ -437,8 +437,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                  and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
         for bm, bn in tiles:
             cands.append(tile_hint(bm, bn, 1))
-            if bm == 128 and not d.merge_x:
-                cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup
+            if not d.merge_x and (bm == 128 or bn == 64):
+                cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup (64x64: two K groups)
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
         if dense and blocks64 < 1024 and not deterministic():
