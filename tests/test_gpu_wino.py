@@ -33,6 +33,13 @@ WINO_CASES = [
     (2, 128, 128, 9, 9, False, False, 32, 32, 3),
     (2, 512, 96, 10, 10, True, False, 64, 64, 4),
     (16, 64, 64, 38, 38, False, False, 64, 64, 1),
+    # four position groups (tile_hint bit 24: splits field + 256)
+    (2, 64, 128, 20, 17, True, True, 64, 64, 1 + 256),
+    (3, 128, 64, 7, 10, False, False, 32, 64, 1 + 256),
+    (2, 48, 256, 10, 10, True, False, 64, 32, 1 + 256),
+    (1, 516, 256, 5, 5, True, True, 32, 32, 1 + 256),
+    (2, 512, 96, 10, 10, True, False, 64, 64, 4 + 256),
+    (16, 64, 64, 38, 38, False, False, 64, 64, 1 + 256),
 ]
 
 
@@ -40,6 +47,7 @@ WINO_CASES = [
 def test_wino_fwd_dgrad(Z, case):
     L, ops = Z
     B, Ci, Co, H, W, bias, relu, TB, BN, splits = case
+    ps4, splits = splits >> 8, splits & 0xff
     g = torch.Generator().manual_seed(7 + Ci + Co + H)
     x = torch.randn(B, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
@@ -52,7 +60,7 @@ def test_wino_fwd_dgrad(Z, case):
     y_ref.backward(gy)
     cp = pad4(Ci)
     st = L.stream_ptr()
-    hint = TB | (BN << 8) | (splits << 16)
+    hint = TB | (BN << 8) | (splits << 16) | (ps4 << 24)
     xd, wd = dev(nhwc(x)), dev(ohwi(w))
     U = make_u(L, ops, wd, Co, cp, 9 * cp, cp, False)
     out = torch.full((B, H, W, Co), float("nan"), device="cuda")
@@ -125,9 +133,9 @@ def test_wino_multilevel_window(Z):
     ov = ops.TView(out.view(-1), B, Co, Co, lv_out)
     wd, bd, ad = dev(ohwi(w)), dev(b), dev(addm)
     U = make_u(L, ops, wd, Co, Cf, 9 * Ct, Ct, False)
-    for TB, BN in ((64, 64), (32, 64), (64, 32), (32, 32)):
+    for TB, BN, ps4 in ((64, 64, 0), (32, 64, 0), (64, 32, 0), (32, 32, 0), (64, 64, 1), (32, 64, 1), (32, 32, 1)):
         out.fill_(float("nan"))
-        desc = ops.fwd_desc(src, ov, Cf, Co, 3, 1, 1, 1, wC=Ct, relu=True, tile_hint=TB | (BN << 8) | (1 << 16))
+        desc = ops.fwd_desc(src, ov, Cf, Co, 3, 1, 1, 1, wC=Ct, relu=True, tile_hint=TB | (BN << 8) | (1 << 16) | (ps4 << 24))
         L.check(L.lib.zsg_conv_wino(C.byref(desc), packed.data_ptr(), U.data_ptr(), out.data_ptr(), bd.data_ptr(), ad.data_ptr(), None, None,
                                     L.stream_ptr()), "wino")
         assert_close(out, ref, 3e-4, 3e-4, f"multi-level wino {TB}x{BN}")

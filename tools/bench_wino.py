@@ -67,13 +67,13 @@ def main():
             line += f" ig[{hint & 0xff}x{(hint >> 8) & 0xff}] {t * 1e3:6.1f}us {gf / t:6.1f}"
         line += " |"
         dense = len(sizes) == 1
-        cands = [(64, 64, 1), (32, 64, 1), (64, 32, 1), (32, 32, 1)]
+        cands = [(64, 64, 1, 0), (32, 64, 1, 0), (32, 32, 1, 0), (64, 64, 1, 1), (32, 64, 1, 1), (64, 32, 1, 1), (32, 32, 1, 1)]
         if dense:
-            cands += [(64, 64, 2), (32, 64, 2), (32, 32, 2), (64, 64, 4), (32, 32, 4)]
-        for TB, BN, sp in cands:
-            d = ops.fwd_desc(src, out, Ci, Co, 3, 1, 1, 1, wC=Ci, tile_hint=TB | (BN << 8) | (sp << 16))
+            cands += [(64, 64, 2, 0), (64, 64, 4, 0), (64, 64, 2, 1), (32, 64, 2, 1), (64, 64, 4, 1)]
+        for TB, BN, sp, ps4 in cands:
+            d = ops.fwd_desc(src, out, Ci, Co, 3, 1, 1, 1, wC=Ci, tile_hint=TB | (BN << 8) | (sp << 16) | (ps4 << 24))
             t = timeit(lambda: check(lib.zsg_conv_wino(C.byref(d), x.data_ptr(), U.data_ptr(), y.data_ptr(), None, None, None, None, st), "wino"))
-            line += f" wn[{TB}x{BN}/{sp}] {t * 1e3:6.1f}us {gf / t:6.1f}"
+            line += f" wn[{TB}x{BN}/{sp}{'q' if ps4 else ''}] {t * 1e3:6.1f}us {gf / t:6.1f}"
         # weight gradient: direct (heuristic / a few splits) vs Winograd F(3x3,2x2)
         dy = torch.randn(oo, device="cuda")
         dw = torch.zeros(Co, 3, 3, Ci, device="cuda")

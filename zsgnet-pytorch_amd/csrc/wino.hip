@@ -52,15 +52,20 @@ __device__ __forceinline__ float quad_other(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
-    constexpr int NT = 128 * TM * TN;            // 2 position halves x TM x TN waves
+// PS position groups per 32x32 sub-block: wave (ph, wm, wn) holds the 16/PS positions with i in {2ph, 2ph+1} (PS = 2) or
+// i = ph (PS = 4).  PS = 4 doubles the waves per SIMD for the same tile (64 instead of 128 accumulator registers each).
+template <int TM, int TN, int PS>
+__global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams p) {
+    constexpr int NT = 64 * PS * TM * TN;        // PS position groups x TM x TN waves
+    constexpr int NP = 16 / PS;                  // positions (accumulator tiles) per wave
     constexpr int TB = 32 * TM, BN = 32 * TN;
     constexpr int SA = TB * 8 + 8;               // floats between positions of the A stage (+8: conflict-free quad writes)
     constexpr int SB = BN * 8;
-    constexpr int IA = TB * 8 / NT;              // A loader items (tile, g, q) per thread
+    constexpr int IA = (TB * 8 + NT - 1) / NT;   // A loader items (tile, g, q) per thread (NT > TB*8: only the first TB*8 threads load)
+    constexpr bool A_ALL = (TB * 8 % NT) == 0;
     constexpr int IB = 32 * BN / NT;             // B loader 16-byte copies per thread
-    static_assert(IA >= 1 && IB >= 1, "tile too small for the thread count");
+    static_assert(IB >= 1 && (A_ALL || IA == 1), "tile too small for the thread count");
+    const bool a_thr = A_ALL || (int)threadIdx.x < TB * 8;      // wave-uniform
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][16][SA]
     float* Bs = smem + 2 * 16 * SA;              // [2][16][SB]
@@ -91,9 +96,9 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
     int a_base[IA], a_mask[IA], a_lds[IA];
 #pragma unroll
     for (int ia = 0; ia < IA; ++ia) {
-        const int t = (tid + NT * ia) >> 3;
+        const int t = ((tid + NT * ia) >> 3) % TB;
         const int m = m0 + t;
-        const bool ok = m < sg.tiles;
+        const bool ok = a_thr & (m < sg.tiles);
         const int mm = ok ? m : 0;
         const int per = sg.tiles_y * sg.tiles_x;
         const int b = mm / per;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
         a_mask[ia] = mask;
         a_base[ia] = sg.src_off + b * sg.src_bstride + (y * sg.W + x0) * src_ld + 4 * g;
         a_lds[ia] = q * SA + t * 8 + 4 * (g ^ ((t >> 3) & 1));
-        if (q == 0 && g == 0) {
+        if (q == 0 && g == 0 && a_thr) {
             rowinfo[2 * t] = ok ? sg.out_off + b * sg.out_bstride + ((2 * ty) * sg.W + 2 * tx) * p.out_ld : -1;
             rowinfo[2 * t + 1] = ((2 * tx + 1 < sg.W) ? 1 : 0) | ((2 * ty + 1 < sg.H) ? 2 : 0);
         }
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
 
     f32x4 ra[IA][4];
     auto load_a = [&](int c, bool live) {
+        if (!a_thr) return;
         const int koff = c * WN_CK + 4 * g;
         const bool kok = live & (koff < p.C);
 #pragma unroll
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
     // ONE cross-lane operand, i.e. one v_fmac_f32 with a DPP source per value.
     const float sgn = (q == 1) ? 1.f : -1.f;
     auto store_a = [&](int buf) {
+        if (!a_thr) return;
         float* a = As + buf * 16 * SA;
 #pragma unroll
         for (int ia = 0; ia < IA; ++ia) {
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
         }
     };
 
-    f32x16 acc[8];
+    f32x16 acc[NP];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NP; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -189,26 +196,28 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
         load_b(c0, 0);
         load_a(c0, true);
         store_a(0);
-        if (ph == 1) load_a(c0 + 1, nc > 1);       // the late half transforms FIRST in every chunk: its next chunk is prefetched here
+        if (ph & 1) load_a(c0 + 1, nc > 1);        // the late groups transform FIRST in every chunk: their next chunk is prefetched here
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int frag_a = (wm * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SA;
-    const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + 2 * ph * SB;
-    auto mfma_pos = [&](const float* a, const float* b, int pl) {       // position p = j*4 + 2*ph + il, pl = j*2 + il
-        const int po = (pl >> 1) * 4 + (pl & 1);
+    const int pbase = (PS == 2) ? 2 * ph : ph;
+    const int frag_a = (wm * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + pbase * SA;
+    const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + pbase * SB;
+    auto mfma_pos = [&](const float* a, const float* b, int pl) {       // position p = j*4 + i: PS 2: pl = j*2 + il, i = 2ph + il; PS 4: pl = j, i = ph
+        const int po = (PS == 2) ? (pl >> 1) * 4 + (pl & 1) : pl * 4;
         const f32x4 fa = *(const f32x4*)(a + po * SA);
         const f32x4 fb = *(const f32x4*)(b + po * SB);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
     };
     // One chunk = MFMAs on buffer it&1 + (A transform, B LDS-DMA) of chunk it+1 into the other buffer; the two are
-    // independent between two barriers, so the two position halves — whose waves share the SIMDs pairwise (wave w and
-    // w + TM*TN) — run them in OPPOSITE order: while one half transforms (VALU / LDS writes) its partner issues MFMAs.
-    //   early half (ph 0): loads of chunk it+1 | 32 MFMAs | transform it+1        (load -> use: the MFMA phase)
-    //   late  half (ph 1): transform it+1 (loaded one chunk ago) | loads of chunk it+2 | 32 MFMAs
-    if (ph == 0) {
+    // independent between two barriers, so the position groups — whose waves share the SIMDs (wave w, w + TM*TN, ...) —
+    // alternate their order: while one group transforms (VALU / LDS writes) its SIMD partner issues MFMAs.
+    //   early groups (ph even): loads of chunk it+1 | MFMAs | transform it+1        (load -> use: the MFMA phase)
+    //   late  groups (ph odd) : transform it+1 (loaded one chunk ago) | loads of chunk it+2 | MFMAs
+    constexpr int NP1 = NP - NP / 4;               // MFMA positions before the transform may start interleaving
+    if ((ph & 1) == 0) {
         for (int it = 0; it < nc; ++it) {
             const float* a = As + (it & 1) * 16 * SA + frag_a;
             const float* b = Bs + (it & 1) * 16 * SB + frag_b;
@@ -216,10 +225,10 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
             load_a(c0 + it + 1, it + 1 < nc);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 6; ++pl) mfma_pos(a, b, pl);
+            for (int pl = 0; pl < NP1; ++pl) mfma_pos(a, b, pl);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_pos(a, b, 6);
-            mfma_pos(a, b, 7);
+#pragma unroll
+            for (int pl = NP1; pl < NP; ++pl) mfma_pos(a, b, pl);
             store_a((it + 1) & 1);                 // (after the last chunk: zeros into the idle buffer)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -233,29 +242,36 @@ __global__ __launch_bounds__(128 * TM * TN) void wino_kernel(const WnParams p) {
             load_a(c0 + it + 2, it + 2 < nc);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 8; ++pl) mfma_pos(a, b, pl);
+            for (int pl = 0; pl < NP; ++pl) mfma_pos(a, b, pl);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
 
-    // ---- output transform: this wave's half of Y = A^T M A --------------------------------------------------------------
-    // z[il][b] = sum_j A^T[b][j] M[i][j];  ph 0 (i = 0,1): Y[0] = z0 + z1, Y[1] = z1;  ph 1 (i = 2,3): Y[0] = z0, Y[1] = -z0 - z1
+    // ---- output transform: this wave's share of Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) ---------------------------------
+    // z[i][b] = sum_j A^T[b][j] M[i][j];  Y[a][b] = sum_i A^T[a][i] z[i][b].  The position groups add their partial Y through
+    // LDS one after the other (fixed order).
     constexpr int LDC = BN + 4;
     float* ct = smem;                               // [TB*4][LDC] — the staging area is no longer needed
     float* red = smem + TB * 4 * LDC;               // [2][RPP][BN] (statistics)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < PS; ++hh) {
         if (ph == hh) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float z00 = acc[0][e] + acc[2][e] + acc[4][e], z01 = acc[2][e] - acc[4][e] - acc[6][e];
-                const float z10 = acc[1][e] + acc[3][e] + acc[5][e], z11 = acc[3][e] - acc[5][e] - acc[7][e];
                 float y[4];
-                if (hh == 0) {
-                    y[0] = z00 + z10; y[1] = z01 + z11; y[2] = z10; y[3] = z11;
-                } else {
-                    y[0] = z00; y[1] = z01; y[2] = -z00 - z10; y[3] = -z01 - z11;
+                if (PS == 2) {
+                    const float z00 = acc[0][e] + acc[2][e] + acc[4][e], z01 = acc[2][e] - acc[4][e] - acc[6][e];
+                    const float z10 = acc[1][e] + acc[3][e] + acc[5][e], z11 = acc[3][e] - acc[5][e] - acc[7][e];
+                    if (hh == 0) {                  // rows i = 0, 1
+                        y[0] = z00 + z10; y[1] = z01 + z11; y[2] = z10; y[3] = z11;
+                    } else {                        // rows i = 2, 3
+                        y[0] = z00; y[1] = z01; y[2] = -z00 - z10; y[3] = -z01 - z11;
+                    }
+                } else {                            // one row i = ph: coefficients A^T[0][i], A^T[1][i]
+                    const float z0 = acc[0][e] + acc[1][e] + acc[2][e], z1 = acc[1][e] - acc[2][e] - acc[3][e];
+                    const float a0 = (hh == 3) ? 0.f : 1.f, a1 = (hh == 0) ? 0.f : ((hh == 1) ? 1.f : -1.f);
+                    y[0] = a0 * z0; y[1] = a0 * z1; y[2] = a1 * z0; y[3] = a1 * z1;
                 }
                 const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 float* o = ct + (tl * 4) * LDC + wn * 32 + li;
@@ -417,26 +433,27 @@ extern "C" int zsg_wino_weights(const void* jobs_dev, int32_t njobs, int32_t tot
     return 0;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int PS>
 static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
-    constexpr int TB = 32 * TM, BN = 32 * TN, NT = 128 * TM * TN;
+    constexpr int TB = 32 * TM, BN = 32 * TN, NT = 64 * PS * TM * TN;
     constexpr int SA = TB * 8 + 8, SB = BN * 8;
     size_t lds = (size_t)2 * 16 * (SA + SB) * sizeof(float) + TB * 2 * sizeof(int);
     const size_t epi = ((size_t)TB * 4 * (BN + 4) + 2 * (NT / (BN / 4)) * BN) * sizeof(float);
     if (epi > (size_t)2 * 16 * (SA + SB) * sizeof(float)) lds = epi + TB * 2 * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((wino_kernel<TM, TN>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((wino_kernel<TM, TN, PS>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_wino");
     return 0;
 }
 
-// tile_hint = TB | (BN << 8) | (split_k << 16), TB (tiles per block) and BN in {32, 64}; 0 = 64x64, no split
+// tile_hint = TB | (BN << 8) | (split_k << 16) | (four position groups << 24), TB (tiles per block) and BN in {32, 64};
+// 0 = 64x64, two position groups, no split
 extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
                              const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
     ZSG_REQUIRE(d && src && U && out, "conv_wino: null argument");
@@ -494,8 +511,14 @@ extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const flo
             if (e != hipSuccess) ZSG_FAIL(-3, "conv_wino: memset: %s", hipGetErrorString(e));
         }
     }
-    if (TB == 64 && BN == 64) return wino_launch<2, 2>(p, st, fl, "wino_kernel<2, 2>");
-    if (TB == 32 && BN == 64) return wino_launch<1, 2>(p, st, fl, "wino_kernel<1, 2>");
-    if (TB == 64 && BN == 32) return wino_launch<2, 1>(p, st, fl, "wino_kernel<2, 1>");
-    return wino_launch<1, 1>(p, st, fl, "wino_kernel<1, 1>");
+    if ((d->tile_hint >> 24) & 1) {            // four position groups: twice the waves per SIMD
+        if (TB == 64 && BN == 64) return wino_launch<2, 2, 4>(p, st, fl, "wino_kernel<2, 2, 4>");
+        if (TB == 32 && BN == 64) return wino_launch<1, 2, 4>(p, st, fl, "wino_kernel<1, 2, 4>");
+        if (TB == 64 && BN == 32) return wino_launch<2, 1, 4>(p, st, fl, "wino_kernel<2, 1, 4>");
+        return wino_launch<1, 1, 4>(p, st, fl, "wino_kernel<1, 1, 4>");
+    }
+    if (TB == 64 && BN == 64) return wino_launch<2, 2, 2>(p, st, fl, "wino_kernel<2, 2, 2>");
+    if (TB == 32 && BN == 64) return wino_launch<1, 2, 2>(p, st, fl, "wino_kernel<1, 2, 2>");
+    if (TB == 64 && BN == 32) return wino_launch<2, 1, 2>(p, st, fl, "wino_kernel<2, 1, 2>");
+    return wino_launch<1, 1, 2>(p, st, fl, "wino_kernel<1, 1, 2>");
 }

@@ -385,7 +385,8 @@ def deterministic() -> bool:
 
 def _wino_cands(d: ConvDesc) -> list:
     tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
-    cands = [tile_hint(64, 64, 1), tile_hint(32, 64, 1), tile_hint(32, 32, 1)]
+    # (tiles per block, channels per block, split-K, four position groups instead of two = twice the waves per SIMD)
+    cands = [tile_hint(64, 64, 1), tile_hint(32, 64, 1), tile_hint(64, 64, 1, 1), tile_hint(32, 64, 1, 1), tile_hint(32, 32, 1, 1)]
     s0 = d.seg[0]
     dense = (d.nseg == 1 and not d.relu and d.out_ld == d.N and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
     if dense and not deterministic():
@@ -394,6 +395,7 @@ def _wino_cands(d: ConvDesc) -> list:
             for sp in (2, 4, 8):
                 if blocks * sp <= 1024 and sp * 4 <= (d.C + 7) // 8:
                     cands.append(tile_hint(tb, bn, sp))
+                    cands.append(tile_hint(tb, bn, sp, 1))
     return cands
 
 
