@@ -155,6 +155,15 @@ int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* in
                  float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
 int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
                                float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* BatchNorm apply straight from the convolution epilogue's partial rows when there are at most zsg_bn_inline_max_chunks()
+ * of them (small maps: layer3 / layer4 / pyramid sizes): every block reduces the rows for its own channels (fp64, fixed
+ * order), block 0 publishes mean / invstd / the running statistics — no separate finalize launch between the convolution
+ * and the normalisation.  (zsg_bn_backward does the equivalent internally for tensors of at most 32 MB.) */
+int32_t zsg_bn_inline_max_chunks(void);
+int zsg_bn_apply_from_partials(const float* x, int64_t rows, int32_t C, const float* partials, int32_t chunks, const float* gamma,
+                               const float* beta, const float* residual, int32_t relu, float* out, uint8_t* relu_mask,
+                               float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
+                               void* stream);
 /* eval mode, folded: every (conv, BatchNorm) pair of the job list gets W*s and (beta - mean*s), s = gamma/sqrt(var+eps)
  * per output channel, written to `arena` in ONE launch; the plan then runs conv(+bias, +residual, ReLU) without any
  * BatchNorm launch.  jobs: device array of { int64 w_off, dst_off, gamma_off, beta_off, bias_off; int32 row0, N, row_len,

@@ -146,6 +146,22 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
                                                      0.1, 1e-5, st), "bn_from_partials")
             assert_close(mean, yf.mean(0), 1e-4, 1e-5, "fused bn mean")
             assert_close(invstd, 1 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5), 2e-4, 0, "fused bn invstd")
+            if chunks <= L.lib.zsg_bn_inline_max_chunks():
+                # finalize-free apply: every block reduces the few partial rows itself; must equal nn.BatchNorm2d(train) + ReLU
+                gam, bet = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+                rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+                m2, i2 = torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+                yb = torch.empty_like(out)
+                mask = torch.empty((out.numel() // 4 + 3) // 4 * 4, dtype=torch.uint8, device="cuda")
+                gd, bd_ = dev(gam), dev(bet)
+                L.check(L.lib.zsg_bn_apply_from_partials(out.data_ptr(), B * Ho * Wo, Co, part.data_ptr(), chunks, gd.data_ptr(), bd_.data_ptr(), None, 1,
+                                                         yb.data_ptr(), mask.data_ptr(), m2.data_ptr(), i2.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, st),
+                        "bn_apply_from_partials")
+                ref_bn = F.relu(F.batch_norm(y_ref.detach(), None, None, gam, bet, True, 0.1, 1e-5))
+                assert_close(yb.permute(0, 3, 1, 2), ref_bn, 5e-4, 5e-4, "bn apply from partials")
+                assert_close(m2, mean, 1e-6, 1e-7, "inline mean == finalize mean")
+                assert_close(rm, 0.1 * yf.mean(0), 1e-4, 1e-6, "running mean")
+                assert_close(rv, 0.9 + 0.1 * yf.var(0, unbiased=True), 2e-4, 1e-6, "running var")
 
     # backward: dy is the gradient w.r.t. the pre-ReLU output
     gpre = gy * (y_ref > 0) if relu else gy

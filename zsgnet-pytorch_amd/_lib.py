@@ -70,6 +70,8 @@ SIGNATURES = {
     "zsg_bn_stats_from_partials": (I32, [P, I32, I64, I32, P, P, P, P, F32, F32, P]),
     "zsg_bn_eval_stats": (I32, [P, P, I32, F32, P, P, P]),
     "zsg_bn_fold": (I32, [P, P, P, F32, P, I32, I32, P, P]),
+    "zsg_bn_inline_max_chunks": (I32, []),
+    "zsg_bn_apply_from_partials": (I32, [P, I64, I32, P, I32, P, P, P, I32, P, P, P, P, P, P, F32, F32, P]),
     "zsg_bn_apply": (I32, [P, I64, I32, P, P, P, P, P, I32, P, P, P]),
     "zsg_bn_backward": (I32, [P, P, P, P, I64, I32, P, P, P, P, P, P, P, I32, P, SZ, P]),
     "zsg_maxpool_fwd": (I32, [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P, P, P]),

@@ -573,7 +573,13 @@ class _Plan:
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
                 partials, out.bn_chunks = self._ws_now(), chunks
         self.fwd.add(fn, d, src.buf, wt, out.buf, bias, None, None, partials, what=L.name, lane=self._lane)
-        if partials is not None:         # finalize at once: the shared workspace is reused by the next launch
+        out.bn_inline = None
+        if partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
+            # few partial rows: the BatchNorm apply launch (the very next launch on this stream: the workspace is still intact)
+            # reduces them itself — no finalize launch
+            out.bn_inline = partials
+            out.bn_mean, out.bn_invstd = self._buf(bn_fuse.c), self._buf(bn_fuse.c)
+        elif partials is not None:         # finalize at once: the shared workspace is reused by the next launch
             Lb = bn_fuse
             rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
             out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
@@ -723,8 +729,14 @@ class _Plan:
         else:
             self.fwd.add(lib.zsg_bn_eval_stats, rm, rv, L.c, 1e-5, mean, invstd, what=L.name, lane=self._lane)
         rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
-        self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
-                     int(relu), out.buf, rmask, what=L.name, lane=(2 if (join and self.training) else self._lane))
+        lane = 2 if (join and self.training) else self._lane
+        inl = getattr(x, "bn_inline", None) if fused else None
+        if inl is not None:
+            self.fwd.add(lib.zsg_bn_apply_from_partials, x.buf, rows, L.c, inl, x.bn_chunks, gam, bet, residual.buf if residual is not None else None,
+                         int(relu), out.buf, rmask, mean, invstd, rm, rv, 0.1, 1e-5, what=L.name, lane=lane)
+        else:
+            self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
+                         int(relu), out.buf, rmask, what=L.name, lane=lane)
 
         def back():
             if out.grad is None:
