@@ -158,7 +158,8 @@ int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t ro
 /* BatchNorm apply straight from the convolution epilogue's partial rows when there are at most zsg_bn_inline_max_chunks()
  * of them (small maps: layer3 / layer4 / pyramid sizes): every block reduces the rows for its own channels (fp64, fixed
  * order), block 0 publishes mean / invstd / the running statistics — no separate finalize launch between the convolution
- * and the normalisation.  (zsg_bn_backward does the equivalent internally for tensors of at most 32 MB.) */
+ * and the normalisation.  (The backward's partial rows are never that few at useful occupancy: a 64-chunk partial pass
+ * measured 3x slower than the finalize launch it would save.) */
 int32_t zsg_bn_inline_max_chunks(void);
 int zsg_bn_apply_from_partials(const float* x, int64_t rows, int32_t C, const float* partials, int32_t chunks, const float* gamma,
                                const float* beta, const float* residual, int32_t relu, float* out, uint8_t* relu_mask,

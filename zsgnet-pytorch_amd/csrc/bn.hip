@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---- finalize-free variants for FEW partial rows --------------------------------------------------------------------------
 // When the producer left at most BN_INL_MAX partial rows (small tensors: layer3 / layer4 / pyramid-sized maps), every block
 // of the streaming pass reduces them for its own channels itself (fp64, fixed order: deterministic) instead of waiting for a
-// separate finalize launch — one dependent ~6 us launch and one launch gap less per BatchNorm and direction.  Per block that
+// separate finalize launch — one dependent ~6 us launch and one launch gap less per such BatchNorm.  Per block that
 // is chunks x 2 coalesced 16-byte loads per thread from L2.
 #define BN_INL_MAX 64
 
@@ -279,51 +279,6 @@ __global__ __launch_bounds__(256) void bn_apply_inl_kernel(const float* __restri
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *(f32x4*)(out + r * C + c) = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_apply_inl_kernel(const float* __restrict__ dout, const float* __restrict__ relu_out,
-                                                               const uint8_t* __restrict__ relu_mask, const float* __restrict__ x,
-                                                               int64_t rows, int C, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                               const float* __restrict__ part, int chunks, float* __restrict__ dx,
-                                                               float* __restrict__ g_out, float* dgamma, float* dbeta, int accumulate,
-                                                               int lanes, int rpb) {
-    const int rowlanes = 256 / lanes;
-    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
-    const int c = (blockIdx.y * lanes + l) * 4;
-    if (c >= C) return;
-    double s[4], ss[4];
-    bn_reduce_rows(part, chunks, C, c, s, ss);
-    f32x4 c1, c2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        c1[e] = (float)(s[e] / (double)rows);
-        c2[e] = (float)(ss[e] / (double)rows);
-        if (blockIdx.x == 0 && rl == 0) {
-            if (dbeta) dbeta[c + e] = (accumulate ? dbeta[c + e] : 0.f) + (float)s[e];
-            if (dgamma) dgamma[c + e] = (accumulate ? dgamma[c + e] : 0.f) + (float)ss[e];
-        }
-    }
-    const f32x4 mu = *(const f32x4*)(mean + c);
-    const f32x4 is = *(const f32x4*)(invstd + c);
-    const f32x4 sc = is * *(const f32x4*)(gamma + c);
-    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
-    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
-    for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-        f32x4 g = *(const f32x4*)(dout + r * C + c);
-        if (relu_mask) {
-            const unsigned m = relu_mask[(r * C + c) >> 2];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
-        } else if (relu_out) {
-            const f32x4 o = *(const f32x4*)(relu_out + r * C + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-        }
-        const f32x4 xh = (*(const f32x4*)(x + r * C + c) - mu) * is;
-        if (g_out) *(f32x4*)(g_out + r * C + c) = g;
-        *(f32x4*)(dx + r * C + c) = sc * (g - c1 - xh * c2);
     }
 }
 
@@ -438,19 +393,6 @@ extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const u
     ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * ((relu_out && !relu_mask ? 3 : 2) * 2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.5 : 0)));
     float* part = (float*)ws;
     float* coef = part + (size_t)g.chunks * 2 * C;
-    if (rows * (int64_t)C <= (8 << 20)) {
-        // small tensor (<= 32 MB): BN_INL_MAX fat row chunks for the partial sums, reduced inside the apply pass — no finalize launch
-        BnGeom gp = g;
-        gp.rpb = (int)cdiv(rows, BN_INL_MAX);
-        if (gp.rpb < gp.rowlanes) gp.rpb = gp.rowlanes;
-        gp.chunks = cdiv(rows, gp.rpb);
-        hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(gp.chunks, gp.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
-                           rows, C, gp.lanes, gp.rpb, part);
-        hipLaunchKernelGGL(bn_bwd_apply_inl_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
-                           gamma, part, gp.chunks, dx, g_out, dgamma, dbeta, accumulate, g.lanes, g.rpb);
-        ZSG_CHECK_LAUNCH("bn_backward");
-        return 0;
-    }
     hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
                        rows, C, g.lanes, g.rpb, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
