@@ -84,53 +84,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// Finalize: 8 channels x 32 chunk-lanes per block; each thread strides over the chunk partials (independent loads in
-// flight instead of one serial latency chain per channel), fp64 LDS tree across the 32 lanes.
-#define BN_FC 8
-#define BN_FK 32
-__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int chunks, int C, int c, int kl, double& s, double& ss,
-                                                   double (*sm)[BN_FK][BN_FC]) {
-    s = 0;
-    ss = 0;
+// Finalize: ONE WAVE per 4 channels — lane k sums partial rows k, k+64, ... with 16-byte loads (independent loads in flight,
+// fp64 accumulation), then a wave-level fp64 butterfly: no LDS, no barriers (the previous 8-channel x 32-lane block with an
+// LDS tree took 5.7 us per launch, most of it its five barriers; 106 such launches sit on the step's critical path).
+#define BN_FW 4                       // waves per block
+__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int chunks, int C, int c, double (&s)[4], double (&ss)[4]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = ss[e] = 0;
     if (c < C) {
 #pragma unroll 4
-        for (int k = kl; k < chunks; k += BN_FK) {
-            s += (double)part[(size_t)k * 2 * C + c];
-            ss += (double)part[(size_t)k * 2 * C + C + c];
+        for (int k = lane; k < chunks; k += 64) {
+            const f32x4 a = *(const f32x4*)(part + (size_t)k * 2 * C + c);
+            const f32x4 b = *(const f32x4*)(part + (size_t)k * 2 * C + C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)a[e];
+                ss[e] += (double)b[e];
+            }
         }
     }
-    const int cl = threadIdx.x % BN_FC;
-    sm[0][kl][cl] = s;
-    sm[1][kl][cl] = ss;
-    __syncthreads();
-    for (int o = BN_FK / 2; o > 0; o >>= 1) {
-        if (kl < o) {
-            sm[0][kl][cl] += sm[0][kl + o][cl];
-            sm[1][kl][cl] += sm[1][kl + o][cl];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] = wave_sum_d(s[e]);
+        ss[e] = wave_sum_d(ss[e]);
     }
-    s = sm[0][0][cl];
-    ss = sm[1][0][cl];
 }
 
-__global__ __launch_bounds__(BN_FC * BN_FK) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
-                                                                          float* mean, float* invstd, float* rmean, float* rvar,
-                                                                          float momentum, float eps) {
-    __shared__ double sm[2][BN_FK][BN_FC];
-    const int c = blockIdx.x * BN_FC + threadIdx.x % BN_FC;
-    const int kl = threadIdx.x / BN_FC;
-    double s, ss;
-    bn_reduce_partials(part, chunks, C, c, kl, s, ss, sm);
-    if (kl != 0 || c >= C) return;
+__global__ __launch_bounds__(64 * BN_FW) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
+                                                                       float* mean, float* invstd, float* rmean, float* rvar,
+                                                                       float momentum, float eps) {
+    const int c = (blockIdx.x * BN_FW + (threadIdx.x >> 6)) * 4;
+    double s[4], ss[4];
+    bn_reduce_partials(part, chunks, C, c, s, ss);
+    const int e = threadIdx.x & 63;
+    if (e >= 4 || c + e >= C) return;              // lanes 0..3 write one channel each
+    const double se = (e == 0) ? s[0] : ((e == 1) ? s[1] : ((e == 2) ? s[2] : s[3]));
+    const double sse = (e == 0) ? ss[0] : ((e == 1) ? ss[1] : ((e == 2) ? ss[2] : ss[3]));
     const double n = (double)rows;
-    const double m = s / n;
-    double var = ss / n - m * m;
+    const double m = se / n;
+    double var = sse / n - m * m;
     if (var < 0) var = 0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
+    mean[c + e] = (float)m;
+    invstd[c + e] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c + e] = (1.f - momentum) * rmean[c + e] + momentum * (float)m;
+    if (rvar) rvar[c + e] = (1.f - momentum) * rvar[c + e] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
 }
 
 __global__ void bn_eval_stats_kernel(const float* rmean, const float* rvar, int C, float eps, float* mean, float* invstd) {
@@ -167,18 +165,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // coef[0][c] = sum g / n ; coef[1][c] = sum g*xhat / n ; dgamma/dbeta written or accumulated.
-__global__ __launch_bounds__(BN_FC * BN_FK) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
-                                                                        float* coef, float* dgamma, float* dbeta, int accumulate) {
-    __shared__ double sm[2][BN_FK][BN_FC];
-    const int c = blockIdx.x * BN_FC + threadIdx.x % BN_FC;
-    const int kl = threadIdx.x / BN_FC;
-    double s, ss;
-    bn_reduce_partials(part, chunks, C, c, kl, s, ss, sm);
-    if (kl != 0 || c >= C) return;
-    coef[c] = (float)(s / (double)rows);
-    coef[C + c] = (float)(ss / (double)rows);
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+__global__ __launch_bounds__(64 * BN_FW) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
+                                                                     float* coef, float* dgamma, float* dbeta, int accumulate) {
+    const int c = (blockIdx.x * BN_FW + (threadIdx.x >> 6)) * 4;
+    double s[4], ss[4];
+    bn_reduce_partials(part, chunks, C, c, s, ss);
+    const int e = threadIdx.x & 63;
+    if (e >= 4 || c + e >= C) return;
+    const double se = (e == 0) ? s[0] : ((e == 1) ? s[1] : ((e == 2) ? s[2] : s[3]));
+    const double sse = (e == 0) ? ss[0] : ((e == 1) ? ss[1] : ((e == 2) ? ss[2] : ss[3]));
+    coef[c + e] = (float)(se / (double)rows);
+    coef[C + c + e] = (float)(sse / (double)rows);
+    if (dbeta) dbeta[c + e] = (accumulate ? dbeta[c + e] : 0.f) + (float)se;
+    if (dgamma) dgamma[c + e] = (accumulate ? dgamma[c + e] : 0.f) + (float)sse;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ relu_out,
@@ -309,7 +308,7 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     float* part = (float*)ws;
     hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -321,7 +320,7 @@ extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks,
     ZSG_REQUIRE(partials && mean && invstd && chunks > 0 && rows > 0 && C > 0, "bn_stats_from_partials: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, partials, chunks, C, rows, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats_from_partials");
     return 0;
@@ -395,7 +394,7 @@ extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const u
     float* coef = part + (size_t)g.chunks * 2 * C;
     hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BN_FC)), dim3(BN_FC * BN_FK), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
                        gamma, coef, dx, g_out, g.lanes, g.rpb);
