@@ -785,11 +785,13 @@ class _Plan:
         # The query encoder is independent of the image encoder: its launches go to the side stream (joined where the head
         # first reads `we`), and its backward is replayed right after the head's — not at the very end of the step.
         we, lstm_tape = None, []
+        self._hoist = []
         if net.use_lang:
             t0 = len(self.tape)
             we = self._lower_lstm()
             lstm_tape = self.tape[t0:]
             del self.tape[t0:]
+        hoist_to = len(self.fwd.calls)            # right behind the query encoder
 
         # ---- encoder ------------------------------------------------------------------------------------------------------
         # (the image-blind variants still run the encoder, as the reference does, mdl.py:363-375: the pyramid sizes and the
@@ -823,6 +825,16 @@ class _Plan:
         self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
         self.tape.extend(lstm_tape)
         self._lower_head(feats, we)
+        # image-independent head launches (language / grid maps of conv0) go to the side stream BEHIND the query encoder: a
+        # side-stream launch waits for the main-stream work enqueued before it, so its place in the program decides what
+        # it can overlap — here the whole image encoder
+        moved_c, moved_l = [], []
+        for (i0, i1) in reversed(self._hoist):          # cut from the back so the earlier spans' indices stay valid ...
+            moved_c[0:0] = self.fwd.calls[i0:i1]
+            moved_l[0:0] = self.fwd.lanes[i0:i1]
+            del self.fwd.calls[i0:i1], self.fwd.lanes[i0:i1]
+        self.fwd.calls[hoist_to:hoist_to] = moved_c      # ... and re-insert in their original order
+        self.fwd.lanes[hoist_to:hoist_to] = moved_l
 
         # ---- backward program: replay the tape in reverse ----------------------------------------------------------
         if self.training:
@@ -1096,7 +1108,12 @@ class _Plan:
             hc.Fp = self.packed("head.feat", B, sizes, 256)
             heads_in = [self.l2norm(f, f"featnorm{i}", out=hc.Fp.lvl(i)) for i, f in enumerate(feats)]
         if net.do_norm and Cw:
-            hc.we = self.l2norm(we, "we.norm", lane=2)
+            # (side stream, behind the query encoder that produces `we`; hoisted together with the language maps that read it)
+            hoist = self.training and Cf
+            i0 = len(self.fwd.calls)
+            hc.we = self.l2norm(we, "we.norm", lane=(1 if hoist else 2))
+            if hoist:
+                self._hoist.append((i0, len(self.fwd.calls)))
         if Cg:
             gm = np.zeros((sum(h * w for h, w in sizes), 4), np.float32)
             o = 0
@@ -1168,19 +1185,26 @@ class _Plan:
         #   lmap[b][p][n] = G[p][n] + sum_{tap valid at p} V[b][n*9+tap],  V = W0[:, :, :, lang] . we[b],  G = conv(grid, W0[..., grid])
         lmap = None
         if Cw or Cg:
+            # None of this depends on the image: in training it runs on the side stream right behind the query encoder (the
+            # launches are moved there after lowering, see _hoist_language_maps) and conv0 joins.
+            side = 1 if (self.training and Cf) else 0
+            i0 = len(self.fwd.calls)
             V = self.act(prefix + ".V", B, 1, 1, 9 * 256, requires_grad=False)          # stays zero without language
             if Cw:
                 dv = fwd_desc(we, V, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what=prefix + "0.V", lane=2)
+                self.fwd.add(lib.zsg_conv_igemm, dv, we.buf, self.P(W0n), V.buf, None, None, None, None, what=prefix + "0.V", lane=(1 if side else 2))
             G = None
             if Cg:
                 G = self.packed(prefix + ".G", 1, sizes, 256)
                 dg = fwd_desc(gridmap, G, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-                self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what=prefix + "0.G")
+                self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what=prefix + "0.G", lane=side)
             lmap = self.packed(prefix + ".lmap", B, sizes, 256)
             for i, (h, w) in enumerate(sizes):
                 self.fwd.add(lib.zsg_head_lang_map, V.buf, self.base(G.lvl(i)) if G is not None else None, B, h, w, 256,
-                             self.base(lmap.lvl(i)), what=f"lmap{i}")
+                             self.base(lmap.lvl(i)), what=f"lmap{i}", lane=side)
+            if side:
+                self._hoist.append((i0, len(self.fwd.calls)))
+                self._join_side()
         if Cf:
             d0 = fwd_desc(Fp, h1, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0, relu=True)
             a0 = (Fp.buf, self.P(W0n), h1.buf, self.P(L0.name + ".bias"), lmap.buf if lmap is not None else None, None, None)
