@@ -285,11 +285,13 @@ def main():
             "forward": fwd, "source_stamp": source_stamp(),
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
-        dist.destroy_process_group()
+        dist.destroy_process_group()            # (RCCL prints its version banner here: keep the JSON line the LAST line of stdout)
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
