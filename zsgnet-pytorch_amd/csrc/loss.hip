@@ -152,14 +152,101 @@ __global__ __launch_bounds__(LS_THREADS) void loss_stats_kernel(const float* __r
     }
 }
 
+// Chunked pass 1 (sigmoid / focal classification, the default): the anchors of a sample are cut into LS_CHUNKS ranges so that
+// B x LS_CHUNKS blocks work instead of B (16 blocks on 256 CUs took 62 us of the step's critical path):
+//   1a  arg-max IoU of every range;  1b  every block merges the sample's range maxima (lowest index wins ties, as before),
+//   then sums its own range.  The per-range records are merged in range order (fixed order: deterministic) by pass 2.
+#define LS_CHUNKS 32
+struct LossPart {
+    double box_sum, cls_sum;
+    int npos, pad;
+};
+__global__ __launch_bounds__(256) void loss_argmax_kernel(const float* __restrict__ annot, const float* __restrict__ anchors, int A,
+                                                          ArgMax* __restrict__ amax) {
+    __shared__ ArgMax sm_a[4];
+    const int b = blockIdx.y, per = (A + LS_CHUNKS - 1) / LS_CHUNKS;
+    const int a0 = blockIdx.x * per, a1 = min(A, a0 + per);
+    const f32x4 bx = *(const f32x4*)(annot + 4 * b);
+    ArgMax m = {-INFINITY, 0x7fffffff};
+    for (int a = a0 + threadIdx.x; a < a1; a += 256) {
+        const float v = iou_exact(bx, *(const f32x4*)(anchors + 4 * a));
+        if (v > m.v) { m.v = v; m.i = a; }
+    }
+    m = block_argmax(m, sm_a);
+    if (threadIdx.x == 0) amax[b * LS_CHUNKS + blockIdx.x] = m;
+}
+__global__ __launch_bounds__(256) void loss_part_kernel(const float* __restrict__ out5, const float* __restrict__ annot,
+                                                        const float* __restrict__ anchors, int A, float alpha, float gamma, float thr,
+                                                        int flags, const ArgMax* __restrict__ amax, LossPart* __restrict__ parts) {
+    __shared__ double sm_d[4];
+    const bool use_focal = flags & 1, use_multi = flags & 2;
+    const int b = blockIdx.y, per = (A + LS_CHUNKS - 1) / LS_CHUNKS;
+    const int a0 = blockIdx.x * per, a1 = min(A, a0 + per);
+    const f32x4 bx = *(const f32x4*)(annot + 4 * b);
+    const float* o = out5 + (size_t)b * A * 5;
+    ArgMax m = amax[b * LS_CHUNKS];
+    for (int c = 1; c < LS_CHUNKS; ++c) m = argmax_merge(m, amax[b * LS_CHUNKS + c]);
+    const int best = m.i == 0x7fffffff ? 0 : m.i;
+    double box = 0, cls = 0;
+    int cnt = 0;
+    for (int a = a0 + threadIdx.x; a < a1; a += 256) {
+        const f32x4 an = *(const f32x4*)(anchors + 4 * a);
+        const float v = iou_exact(bx, an);
+        const bool pos = (use_multi && v > thr) || a == best;
+        const float t = pos ? 1.f : 0.f;
+        cnt += pos;
+        float d[4];
+        const float s = box_terms(o + a * 5, an, bx, d);
+        box += (double)(s * t);                         // multiply (not select): inf * 0 = NaN, as the reference
+        const float x = o[a * 5 + 4];
+        const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        float w = 1.f;
+        if (use_focal) {
+            const float p = 1.0f / (1.0f + expf(-x));
+            w = focal_pow(t * (1.f - p) + (1.f - t) * p, gamma) * ((1.f - t) * alpha + t * (1.f - alpha));
+        }
+        cls += (double)(w * bce);
+    }
+    box = block_sum_d(box, sm_d);
+    cls = block_sum_d(cls, sm_d);
+    const int npos = (int)(block_sum_d((double)cnt, sm_d) + 0.5);
+    if (threadIdx.x == 0) {
+        LossPart r;
+        r.box_sum = box; r.cls_sum = cls; r.npos = npos; r.pad = best;       // (pad carries the sample's arg-max for pass 2)
+        parts[b * LS_CHUNKS + blockIdx.x] = r;
+    }
+}
+
 // pass 2: totals (every block recomputes them from the B records), loss scalars, gradients.
+#define LS_MAX_B 512
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ out5, const float* __restrict__ annot,
                                                         const float* __restrict__ anchors, int B, int A, float alpha, float gamma,
                                                         float lamb, float thr, int flags, float grad_scale,
-                                                        const LossWs* __restrict__ ws, float* __restrict__ losses,
+                                                        const LossWs* __restrict__ ws_in, const LossPart* __restrict__ parts,
+                                                        float* __restrict__ losses,
                                                         float* __restrict__ grad5, int* __restrict__ match_idx, int* __restrict__ npos_out) {
     const bool use_focal = flags & 1, use_multi = flags & 2, use_softmax = flags & 4;
     const int b = blockIdx.y;
+    __shared__ LossWs ws[LS_MAX_B];
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        LossWs r;
+        if (parts) {                                     // merge the sample's range records in range order
+            r.box_sum = r.cls_sum = r.row_max = r.row_lse = 0;
+            r.npos = 0;
+            for (int c = 0; c < LS_CHUNKS; ++c) {
+                const LossPart q = parts[k * LS_CHUNKS + c];
+                r.box_sum += q.box_sum;
+                r.cls_sum += q.cls_sum;
+                r.npos += q.npos;
+            }
+            r.best = parts[k * LS_CHUNKS].pad;
+            r.pad0 = r.pad1 = 0;
+        } else {
+            r = ws_in[k];
+        }
+        ws[k] = r;
+    }
+    __syncthreads();
     double box = 0, cls = 0;
     long long npos_all = 0;
     for (int k = 0; k < B; ++k) {
@@ -212,7 +299,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
 
 extern "C" size_t zsg_loss_workspace_bytes(int32_t B, int32_t A) {
     (void)A;
-    return (size_t)B * sizeof(LossWs);
+    return (size_t)B * (sizeof(LossWs) + LS_CHUNKS * (sizeof(ArgMax) + sizeof(LossPart)));
 }
 
 extern "C" int zsg_loss_fwd_bwd(const float* out5, const float* annot, const float* anchors, int32_t B, int32_t A, float alpha, float gamma,
@@ -223,10 +310,22 @@ extern "C" int zsg_loss_fwd_bwd(const float* out5, const float* annot, const flo
     if (ws_bytes < zsg_loss_workspace_bytes(B, A)) ZSG_FAIL(-2, "loss_fwd_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("loss_fwd_bwd", st, 0, (double)B * A * 5 * 4 * 3);
-    hipLaunchKernelGGL(loss_stats_kernel, dim3(B), dim3(LS_THREADS), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags, (LossWs*)ws);
+    ZSG_REQUIRE(B <= LS_MAX_B, "loss_fwd_bwd: B=%d exceeds %d", B, LS_MAX_B);
+    LossWs* rec = (LossWs*)ws;
+    LossPart* parts = (LossPart*)(rec + B);
+    ArgMax* amax = (ArgMax*)(parts + (size_t)B * LS_CHUNKS);
+    const bool chunked = !(flags & 4) && A >= 4 * LS_CHUNKS;      // softmax needs row-wide max / sum passes: one block per sample
+    if (chunked) {
+        hipLaunchKernelGGL(loss_argmax_kernel, dim3(LS_CHUNKS, B), dim3(256), 0, st, annot, anchors, A, amax);
+        hipLaunchKernelGGL(loss_part_kernel, dim3(LS_CHUNKS, B), dim3(256), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags,
+                           (const ArgMax*)amax, parts);
+    } else {
+        hipLaunchKernelGGL(loss_stats_kernel, dim3(B), dim3(LS_THREADS), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags, rec);
+    }
     const int chunks = min(32, cdiv(A, 256));
     hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks, B), dim3(256), 0, st, out5, annot, anchors, B, A, alpha, gamma, lamb_reg, match_thr,
-                       flags, grad_scale, (const LossWs*)ws, losses, grad5, match_idx, npos);
+                       flags, grad_scale, (const LossWs*)rec, chunked ? (const LossPart*)parts : (const LossPart*)nullptr, losses, grad5,
+                       match_idx, npos);
     ZSG_CHECK_LAUNCH("loss_fwd_bwd");
     return 0;
 }

@@ -417,6 +417,7 @@ class _Plan:
         self.dev = net.device
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
+        self._prep_stream, self._prep_ev, self._prep_fwd = None, None, -1
         self.bwd = Program("bwd")
         self.tape = []
         self.acts: Dict[str, Act] = {}
@@ -1326,6 +1327,15 @@ class _Plan:
             check(lib.zsg_u8hwc_to_nhwc4(img.data_ptr(), B * self.H * self.W, self.fwd.calls[self.img_slot][1][5], stream_ptr()), "u8hwc_to_nhwc4")
         else:
             self.fwd.run(stream_ptr(), 0, 1, graph=False)          # the one launch with a per-call pointer (the caller's image)
+        if self.training and torch.is_grad_enabled() and len(self.prep):
+            # the backward's weight images (transposed filters of the data gradients, their Winograd transforms) depend on
+            # the weights only: produced here on a stream of their own, under the forward, instead of heading the backward
+            if self._prep_stream is None:
+                self._prep_stream, self._prep_ev = torch.cuda.Stream(), torch.cuda.Event()
+            self._prep_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step that wrote the weights
+            self.prep.run(self._prep_stream.cuda_stream)
+            self._prep_ev.record(self._prep_stream)
+            self._prep_fwd = self.fwd_id
         self.fwd.run(stream_ptr(), 1)
         return self.out5.buf.view(B, self.A, 5).clone()
 
@@ -1344,7 +1354,10 @@ class _Plan:
                 p.grad = net.store.view(n, net.store.grad)
         self.g5_in.view_as(g5).copy_(g5)
         ddp = getattr(net, "_ddp", None)
-        self.prep.run(st)
+        if self._prep_fwd == self.fwd_id:
+            torch.cuda.current_stream().wait_event(self._prep_ev)
+        else:
+            self.prep.run(st)
         if ddp is not None and ddp.active:
             # The reducer SUM-all-reduces the whole (accumulating) gradient buffer: a second backward before zero_grad would
             # reduce the first one's gradients again.  FusedAdam.zero_grad / dropping the p.grad clears the flag.

@@ -201,6 +201,32 @@ HIP_GRAPH = False if HIP_GRAPH == "0" else (True if HIP_GRAPH == "1" else tuple(
 GRAPH_WARMUP = 2                                             # eager replays of a range before it is captured
 
 
+# Backward: a side-stream (weight-gradient) launch is released only after this many further main-stream convolutions have
+# been enqueued.  1 = the weight gradient of a layer starts when that layer's data gradient has finished, i.e. it runs under
+# the BatchNorm backward of the next layer down (which otherwise has the GPU to itself) instead of splitting the CUs with the
+# data gradient: 15.27 -> 15.12 ms per step (tools/trace_overlap.py); 2-3 are no better.
+SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
+
+
+_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino)
+
+
+def make_side_stream():
+    """The side stream of a Program.  ZSG_SIDE_PRIO=low creates it with the device's LEAST stream priority (torch only offers
+    normal and higher): the dispatcher then serves the main stream's blocks first and the side stream's weight-gradient
+    kernels fill what is left (experiment)."""
+    if os.environ.get("ZSG_SIDE_PRIO", "") != "low":
+        return torch.cuda.Stream()
+    hip = C.CDLL("libamdhip64.so")
+    lo, hi = C.c_int(0), C.c_int(0)
+    assert hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) == 0
+    st = C.c_void_p()
+    assert hip.hipStreamCreateWithPriority(C.byref(st), C.c_uint(1), lo) == 0          # 1 = hipStreamNonBlocking
+    if os.environ.get("ZSG_VERBOSE"):
+        print(f"[zsg] side stream priority {lo.value} (range least {lo.value} .. greatest {hi.value})")
+    return torch.cuda.ExternalStream(st.value)
+
+
 class Program:
     """A static list of foreign calls.  `add(fn, *args)` marshals once; `run(stream)` replays."""
 
@@ -224,32 +250,55 @@ class Program:
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream, "Program.run expects torch's current stream"
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = make_side_stream()
             self._ev_pool = []
         side = self._side
         st0, st1 = C.c_void_p(stream), C.c_void_p(side.cuda_stream)
         dirty, used, nev = True, False, 0
+        defer = SIDE_DEFER if self.name == "bwd" else 0
+        pending = []            # deferred lane-1 launches: [index, main-stream convolutions still to enqueue before it]
+
+        def side_launch(i):
+            nonlocal dirty, used, nev
+            fn, args, what = self.calls[i]
+            if dirty:
+                if nev == len(self._ev_pool):
+                    self._ev_pool.append(torch.cuda.Event())
+                ev = self._ev_pool[nev]
+                nev += 1
+                ev.record(main)
+                side.wait_event(ev)
+                dirty = False
+            used = True
+            rc = fn(*args, st1)
+            if rc:
+                raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
+
         for i in range(start, stop):
             fn, args, what = self.calls[i]
-            if self.lanes[i] == 2 and used:
+            if self.lanes[i] == 2 and (used or pending):
+                for j, _ in pending:
+                    side_launch(j)
+                pending.clear()
                 main.wait_stream(side)
                 used = False
             if self.lanes[i] == 1:
-                if dirty:
-                    if nev == len(self._ev_pool):
-                        self._ev_pool.append(torch.cuda.Event())
-                    ev = self._ev_pool[nev]
-                    nev += 1
-                    ev.record(main)
-                    side.wait_event(ev)
-                    dirty = False
-                used = True
-                rc = fn(*args, st1)
-            else:
-                dirty = True
-                rc = fn(*args, st0)
+                if defer:
+                    pending.append([i, defer])
+                else:
+                    side_launch(i)
+                continue
+            dirty = True
+            rc = fn(*args, st0)
             if rc:
                 raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
+            if pending and fn in _MAIN_CONVS:
+                for e in pending:
+                    e[1] -= 1
+                while pending and pending[0][1] <= 0:
+                    side_launch(pending.pop(0)[0])
+        for j, _ in pending:
+            side_launch(j)
         if used:
             main.wait_stream(side)
 
@@ -377,6 +426,16 @@ def wino_mode() -> str:
     return os.environ.get("ZSG_WINO", "1")
 
 
+BX_FLAG = 1 << 26            # tile_hint bit: the bf16x6 matrix path of the kernel
+
+
+def matrix_mode() -> str:
+    """ZSG_MATRIX: 'fp32' = fp32-input MFMA only (v_mfma_f32_32x32x2_f32); 'bf16x6' = the autotuner may also pick the
+    kernels' bf16x6 variants — every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per product block,
+    fp32 accumulation: fp32-grade results (tests/test_gpu_bx.py) at 0.375 of the matrix-pipe time."""
+    return os.environ.get("ZSG_MATRIX", "fp32")
+
+
 def deterministic() -> bool:
     """ZSG_DETERMINISTIC=1: no launch may combine partial results with fp32 atomics (split-K candidates are not offered),
     so two processes that use the same tile choices (ZSG_TUNE_CACHE) produce bit-identical results."""
@@ -425,7 +484,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         return 0
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
-                         mode if wino_args is not None else "", deterministic()))
+                         mode if wino_args is not None else "", deterministic(), matrix_mode()))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -441,12 +500,16 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands.append(tile_hint(bm, bn, 1))
             if not d.merge_x and (bm == 128 or bn == 64):
                 cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup (64x64: two K groups)
+        if matrix_mode() == "bf16x6" and not d.merge_x:
+            cands += [tile_hint(bm, bn, 1, w8) | BX_FLAG for bm, bn in tiles for w8 in (0, 1)]
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
         if dense and blocks64 < 1024 and not deterministic():
             for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if sp <= n_it and blocks64 * sp <= 3072:
                     cands.append(tile_hint(64, 64, sp))
+                    if matrix_mode() == "bf16x6":
+                        cands.append(tile_hint(64, 64, sp, 1) | BX_FLAG)
                     if blocks64 * sp < 256:
                         cands.append(tile_hint(128, 64, sp))
     else:
