@@ -114,6 +114,20 @@ int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, fl
  * ------------------------------------------------------------------------------------------------------------- */
 int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
                   const float* add_src, const float* mask_src, float* bn_partials, void* stream);
+
+/* Data gradient that COMPLETES dout of a train-mode BatchNorm (out = dgrad [+ add_src]; autograd's conv backward followed by
+ * native_batch_norm_backward of fpn_resnet.py:86-97's conv-bn-relu chains): the epilogue also reduces that BatchNorm's
+ * backward sums per output tile — partials[m_tile][0][n] = sum g, partials[m_tile][1][n] = sum g * (x - mean) * invstd with
+ * g = out * relu-bit (bn_relu_mask as written by zsg_bn_apply, or NULL) — so that zsg_bn_backward_from_partials needs no
+ * pass of its own over dout and x.  bn_x / bn_relu_mask are indexed with the convolution's OUTPUT element offsets (dense
+ * [rows][N], the layout of dout).  Rows of partials: as bn_partials of zsg_conv_igemm / zsg_conv_wino for the same
+ * tile_hint.  Requires split_k <= 1, every output element covered by the launch, N % 4 == 0. */
+int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* add_src,
+                       const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                       float* partials, void* stream);
+int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* add_src,
+                      const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                      float* partials, void* stream);
 /* elements of the transformed image of a C -> N 3x3 filter: [ceil(C/8)][16][roundup(N,64)][8] */
 int64_t zsg_wino_u_elems(int32_t C, int32_t N);
 /* U = G g G^T for every job in ONE launch.  jobs: device array of { int64 src, dst (absolute device addresses);
@@ -184,6 +198,12 @@ int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float* mean, con
 int zsg_bn_backward(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,
                     const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
                     float* dgamma, float* dbeta, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same from the partial rows [chunks][2][C] of zsg_conv_igemm_bnb / zsg_conv_wino_bnb (finalize + apply: one pass over
+ * dout and x instead of two).  ws: >= 2*C floats. */
+int zsg_bn_backward_from_partials(const float* dout, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,
+                                  const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
+                                  float* dgamma, float* dbeta, int32_t accumulate, const float* partials, int32_t chunks,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Pooling / resampling / elementwise (NHWC, C % 4 == 0).

@@ -1,0 +1,125 @@
+"""BatchNorm-backward sums fused into the epilogue of the data gradient that completes dout (zsg_conv_igemm_bnb /
+zsg_conv_wino_bnb + zsg_bn_backward_from_partials) against (a) fp64 sums computed on the host and (b) the unfused
+zsg_conv_igemm + zsg_bn_backward pair on the same inputs.  Tolerances: the convolution output must be bit-identical to the
+unfused launch (same kernel, same tile); sums rel 1e-4 of their scale (fp32 partial rows, different grouping); dx / dgamma /
+dbeta rel 2e-4."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_ops import Z, dev, nhwc, ohwi, pad4, view_of  # noqa: F401
+from test_gpu_wino import make_u  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Cin (of the forward conv = channels of the BatchNorm), Cout, H, W, k, stride, accumulate, relu-mask, kernel, hint(bm,bn,w8) | (tb,bn,ps4)
+    (2, 64, 256, 19, 19, 1, 1, False, True, "igemm", (64, 64, 0)),
+    (2, 64, 256, 19, 19, 1, 1, True, True, "igemm", (128, 64, 0)),
+    (3, 128, 64, 10, 13, 1, 1, True, False, "igemm", (128, 128, 1)),
+    (2, 256, 128, 9, 9, 1, 1, False, True, "igemm", (64, 64, 1)),
+    (2, 64, 64, 21, 21, 3, 2, False, True, "igemm", (64, 64, 0)),        # 3x3 stride 2: four parity classes, all with taps
+    (2, 64, 64, 19, 19, 3, 1, False, True, "igemm", (128, 64, 1)),
+    (2, 64, 64, 19, 19, 3, 1, False, True, "wino", (64, 64, 0)),
+    (2, 128, 96, 10, 7, 3, 1, True, True, "wino", (32, 64, 1)),
+    (3, 64, 128, 5, 5, 3, 1, False, False, "wino", (32, 32, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"b{i}" for i in range(len(CASES))])
+def test_dgrad_with_bn_backward_sums(Z, case):
+    L, ops = Z
+    B, Ci, Co, H, W, k, s, acc, use_mask, kern, hint3 = case
+    g = torch.Generator().manual_seed(31 + Ci + Co + H)
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)                       # gradient w.r.t. the convolution's output
+    prev = torch.randn(B, H, W, Ci, generator=g) if acc else None      # what earlier consumers left in dout
+    xbn = torch.randn(B, H, W, Ci, generator=g) * 2 + 0.5               # BatchNorm input
+    mean, invstd = torch.randn(Ci, generator=g) * 0.3, torch.rand(Ci, generator=g) + 0.5
+    gamma = torch.rand(Ci, generator=g) + 0.5
+    bits = (torch.rand(B, H, W, Ci, generator=g) > 0.4) if use_mask else None
+    st = L.stream_ptr()
+    # reference dout in fp64
+    dxr = torch.nn.grad.conv2d_input((B, Ci, H, W), w.double(), dy.double(), s, p).permute(0, 2, 3, 1)
+    if acc:
+        dxr = dxr + prev.double()
+    gref = dxr * bits.double() if use_mask else dxr
+    xhat = (xbn.double() - mean.double()) * invstd.double()
+    s1_ref, s2_ref = gref.reshape(-1, Ci).sum(0), (gref * xhat).reshape(-1, Ci).sum(0)
+
+    Cop = pad4(Co)
+    dyd = dev(nhwc(dy, Cop))
+    dyv = view_of(ops, dyd, B, Ho, Wo, Cop)
+    wd = dev(ohwi(w))
+    wt = torch.empty((Ci, k, k, Cop), device="cuda")
+    L.check(L.lib.zsg_transpose_w(wd.data_ptr(), wt.data_ptr(), Co, k * k, Ci, Cop, st), "transpose_w")
+    rows = B * H * W
+    maskb = None
+    if use_mask:
+        bb = bits.reshape(-1, 4).to(torch.uint8)
+        maskb = dev((bb[:, 0] | (bb[:, 1] << 1) | (bb[:, 2] << 2) | (bb[:, 3] << 3)).contiguous())
+    xd, md, isd, gd = dev(xbn), dev(mean), dev(invstd), dev(gamma)
+    if kern == "wino":
+        tb, bn, ps4 = hint3
+        hint = tb | (bn << 8) | (1 << 16) | (ps4 << 24)
+        wop = make_u(L, ops, wt, Ci, Cop, k * k * Cop, Cop, True)
+        fn_plain, fn_bnb = L.lib.zsg_conv_wino, L.lib.zsg_conv_wino_bnb
+        chunks = (B * ((H + 1) // 2) * ((W + 1) // 2) + tb - 1) // tb
+    else:
+        bm, bn, w8 = hint3
+        hint = ops.tile_hint(bm, bn, 1, w8)
+        wop = wt
+        fn_plain, fn_bnb = L.lib.zsg_conv_igemm, L.lib.zsg_conv_igemm_bnb
+
+    def fresh():
+        return dev(prev.clone()) if acc else torch.full((B, H, W, Ci), float("nan"), device="cuda")
+
+    dx0 = fresh()
+    d0 = ops.dgrad_desc(dyv, view_of(ops, dx0, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)
+    assert not d0.zero_fill
+    if kern != "wino":
+        chunks = sum((B * d0.seg[i].rows_y * d0.seg[i].rows_x + bm - 1) // bm for i in range(d0.nseg))
+    L.check(fn_plain(C.byref(d0), dyd.data_ptr(), wop.data_ptr(), dx0.data_ptr(), None, dx0.data_ptr() if acc else None, None, None, st), "plain dgrad")
+    dx1 = fresh()
+    d1 = ops.dgrad_desc(dyv, view_of(ops, dx1, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)
+    part = torch.full((chunks, 2, Ci), float("nan"), device="cuda")
+    L.check(fn_bnb(C.byref(d1), dyd.data_ptr(), wop.data_ptr(), dx1.data_ptr(), dx1.data_ptr() if acc else None, xd.data_ptr(), md.data_ptr(),
+                   isd.data_ptr(), maskb.data_ptr() if use_mask else None, part.data_ptr(), st), "dgrad + bn-backward sums")
+    assert torch.equal(dx0, dx1), "the fused launch must store exactly what the plain launch stores"
+    assert float((dx1.double().cpu() - dxr).abs().max()) < 2e-4 * float(dxr.abs().max())
+    s1, s2 = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
+    assert not torch.isnan(part).any()
+    sc1 = float(gref.abs().reshape(-1, Ci).sum(0).max())
+    sc2 = float((gref * xhat).abs().reshape(-1, Ci).sum(0).max())
+    assert float((s1 - s1_ref).abs().max()) < 1e-4 * sc1, (float((s1 - s1_ref).abs().max()), sc1)
+    assert float((s2 - s2_ref).abs().max()) < 1e-4 * sc2, (float((s2 - s2_ref).abs().max()), sc2)
+
+    # finalize + apply from the partial rows  ==  the unfused zsg_bn_backward on the same dout
+    ws = torch.empty(int(L.lib.zsg_bn_workspace_bytes(rows, Ci)) // 4 + 2 * Ci, device="cuda")
+    outs = []
+    for fused in (False, True):
+        dxo, go = torch.empty(B, H, W, Ci, device="cuda"), torch.empty(B, H, W, Ci, device="cuda")
+        dga, dbe = torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda")          # accumulate into existing values
+        if fused:
+            L.check(L.lib.zsg_bn_backward_from_partials(dx1.data_ptr(), maskb.data_ptr() if use_mask else None, xd.data_ptr(), rows, Ci, md.data_ptr(),
+                                                        isd.data_ptr(), gd.data_ptr(), dxo.data_ptr(), go.data_ptr(), dga.data_ptr(), dbe.data_ptr(), 1,
+                                                        part.data_ptr(), chunks, ws.data_ptr(), ws.numel() * 4, st), "bn_backward_from_partials")
+        else:
+            L.check(L.lib.zsg_bn_backward(dx0.data_ptr(), None, maskb.data_ptr() if use_mask else None, xd.data_ptr(), rows, Ci, md.data_ptr(),
+                                          isd.data_ptr(), gd.data_ptr(), dxo.data_ptr(), go.data_ptr(), dga.data_ptr(), dbe.data_ptr(), 1,
+                                          ws.data_ptr(), ws.numel() * 4, st), "bn_backward")
+        outs.append((dxo.cpu(), go.cpu(), dga.cpu(), dbe.cpu()))
+    for a, b_, what in zip(outs[1], outs[0], ("dx", "g_out", "dgamma", "dbeta")):
+        assert torch.allclose(a, b_, rtol=2e-4, atol=2e-4 * float(b_.abs().max())), what
+    assert torch.equal(outs[1][1], outs[0][1])
+    # and against the closed form in fp64
+    n = float(rows)
+    dbeta_ref, dgamma_ref = s1_ref, s2_ref
+    dx_ref = gamma.double() * invstd.double() * (gref - dbeta_ref / n - xhat * dgamma_ref / n)
+    assert float((outs[1][0].double() - dx_ref).abs().max()) < 3e-4 * float(dx_ref.abs().max())
+    assert float((outs[1][2].double() - 1 - dgamma_ref).abs().max()) < 1e-4 * sc2 + 1e-5
+    assert float((outs[1][3].double() - 1 - dbeta_ref).abs().max()) < 1e-4 * sc1 + 1e-5

@@ -55,6 +55,9 @@ SIGNATURES = {
     "zsg_comm_wait": (I32, [P, P]),
     "zsg_comm_destroy": (I32, [P]),
     "zsg_conv_wino": (I32, [DP, P, P, P, P, P, P, P, P]),
+    "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
+    "zsg_conv_wino_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
+    "zsg_bn_backward_from_partials": (I32, [P, P, P, I64, I32, P, P, P, P, P, P, P, I32, P, I32, P, SZ, P]),
     "zsg_wino_u_elems": (I64, [I32, I32]),
     "zsg_wino_weights": (I32, [P, I32, I32, P]),
     "zsg_conv_wgrad_workspace_bytes": (SZ, [DP]),

@@ -382,6 +382,27 @@ extern "C" int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float
     return 0;
 }
 
+// zsg_bn_backward without its first pass: the (sum g, sum g * xhat) partial rows [chunks][2][C] were written by the epilogue of
+// the data-gradient convolution that completed dout (zsg_conv_igemm_bnb / zsg_conv_wino_bnb).  ws: >= 2 * C floats (coefficients).
+extern "C" int zsg_bn_backward_from_partials(const float* dout, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,
+                                             const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
+                                             float* dgamma, float* dbeta, int32_t accumulate, const float* partials, int32_t chunks,
+                                             void* ws, size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(dout && x && mean && invstd && gamma && dx && ws && partials && chunks > 0 && rows > 0 && C > 0 && (C % 4) == 0,
+                "bn_backward_from_partials: bad argument");
+    if (ws_bytes < 2 * (size_t)C * sizeof(float)) ZSG_FAIL(-2, "bn_backward_from_partials: workspace too small");
+    BnGeom g = bn_geom(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * (2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.25 : 0)));
+    float* coef = (float*)ws;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, coef, dgamma, dbeta,
+                       accumulate);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, (const float*)nullptr, relu_mask, x, rows, C, mean,
+                       invstd, gamma, coef, dx, g_out, g.lanes, g.rpb);
+    ZSG_CHECK_LAUNCH("bn_backward_from_partials");
+    return 0;
+}
+
 extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C, const float* mean,
                                const float* invstd, const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta,
                                int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {

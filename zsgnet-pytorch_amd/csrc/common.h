@@ -10,6 +10,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// BatchNorm-backward statistics fused into the epilogue of the data-gradient convolution that completes dout (the gradient
+// w.r.t. the BatchNorm's ReLU output): per output tile, per channel, (sum g, sum g * xhat) with g = dout * relu-bit and
+// xhat = (x - mean) * invstd — the pass zsg_bn_backward otherwise makes over dout and x.  x / mask are indexed with the
+// OUTPUT element offsets of the convolution (the same dense [rows][C] layout as dout).
+struct BnbDev {
+    const float* x;               // BatchNorm input (the forward convolution's output); nullptr = no fusion
+    const float* mean;
+    const float* invstd;
+    const unsigned char* mask;    // 4 ReLU bits per 16-byte group (bn_apply's relu_mask) or nullptr
+};
+
 #define ZSG_WAVE 64
 #define ZSG_NUM_CU 256
 #define ZSG_NUM_XCD 8

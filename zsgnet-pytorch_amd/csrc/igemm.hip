@@ -38,6 +38,7 @@ struct IgParams {
     int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
+    BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     IgSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     }
 
     // ---- fused BatchNorm statistics: per-column (sum, sum^2) over this tile's rows (dead rows hold exact zeros) -----
-    if (p.stats) {
+    if (p.stats && !p.bnb.x) {
         float* red = smem;                            // [2][WM][BN] — the K-loop tiles are no longer needed
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     if (vec_ok) {
         constexpr int LDC = BN + 4;
         float* ct = smem;                             // [BM][LDC] — reuses the K-loop staging area
-        if (p.stats) __syncthreads();                 // the statistics block above also used smem
+        if (p.stats && !p.bnb.x) __syncthreads();     // the statistics block above also used smem
         if (kg == 0) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -380,9 +381,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         constexpr int RPP = NT / CG;                  // rows per pass
         const int cg = tid % CG, rr = tid / CG;
         const int n = n0 + 4 * cg;
+        const bool bnb = p.bnb.x != nullptr;
+        f32x4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
         if (n < p.N) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *(const f32x4*)(p.bias + n);
+            if (bnb) {
+                mu = *(const f32x4*)(p.bnb.mean + n);
+                is = *(const f32x4*)(p.bnb.invstd + n);
+            }
 #pragma unroll 4
             for (int row = rr; row < BM; row += RPP) {
                 const int ro = rowout[row];
@@ -400,6 +407,35 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                 }
                 *(f32x4*)(p.out + o) = v;
+                if (bnb) {
+                    f32x4 g = v;
+                    if (p.bnb.mask) {
+                        const unsigned m = p.bnb.mask[o >> 2];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+                    }
+                    const f32x4 xv = *(const f32x4*)(p.bnb.x + o);
+                    q1 += g;
+                    q2 += g * ((xv - mu) * is);
+                }
+            }
+        }
+        if (bnb) {                                    // fixed-order (deterministic) reduction over the RPP row lanes
+            __syncthreads();                          // every row of ct has been read
+            float* red = smem;                        // [2][RPP][BN]
+            *(f32x4*)(red + rr * BN + 4 * cg) = q1;
+            *(f32x4*)(red + (RPP + rr) * BN + 4 * cg) = q2;
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < RPP; ++r) {
+                    a1 += red[r * BN + tid];
+                    a2 += red[(RPP + r) * BN + tid];
+                }
+                float* o = p.stats + (size_t)mt * 2 * p.N;
+                o[n0 + tid] = a1;
+                o[p.N + n0 + tid] = a2;
             }
         }
         return;
@@ -530,8 +566,8 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int
     }
 }
 
-extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                              const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
+static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
+                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
     int BM = 64, BN = 64, splits = 1, w8 = 0, bx = 0;
     pick_tile(d, &BM, &BN, &splits, &w8, &bx);
@@ -552,7 +588,15 @@ extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const fl
         const uintptr_t al = (uintptr_t)out | (uintptr_t)bias | (uintptr_t)add_src | (uintptr_t)mask_src;
         p.vec = (v && (al & 15) == 0) ? 1 : 0;
     }
-    if (bn_partials) ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu, "conv_igemm: BN-statistics fusion needs a plain (bias-free, unsplit) convolution");
+    if (bnb) {
+        ZSG_REQUIRE(bn_partials && bnb->x && bnb->mean && bnb->invstd, "conv_igemm_bnb: null argument");
+        ZSG_REQUIRE(splits == 1 && p.vec && !bias && !d->relu && !mask_src && !d->merge_x,
+                    "conv_igemm_bnb: needs an unsplit, bias-free convolution with 16-byte addressable output rows");
+        ZSG_REQUIRE((((uintptr_t)bnb->x | (uintptr_t)bnb->mean | (uintptr_t)bnb->invstd) & 15) == 0, "conv_igemm_bnb: operands not 16-byte aligned");
+        p.bnb = *bnb;
+    } else if (bn_partials) {
+        ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu, "conv_igemm: BN-statistics fusion needs a plain (bias-free, unsplit) convolution");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (splits > 1) {
         ZSG_REQUIRE(!d->relu && d->nseg == 1 && d->out_ld == d->N && d->seg[0].osy == 1 && d->seg[0].osx == 1 &&
@@ -588,4 +632,19 @@ extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const fl
     if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2, false>(p, st, flops, "igemm_kernel<128, 64, 2, 2, false>");
     if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2, false>(p, st, flops, "igemm_kernel<64, 64, 2, 2, false>");
     ZSG_FAIL(-1, "conv_igemm: unsupported tile %dx%d", BM, BN);
+}
+
+extern "C" int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
+                              const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
+    return conv_igemm_impl(d, src, wt, out, bias, add_src, mask_src, bn_partials, nullptr, stream);
+}
+
+// The data gradient that COMPLETES dout of a BatchNorm (out = acc [+ add_src]) also emits that BatchNorm's backward partials
+// [m_tiles][2][N] = per tile (sum g, sum g * xhat), g = out * relu-bit: zsg_bn_backward_from_partials then needs no pass of
+// its own over dout and x for the two sums (reference: autograd's native_batch_norm_backward after the conv's backward).
+extern "C" int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* add_src,
+                                  const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                                  float* partials, void* stream) {
+    BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
+    return conv_igemm_impl(d, src, wt, out, nullptr, add_src, nullptr, partials, &b, stream);
 }

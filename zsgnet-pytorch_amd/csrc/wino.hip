@@ -40,6 +40,7 @@ struct WnParams {
     const float* add_src;
     const float* mask_src;
     float* stats;        // optional BatchNorm partials [m_blocks][2][N]
+    BnbDev bnb;          // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (common.h)
     int C, N, Npad, src_ld, out_ld, relu, nseg;
     int m_blocks, n_blocks, splits, chunks, vec, add_is_out;
     WnSegDev seg[ZSG_MAX_SEG];
@@ -293,9 +294,14 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
         const int cg = tid % CG, rr = tid / CG;
         const int n = n0 + 4 * cg;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        const bool bnb = p.bnb.x != nullptr;
         if (n < p.N) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *(const f32x4*)(p.bias + n);
+            if (bnb) {
+                mu = *(const f32x4*)(p.bnb.mean + n);
+                is = *(const f32x4*)(p.bnb.invstd + n);
+            }
 #pragma unroll 4
             for (int row = rr; row < TB * 4; row += RPP) {
                 const int tl = row >> 2, px = row & 3;
@@ -303,8 +309,10 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                 if (ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
                 const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
                 f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
-                s1 += v;
-                s2 += v * v;
+                if (!bnb) {
+                    s1 += v;
+                    s2 += v * v;
+                }
                 v += bv;
                 if (p.add_src) v += *(const f32x4*)(p.add_src + o);
                 if (p.relu) {
@@ -317,6 +325,17 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                 }
                 *(f32x4*)(p.out + o) = v;
+                if (bnb) {
+                    f32x4 g = v;
+                    if (p.bnb.mask) {
+                        const unsigned m = p.bnb.mask[o >> 2];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+                    }
+                    const f32x4 xv = *(const f32x4*)(p.bnb.x + o);
+                    s1 += g;
+                    s2 += g * ((xv - mu) * is);
+                }
             }
         }
         if (p.stats) {                               // fixed-order (deterministic) reduction over the RPP row lanes
@@ -454,8 +473,8 @@ static int wino_launch(const WnParams& p, hipStream_t st, double flops, const ch
 
 // tile_hint = TB | (BN << 8) | (split_k << 16) | (four position groups << 24), TB (tiles per block) and BN in {32, 64};
 // 0 = 64x64, two position groups, no split
-extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
-                             const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
+static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
+                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
     ZSG_REQUIRE(d && src && U && out, "conv_wino: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0, "conv_wino: C=%d src_ld=%d must be multiples of 4", d->C, d->src_ld);
@@ -499,8 +518,14 @@ extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const flo
     p.n_blocks = cdiv(d->N, BN);
     const uintptr_t al = (uintptr_t)out | (uintptr_t)bias | (uintptr_t)add_src | (uintptr_t)mask_src;
     p.vec = (v && (al & 15) == 0) ? 1 : 0;
-    if (bn_partials)
+    if (bnb) {
+        ZSG_REQUIRE(bn_partials && bnb->x && bnb->mean && bnb->invstd, "conv_wino_bnb: null argument");
+        ZSG_REQUIRE(splits == 1 && p.vec && !bias && !d->relu && !mask_src, "conv_wino_bnb: needs an unsplit, bias-free convolution with 16-byte addressable output rows");
+        ZSG_REQUIRE((((uintptr_t)bnb->x | (uintptr_t)bnb->mean | (uintptr_t)bnb->invstd) & 15) == 0, "conv_wino_bnb: operands not 16-byte aligned");
+        p.bnb = *bnb;
+    } else if (bn_partials) {
         ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu && p.vec, "conv_wino: BN-statistics fusion needs a plain (bias-free, unsplit, 16-byte addressable) convolution");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (splits > 1) {
         ZSG_REQUIRE(!d->relu && d->nseg == 1 && d->out_ld == d->N && d->seg[0].out_bstride == (int64_t)d->seg[0].rows_y * d->seg[0].rows_x * d->N,
@@ -521,4 +546,17 @@ extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const flo
     if (TB == 32 && BN == 64) return wino_launch<1, 2, 2>(p, st, fl, "wino_kernel<1, 2, 2>");
     if (TB == 64 && BN == 32) return wino_launch<2, 1, 2>(p, st, fl, "wino_kernel<2, 1, 2>");
     return wino_launch<1, 1, 2>(p, st, fl, "wino_kernel<1, 1, 2>");
+}
+
+extern "C" int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
+                             const float* add_src, const float* mask_src, float* bn_partials, void* stream) {
+    return conv_wino_impl(d, src, U, out, bias, add_src, mask_src, bn_partials, nullptr, stream);
+}
+
+// see zsg_conv_igemm_bnb: the data gradient that completes a BatchNorm's dout also emits that BatchNorm's backward partials
+extern "C" int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* add_src,
+                                 const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                                 float* partials, void* stream) {
+    BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
+    return conv_wino_impl(d, src, U, out, nullptr, add_src, nullptr, partials, &b, stream);
 }

@@ -16,6 +16,7 @@ The whole forward is a single autograd node, so the reference trainer's `loss.ba
 keep working while no autograd graph is built per layer.
 """
 import math
+import os
 import types
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
@@ -26,7 +27,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, wino_mode, wino_ok
+from .ops import Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, marshal, wino_mode, wino_ok
 from .params import ParamStore, pad4, register_named
 
 VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
@@ -62,6 +63,9 @@ class BnL:
     name: str
     c: int
     index: int = 0      # slot in the flat running-stat buffers
+
+
+BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward sums in the epilogue of the data gradient that completes dout
 
 
 class Act(TView):
@@ -588,7 +592,11 @@ class _Plan:
             self.fwd.add(lib.zsg_bn_stats_from_partials, partials, out.bn_chunks, rows, Lb.c, out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5,
                          what="stats:" + Lb.name, lane=self._lane)
         out.needs_mask = relu
-        self.tape.append(lambda: self._conv_bwd(L, src, out))
+        # the first consumer lowered is the LAST to add to src's gradient in the backward: if src is a train-mode BatchNorm's
+        # output, that data gradient completes the BatchNorm's dout and can carry its backward sums (see bn())
+        completes = self.training and getattr(src, "bn_out", False) and not getattr(src, "_consumed", False)
+        src._consumed = True
+        self.tape.append(lambda: self._conv_bwd(L, src, out, completes_bn=completes))
         return out
 
     def conv_bn(self, L: ConvL, Lb: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, yname=None) -> Act:
@@ -654,7 +662,7 @@ class _Plan:
         if wj.jobs:          # rotated filter transforms of the Winograd data gradients, from the transposed images
             self.prep.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino dgrad filter transforms")
 
-    def _conv_bwd(self, L: ConvL, src: Act, out: Act, dy: Optional[Act] = None):
+    def _conv_bwd(self, L: ConvL, src: Act, out: Act, dy: Optional[Act] = None, completes_bn: bool = False):
         dy = dy or out.grad
         if dy is None:
             return
@@ -665,7 +673,7 @@ class _Plan:
             self.bwd.add(lib.zsg_colsum, dy.buf[base:], 1, 0, dy.rows(), dy.ld, 0, L.cout, self.G(L.name + ".bias"), 1,
                          what="bgrad:" + L.name, lane=1)
         if src.requires_grad:
-            self.dgrad(L, dy, src, n=L.cpad)
+            self.dgrad(L, dy, src, n=L.cpad, completes_bn=completes_bn)
 
     def wgrad(self, d, src: Act, dy: Act, pname: str, what: str):
         """weight gradient of one parameter, accumulated into the flat gradient buffer (every parameter has exactly one
@@ -680,7 +688,7 @@ class _Plan:
         autotune_conv("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
         self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
 
-    def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None):
+    def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None, completes_bn: bool = False):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
         cred = dy.ld
         assert cred % 4 == 0
@@ -704,13 +712,19 @@ class _Plan:
         if wino_ok(L.k, L.stride, L.pad, L.dil) and wino_mode() != "0":
             U, job = self._wino_u(wt.data_ptr() + 4 * wt_off, n, cred, L.k * L.k * cred, cred, 1)
             wargs = (dy.buf, U) + args[2:]
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), wino_args=wargs)
+        # a split-K choice would cost the BatchNorm below its fused backward sums: a pass over dout and x plus a launch
+        pen = (0.006 + 2 * dx.rows() * n * 4 / 4e9) if (completes_bn and BNB_FUSE and not d.zero_fill and mask is None) else 0.0
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), split_penalty_ms=pen, wino_args=wargs)
         if d.use_wino:
             self.wino_jobs["bwd"].add(*job)
             self.bwd.add(lib.zsg_conv_wino, d, *wargs, what="dgrad:" + L.name)
         else:
             self.bwd.add(lib.zsg_conv_igemm, d, *args, what="dgrad:" + L.name)
         dx.gfilled = True
+        # If this launch turns out to be the one that COMPLETES a BatchNorm's dout (the BatchNorm's backward is lowered right
+        # after it), its epilogue can also produce that BatchNorm's backward sums: remember how to re-issue it (see bn()).
+        covers_all = not d.zero_fill and mask is None and ((d.tile_hint >> 16) & 0xff) <= 1 and d.tile_hint and dx.ld == n and n % 4 == 0
+        dx.last_writer = (len(self.bwd.calls) - 1, d, wargs if d.use_wino else args, "dgrad:" + L.name) if covers_all else None
 
     def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False) -> Act:
         """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2)"""
@@ -739,6 +753,8 @@ class _Plan:
             self.fwd.add(lib.zsg_bn_apply, x.buf, rows, L.c, mean, invstd, gam, bet, residual.buf if residual is not None else None,
                          int(relu), out.buf, rmask, what=L.name, lane=lane)
 
+        out.bn_out = self.training
+
         def back():
             if out.grad is None:
                 return
@@ -749,9 +765,32 @@ class _Plan:
                 assert not rg.gfilled, "residual gradient must be produced first (tape order)"
                 g_out = rg.buf
                 rg.gfilled = True
-            self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
-                         dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,
-                         what="bnbwd:" + L.name)
+            lw = getattr(out.grad, "last_writer", None)
+            fuse = (BNB_FUSE and lw is not None and lw[0] == len(self.bwd.calls) - 1 and self.bwd.lanes[lw[0]] == 0
+                    and len(out.grad.levels) == 1 and out.grad.levels[0].off == 0 and x.levels[0].off == 0 and out.grad.ld == L.c and x.ld == L.c)
+            if fuse:
+                # re-issue the data gradient that has just completed dout with the BatchNorm-backward sums in its epilogue
+                # (per-tile partial rows, reduced in a fixed order by the finalize launch: deterministic)
+                idx, d, a, what = lw
+                if d.use_wino:
+                    chunks = self._wino_chunks(d, x.B)
+                else:
+                    bm = d.tile_hint & 0xff
+                    chunks = sum((x.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
+                fuse = chunks * 2 * L.c * 4 + 2 * L.c * 4 <= self.ws_bytes
+            if fuse:
+                part = self.ws[2 * L.c:]              # (the first 2C floats of the workspace: the finalize launch's coefficients)
+                fn = lib.zsg_conv_wino_bnb if d.use_wino else lib.zsg_conv_igemm_bnb
+                # a = (src, wt|U, out, bias=None, add_src, mask=None, partials=None)
+                assert a[3] is None and a[5] is None and a[6] is None
+                self.bwd.calls[idx] = (fn, marshal(fn, (d, a[0], a[1], a[2], a[4], x.buf, mean, invstd, rmask, part), self.bwd.keep), what + "+bnb")
+                self.bwd.add(lib.zsg_bn_backward_from_partials, self.base(out.grad), rmask, x.buf, rows, L.c, mean, invstd, gam,
+                             dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, part, chunks, self.ws, self.ws_bytes,
+                             what="bnbwd:" + L.name)
+            else:
+                self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
+                             dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,
+                             what="bnbwd:" + L.name)
             dx.gfilled = True
         self.tape.append(back)
         return out
