@@ -364,6 +364,27 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     if (vec_ok) {
         constexpr int LDC = BN + 4;
         float* ct = smem;                             // [BM][LDC] — reuses the K-loop staging area
+        constexpr int CG = BN / 4;                    // 16-byte column groups per row
+        constexpr int RPP = NT / CG;                  // rows per pass
+        constexpr int NR = BM / RPP;                  // rows per thread
+        static_assert(BM % RPP == 0, "epilogue row passes");
+        const int cg = tid % CG, rr = tid / CG;
+        const int n = n0 + 4 * cg;
+        const bool bnb = p.bnb.x != nullptr;
+        // BatchNorm-backward fusion: this thread's x values and ReLU bits are requested BEFORE the accumulators go through LDS
+        // (cold HBM reads: their latency hides behind the transposition instead of ending the block)
+        f32x4 xpre[NR];
+        unsigned mpre[NR];
+        if (bnb) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int ro = rowout[rr + RPP * i];
+                const bool ok = (ro >= 0) & (n < p.N);
+                const size_t o = ok ? (size_t)ro + n : 0;
+                xpre[i] = *(const f32x4*)(p.bnb.x + o);
+                mpre[i] = p.bnb.mask ? p.bnb.mask[o >> 2] : 0xfu;
+            }
+        }
         if (p.stats && !p.bnb.x) __syncthreads();     // the statistics block above also used smem
         if (kg == 0) {
 #pragma unroll
@@ -377,11 +398,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                     }
         }
         __syncthreads();
-        constexpr int CG = BN / 4;                    // 16-byte column groups per row
-        constexpr int RPP = NT / CG;                  // rows per pass
-        const int cg = tid % CG, rr = tid / CG;
-        const int n = n0 + 4 * cg;
-        const bool bnb = p.bnb.x != nullptr;
         f32x4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
         if (n < p.N) {
             f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
@@ -390,6 +406,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                 mu = *(const f32x4*)(p.bnb.mean + n);
                 is = *(const f32x4*)(p.bnb.invstd + n);
             }
+            if (bnb) {                                // (bias / ReLU / float mask are excluded by the host for this mode)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int row = rr + RPP * i;
+                    const int ro = rowout[row];
+                    if (ro < 0) continue;
+                    const size_t o = (size_t)ro + n;
+                    f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
+                    if (p.add_src) v += *(const f32x4*)(p.add_src + o);
+                    *(f32x4*)(p.out + o) = v;
+                    f32x4 g = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = ((mpre[i] >> e) & 1u) ? g[e] : 0.f;
+                    q1 += g;
+                    q2 += g * ((xpre[i] - mu) * is);
+                }
+            } else
 #pragma unroll 4
             for (int row = rr; row < BM; row += RPP) {
                 const int ro = rowout[row];
@@ -407,17 +440,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                 }
                 *(f32x4*)(p.out + o) = v;
-                if (bnb) {
-                    f32x4 g = v;
-                    if (p.bnb.mask) {
-                        const unsigned m = p.bnb.mask[o >> 2];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
-                    }
-                    const f32x4 xv = *(const f32x4*)(p.bnb.x + o);
-                    q1 += g;
-                    q2 += g * ((xv - mu) * is);
-                }
             }
         }
         if (bnb) {                                    // fixed-order (deterministic) reduction over the RPP row lanes

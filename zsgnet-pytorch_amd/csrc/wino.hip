@@ -255,6 +255,24 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     constexpr int LDC = BN + 4;
     float* ct = smem;                               // [TB*4][LDC] — the staging area is no longer needed
     float* red = smem + TB * 4 * LDC;               // [2][RPP][BN] (statistics)
+    // BatchNorm-backward fusion: this thread's x values and ReLU bits (cold HBM reads) are requested before the output transform
+    constexpr int E_CG = BN / 4, E_RPP = NT / E_CG, E_NR = TB * 4 / E_RPP;
+    static_assert((TB * 4) % E_RPP == 0, "epilogue row passes");
+    f32x4 xpre[E_NR];
+    unsigned mpre[E_NR];
+    if (p.bnb.x) {
+        const int en = n0 + 4 * (tid % E_CG);
+#pragma unroll
+        for (int i = 0; i < E_NR; ++i) {
+            const int row = tid / E_CG + E_RPP * i;
+            const int tl = row >> 2, px = row & 3;
+            const int ro = rowinfo[2 * tl], fl = rowinfo[2 * tl + 1];
+            const bool ok = !(ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) & (en < p.N);
+            const size_t o = ok ? (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + en : 0;
+            xpre[i] = *(const f32x4*)(p.bnb.x + o);
+            mpre[i] = p.bnb.mask ? p.bnb.mask[o >> 2] : 0xfu;
+        }
+    }
 #pragma unroll
     for (int hh = 0; hh < PS; ++hh) {
         if (ph == hh) {
@@ -302,6 +320,24 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                 mu = *(const f32x4*)(p.bnb.mean + n);
                 is = *(const f32x4*)(p.bnb.invstd + n);
             }
+            if (bnb) {                                // (bias / ReLU / float mask are excluded by the host for this mode)
+#pragma unroll
+                for (int i = 0; i < E_NR; ++i) {
+                    const int row = rr + RPP * i;
+                    const int tl = row >> 2, px = row & 3;
+                    const int ro = rowinfo[2 * tl], fl = rowinfo[2 * tl + 1];
+                    if (ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
+                    const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
+                    f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
+                    if (p.add_src) v += *(const f32x4*)(p.add_src + o);
+                    *(f32x4*)(p.out + o) = v;
+                    f32x4 g = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = ((mpre[i] >> e) & 1u) ? g[e] : 0.f;
+                    s1 += g;
+                    s2 += g * ((xpre[i] - mu) * is);
+                }
+            } else
 #pragma unroll 4
             for (int row = rr; row < TB * 4; row += RPP) {
                 const int tl = row >> 2, px = row & 3;
@@ -309,10 +345,8 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                 if (ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
                 const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
                 f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
-                if (!bnb) {
-                    s1 += v;
-                    s2 += v * v;
-                }
+                s1 += v;
+                s2 += v * v;
                 v += bv;
                 if (p.add_src) v += *(const f32x4*)(p.add_src + o);
                 if (p.relu) {
@@ -325,17 +359,6 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                 }
                 *(f32x4*)(p.out + o) = v;
-                if (bnb) {
-                    f32x4 g = v;
-                    if (p.bnb.mask) {
-                        const unsigned m = p.bnb.mask[o >> 2];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
-                    }
-                    const f32x4 xv = *(const f32x4*)(p.bnb.x + o);
-                    s1 += g;
-                    s2 += g * ((xv - mu) * is);
-                }
             }
         }
         if (p.stats) {                               // fixed-order (deterministic) reduction over the RPP row lanes
