@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         const bool bnb = p.bnb.x != nullptr;
         // BatchNorm-backward fusion: this thread's x values and ReLU bits are requested BEFORE the accumulators go through LDS
         // (cold HBM reads: their latency hides behind the transposition instead of ending the block)
-        f32x4 xpre[NR];
+        f32x4 xpre[NR], apre[NR];
         unsigned mpre[NR];
         if (bnb) {
 #pragma unroll
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                 const size_t o = ok ? (size_t)ro + n : 0;
                 xpre[i] = *(const f32x4*)(p.bnb.x + o);
                 mpre[i] = p.bnb.mask ? p.bnb.mask[o >> 2] : 0xfu;
+                if (p.add_src) apre[i] = *(const f32x4*)(p.add_src + o);      // (accumulate: what earlier consumers left in dout)
             }
         }
         if (p.stats && !p.bnb.x) __syncthreads();     // the statistics block above also used smem
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                     if (ro < 0) continue;
                     const size_t o = (size_t)ro + n;
                     f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
-                    if (p.add_src) v += *(const f32x4*)(p.add_src + o);
+                    if (p.add_src) v += apre[i];
                     *(f32x4*)(p.out + o) = v;
                     f32x4 g = v;
 #pragma unroll

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     // BatchNorm-backward fusion: this thread's x values and ReLU bits (cold HBM reads) are requested before the output transform
     constexpr int E_CG = BN / 4, E_RPP = NT / E_CG, E_NR = TB * 4 / E_RPP;
     static_assert((TB * 4) % E_RPP == 0, "epilogue row passes");
-    f32x4 xpre[E_NR];
+    f32x4 xpre[E_NR], apre[E_NR];
     unsigned mpre[E_NR];
     if (p.bnb.x) {
         const int en = n0 + 4 * (tid % E_CG);
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
             const size_t o = ok ? (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + en : 0;
             xpre[i] = *(const f32x4*)(p.bnb.x + o);
             mpre[i] = p.bnb.mask ? p.bnb.mask[o >> 2] : 0xfu;
+            if (p.add_src) apre[i] = *(const f32x4*)(p.add_src + o);
         }
     }
 #pragma unroll
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                     if (ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
                     const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
                     f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
-                    if (p.add_src) v += *(const f32x4*)(p.add_src + o);
+                    if (p.add_src) v += apre[i];
                     *(f32x4*)(p.out + o) = v;
                     f32x4 g = v;
 #pragma unroll
