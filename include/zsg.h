@@ -82,7 +82,10 @@ typedef struct {
     int32_t relu;         /* epilogue: max(.,0)                                                             */
     int32_t merge_x;      /* 1: C==4 and all x-taps of a row are one contiguous run (stem / RGB input)       */
     int32_t nseg;
-    int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16); chosen by the host autotuner     */
+    int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16) | variant bits; chosen by the host autotuner.
+                           * bit 24: 8-wave workgroup (igemm, wgrad) / four position groups (wino); bit 25: 32-pixel K tiles
+                           * (wgrad); bit 26 (igemm): bf16x6 matrix path — every fp32 operand value split exactly into three
+                           * bf16 terms, six bf16 MFMAs per product block, fp32 accumulation; dropped terms <= 2^-26 |a*b|   */
     zsg_seg seg[ZSG_MAX_SEG];
 } zsg_conv_desc;
 

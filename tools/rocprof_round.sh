@@ -11,3 +11,4 @@ ZSG_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/stats_serial --output
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bx > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bx > /dev/null 2>&1
 cd $R && python tools/summarize_rocprof.py $OUT $TAG
+cp $R/gpurun_out/profiles_$TAG/${TAG}_hbm_traffic.json $R/profiles/ 2>/dev/null || true   # a bench.py run that follows in the same call picks the fresh, stamped traffic up
