@@ -25,6 +25,9 @@ CASES = [
     (2, 64, 64, 19, 19, 3, 1, False, True, "wino", (64, 64, 0)),
     (2, 128, 96, 10, 7, 3, 1, True, True, "wino", (32, 64, 1)),
     (3, 64, 128, 5, 5, 3, 1, False, False, "wino", (32, 32, 1)),
+    # many partial rows (100 / 200)
+    (4, 64, 64, 40, 40, 1, 1, False, True, "igemm", (64, 64, 0)),
+    (4, 64, 32, 40, 40, 3, 1, True, True, "wino", (32, 64, 1)),
 ]
 
 

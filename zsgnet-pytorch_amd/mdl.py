@@ -390,6 +390,7 @@ class ZSGNet(nn.Module):
         # parameter (161 AccumulateGrad nodes cost the host ~0.5 ms per step with the GPU idle at the end of backward)
         if self._anchor is None or self._anchor.device != img.device:
             self._anchor = torch.zeros(1, device=img.device, requires_grad=True)
+        plan.expect_backward = torch.is_grad_enabled()      # (grad mode is off inside autograd.Function.forward: decide here)
         out5 = _NetFn.apply(self, plan, img, qvec, qlens, h0, c0, self._anchor)
         return dict(att_out=out5[..., 4:5], bbx_out=out5[..., :4], feat_sizes=plan.feat_sizes_t,
                     num_f_out=plan.num_f_out_t, att_bbx_out=out5)
@@ -422,6 +423,7 @@ class _Plan:
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
         self._prep_stream, self._prep_ev, self._prep_fwd = None, None, -1
+        self.expect_backward = False
         self.bwd = Program("bwd")
         self.tape = []
         self.acts: Dict[str, Act] = {}
@@ -1366,7 +1368,7 @@ class _Plan:
             check(lib.zsg_u8hwc_to_nhwc4(img.data_ptr(), B * self.H * self.W, self.fwd.calls[self.img_slot][1][5], stream_ptr()), "u8hwc_to_nhwc4")
         else:
             self.fwd.run(stream_ptr(), 0, 1, graph=False)          # the one launch with a per-call pointer (the caller's image)
-        if self.training and torch.is_grad_enabled() and len(self.prep):
+        if self.training and self.expect_backward and len(self.prep):
             # the backward's weight images (transposed filters of the data gradients, their Winograd transforms) depend on
             # the weights only: produced here on a stream of their own, under the forward, instead of heading the backward
             if self._prep_stream is None:
