@@ -274,13 +274,41 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
             if (p.add_src) apre[i] = *(const f32x4*)(p.add_src + o);
         }
     }
+    if (PS == 4) {
+        // Group ph holds row i = ph of M: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3 along j, and Y = A^T z with A^T[.][i] = (1,0), (1,1),
+        // (1,-1), (0,-1): pixels (0,1) get z(0) + z(1) + z(2), pixels (2,3) get z(1) - z(2) - z(3).  Three rounds in which TWO groups
+        // work on disjoint pixel rows (fixed order: deterministic) — A: group 0 stores (0,1), group 3 stores (2,3); B: group 1 adds
+        // to (0,1), group 2 to (2,3); C: group 1 adds to (2,3), group 2 to (0,1) — instead of four rounds of one group touching all
+        // four pixels (the other twelve waves idle at the barrier): 160 instead of 448 LDS operations on the critical path.
 #pragma unroll
-    for (int hh = 0; hh < PS; ++hh) {
-        if (ph == hh) {
+        for (int rnd = 0; rnd < 3; ++rnd) {
+            const bool lo = (rnd == 0) ? (ph == 0) : ((rnd == 1) ? (ph == 1) : (ph == 2));      // this group writes pixels (0,1)
+            const bool hi = (rnd == 0) ? (ph == 3) : ((rnd == 1) ? (ph == 2) : (ph == 1));      // this group writes pixels (2,3)
+            if (lo | hi) {
+                const float sgn = (hi && ph != 1) ? -1.f : 1.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float y[4];
-                if (PS == 2) {
+                for (int e = 0; e < 16; ++e) {
+                    const float z0 = sgn * (acc[0][e] + acc[1][e] + acc[2][e]), z1 = sgn * (acc[1][e] - acc[2][e] - acc[3][e]);
+                    const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float* o = ct + (tl * 4 + (hi ? 2 : 0)) * LDC + wn * 32 + li;
+                    if (rnd == 0) {
+                        o[0] = z0;
+                        o[LDC] = z1;
+                    } else {
+                        o[0] += z0;
+                        o[LDC] += z1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int hh = 0; hh < PS; ++hh) {
+            if (ph == hh) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float y[4];
                     const float z00 = acc[0][e] + acc[2][e] + acc[4][e], z01 = acc[2][e] - acc[4][e] - acc[6][e];
                     const float z10 = acc[1][e] + acc[3][e] + acc[5][e], z11 = acc[3][e] - acc[5][e] - acc[7][e];
                     if (hh == 0) {                  // rows i = 0, 1
@@ -288,21 +316,17 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
                     } else {                        // rows i = 2, 3
                         y[0] = z00; y[1] = z01; y[2] = -z00 - z10; y[3] = -z01 - z11;
                     }
-                } else {                            // one row i = ph: coefficients A^T[0][i], A^T[1][i]
-                    const float z0 = acc[0][e] + acc[1][e] + acc[2][e], z1 = acc[1][e] - acc[2][e] - acc[3][e];
-                    const float a0 = (hh == 3) ? 0.f : 1.f, a1 = (hh == 0) ? 0.f : ((hh == 1) ? 1.f : -1.f);
-                    y[0] = a0 * z0; y[1] = a0 * z1; y[2] = a1 * z0; y[3] = a1 * z1;
-                }
-                const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float* o = ct + (tl * 4) * LDC + wn * 32 + li;
+                    const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float* o = ct + (tl * 4) * LDC + wn * 32 + li;
 #pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    if (hh == 0) o[px * LDC] = y[px];
-                    else o[px * LDC] += y[px];
+                    for (int px = 0; px < 4; ++px) {
+                        if (hh == 0) o[px * LDC] = y[px];
+                        else o[px * LDC] += y[px];
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- epilogue: bias, residual / accumulate, relu, relu-mask, BatchNorm partial statistics ---------------------------
