@@ -321,6 +321,11 @@ def main():
         dist.destroy_process_group()            # (RCCL prints its version banner here: keep the JSON line the LAST line of stdout)
     if rank == 0:
         sys.stdout.flush()
+        try:                                    # RCCL's banner sits in the C library's stdout buffer until exit: push it out first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
 

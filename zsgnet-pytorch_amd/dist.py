@@ -10,7 +10,7 @@ on all of them.  The same code runs on CPU tensors over gloo, which is how it is
 """
 import os
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -130,20 +130,36 @@ class BucketReducer:
         self.flat, self.buckets, self.group, self.comm = flat, buckets, group, comm
         self.pending = []
 
-    def run(self, n_launches: int, launch_range: Callable[[int, int], None]):
-        """launch_range(i, j) enqueues launches [i, j).  After the launch with index b.ready, bucket b is reduced."""
+    def run(self, n_launches: int, launch_range: Callable[[int, int], None], side_stream: Optional[Callable[[], Any]] = None):
+        """launch_range(i, j) enqueues launches [i, j).  After the launch with index b.ready, bucket b is reduced.
+        side_stream() (optional): a second compute stream that launch_range also enqueues on (the weight-gradient kernels) and
+        does NOT join at the end of a range — the collective is then issued from that stream once it has caught up with the
+        main stream, and the critical chain on the main stream never waits for the weight gradients at a bucket boundary (the join cost 0.67 ms of a
+        15.5 ms step in a 1-rank group)."""
         done = 0
         for b in self.buckets:
             upto = min(max(b.ready + 1, done), n_launches)
             if upto > done:
                 launch_range(done, upto)
                 done = upto
-            if self.comm is not None:
-                self.comm.all_reduce(self.flat[b.start:b.end])
+            t = self.flat[b.start:b.end]
+            side = side_stream() if side_stream is not None else None
+            if side is not None and t.is_cuda:
+                # issued from the side stream after it has caught up with the main stream: the collective is then ordered after
+                # BOTH (no third stream: HIP streams share 4 hardware queues, see ops.shared_side_stream)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._reduce(t)
             else:
-                self.pending.append(dist.all_reduce(self.flat[b.start:b.end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce(t)
         if done < n_launches:
             launch_range(done, n_launches)
+
+    def _reduce(self, t: torch.Tensor):
+        if self.comm is not None:
+            self.comm.all_reduce(t)
+        else:
+            self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
         if self.comm is not None:

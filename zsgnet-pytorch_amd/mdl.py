@@ -27,7 +27,8 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, marshal, wino_mode, wino_ok
+from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, marshal, shared_side_stream,
+                  wino_mode, wino_ok)
 from .params import ParamStore, pad4, register_named
 
 VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
@@ -1370,9 +1371,9 @@ class _Plan:
             self.fwd.run(stream_ptr(), 0, 1, graph=False)          # the one launch with a per-call pointer (the caller's image)
         if self.training and self.expect_backward and len(self.prep):
             # the backward's weight images (transposed filters of the data gradients, their Winograd transforms) depend on
-            # the weights only: produced here on a stream of their own, under the forward, instead of heading the backward
+            # the weights only: produced here on the side stream, under the forward, instead of heading the backward
             if self._prep_stream is None:
-                self._prep_stream, self._prep_ev = torch.cuda.Stream(), torch.cuda.Event()
+                self._prep_stream, self._prep_ev = shared_side_stream(), torch.cuda.Event()
             self._prep_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step that wrote the weights
             self.prep.run(self._prep_stream.cuda_stream)
             self._prep_ev.record(self._prep_stream)
@@ -1413,7 +1414,10 @@ class _Plan:
                 ents = net.store.entries
                 spans = [(ents[n].offset, (ents[n].size + 3) // 4 * 4, self.grad_ready.get(n, -1)) for n in net._param_names]
                 self.reducer = ddp.make_reducer(spans)
-            self.reducer.run(len(self.bwd.calls), lambda i, j: self.bwd.run(st, i, j))
+            # (join=False: a range that ends at a bucket boundary leaves the side stream's weight gradients running; the
+            # bucket's collective waits for both streams, the main stream only joins at the very end)
+            nb = len(self.bwd.calls)
+            self.reducer.run(nb, lambda i, j: self.bwd.run(st, i, j, join=(j == nb)), side_stream=lambda: self.bwd._side)
             self.reducer.wait()
         else:
             self.bwd.run(st)

@@ -211,6 +211,20 @@ SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
 _MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino)
 
 
+_SIDE = {}
+
+
+def shared_side_stream():
+    """ONE side stream per device for every Program (forward, backward, the backward's weight preparation): ROCm multiplexes HIP
+    streams onto 4 hardware queues per process, and two streams that share a queue serialise — with a stream per Program plus a
+    preparation stream, RCCL's stream (DDP) pushed the count past four and the 'concurrent' weight gradients queued behind the
+    critical chain."""
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = make_side_stream()
+    return _SIDE[dev]
+
+
 def make_side_stream():
     """The side stream of a Program.  ZSG_SIDE_PRIO=low creates it with the device's LEAST stream priority (torch only offers
     normal and higher): the dispatcher then serves the main stream's blocks first and the side stream's weight-gradient
@@ -237,20 +251,21 @@ class Program:
                                 # join); 2 = the caller's stream after it has waited for the side stream (a join)
         self.keep = []          # ctypes structs / tensors that must outlive the program
         self._side = None
+        self._side_busy = False
         self._graphs = {}       # (start, stop, side-stream mode) -> [eager replays so far, captured graph | None]
 
     def add(self, fn, *args, what: str = "", lane: int = 0):
         self.calls.append((fn, marshal(fn, args, self.keep), what or fn.__name__))
         self.lanes.append(lane)
 
-    def _run_lanes(self, stream: int, start: int, stop: int):
+    def _run_lanes(self, stream: int, start: int, stop: int, join: bool = True):
         """Replay with lane-1 launches on a side HIP stream: each one waits for everything enqueued on the main stream
         before it (its inputs), and the main stream re-joins the side stream at the end of the range.  Weight-gradient
         kernels are leaves of the backward graph, so they fill the CUs the critical path's small launches leave idle."""
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream, "Program.run expects torch's current stream"
         if self._side is None:
-            self._side = make_side_stream()
+            self._side = shared_side_stream()
             self._ev_pool = []
         side = self._side
         st0, st1 = C.c_void_p(stream), C.c_void_p(side.cuda_stream)
@@ -270,18 +285,19 @@ class Program:
                 side.wait_event(ev)
                 dirty = False
             used = True
+            self._side_busy = True              # (survives the call: a later range may have to join what this one started)
             rc = fn(*args, st1)
             if rc:
                 raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
 
         for i in range(start, stop):
             fn, args, what = self.calls[i]
-            if self.lanes[i] == 2 and (used or pending):
+            if self.lanes[i] == 2 and (self._side_busy or pending):
                 for j, _ in pending:
                     side_launch(j)
                 pending.clear()
                 main.wait_stream(side)
-                used = False
+                used = self._side_busy = False
             if self.lanes[i] == 1:
                 if defer:
                     pending.append([i, defer])
@@ -299,10 +315,11 @@ class Program:
                     side_launch(pending.pop(0)[0])
         for j, _ in pending:
             side_launch(j)
-        if used:
+        if join and self._side_busy:
             main.wait_stream(side)
+            self._side_busy = False
 
-    def run(self, stream: int, start: int = 0, stop: Optional[int] = None, graph: bool = True):
+    def run(self, stream: int, start: int = 0, stop: Optional[int] = None, graph: bool = True, join: bool = True):
         """Replay calls[start:stop] on `stream` (torch's current stream), eagerly by default (3.4-3.9 us of host time per
         launch: the host stays ahead of the GPU).  With HIP_GRAPH on, a range that has been replayed GRAPH_WARMUP times is
         captured into a hipGraph (both lanes, with their event edges) and launched as ONE graph from then on — measured
@@ -318,7 +335,7 @@ class Program:
                 torch.cuda.synchronize()
             return
         if not (HIP_GRAPH and graph) or stop - start < 8 or (isinstance(HIP_GRAPH, tuple) and self.name not in HIP_GRAPH):
-            return self._run_eager(stream, start, stop)
+            return self._run_eager(stream, start, stop, join)
         key = (start, stop, SIDE_STREAM)
         ent = self._graphs.setdefault(key, [0, None])
         if ent[1] is not None:
@@ -334,9 +351,9 @@ class Program:
         ent[1] = g
         g.replay()
 
-    def _run_eager(self, stream: int, start: int, stop: int):
+    def _run_eager(self, stream: int, start: int, stop: int, join: bool = True):
         if SIDE_STREAM and any(self.lanes[start:stop]):
-            return self._run_lanes(stream, start, stop)
+            return self._run_lanes(stream, start, stop, join)
         st = C.c_void_p(stream)
         for fn, args, what in self.calls[start:stop]:
             rc = fn(*args, st)
