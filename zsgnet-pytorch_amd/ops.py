@@ -208,7 +208,7 @@ GRAPH_WARMUP = 2                                             # eager replays of 
 SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
 
 
-_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino)
+_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb)
 
 
 _SIDE = {}
