@@ -426,6 +426,7 @@ class _Plan:
         self._prep_stream, self._prep_ev, self._prep_fwd = None, None, -1
         self.expect_backward = False
         self.bwd = Program("bwd")
+        self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
         self.tape = []
         self.acts: Dict[str, Act] = {}
         self.bytes = 0

@@ -206,6 +206,12 @@ GRAPH_WARMUP = 2                                             # eager replays of 
 # the BatchNorm backward of the next layer down (which otherwise has the GPU to itself) instead of splitting the CUs with the
 # data gradient: 15.27 -> 15.12 ms per step (tools/trace_overlap.py); 2-3 are no better.
 SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
+# ... and only at every n-th main-stream convolution: every release costs the main stream an event record, i.e. a marker packet
+# the next kernel has to wait for (~4 us each: doubling the ~70 records of a ResNet-50 backward costs 0.28 ms).  Measured on
+# configs[1]: n = 1 / 2 / 3 / 4 / 5 / 6 -> 14.59 / 14.66 / 14.40 / 14.56 / 14.41 / 14.51 ms; SSD-VGG B=32 39.49 -> 39.15 ms;
+# ResNet-18 neutral; ResNet-101 @600^2 B=32 (launches of several hundred us: overlap matters, markers do not) 110.4 -> 111.9 ms,
+# hence the plan picks 3 for small launches and 1 for large ones unless ZSG_SIDE_BATCH says otherwise (Program.side_batch).
+SIDE_BATCH = int(os.environ.get("ZSG_SIDE_BATCH", "0"))
 
 
 _MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb)
@@ -251,6 +257,7 @@ class Program:
                                 # join); 2 = the caller's stream after it has waited for the side stream (a join)
         self.keep = []          # ctypes structs / tensors that must outlive the program
         self._side = None
+        self.side_batch = 1     # deferred side launches are released at every side_batch-th main-stream convolution
         self._side_busy = False
         self._graphs = {}       # (start, stop, side-stream mode) -> [eager replays so far, captured graph | None]
 
@@ -272,6 +279,7 @@ class Program:
         dirty, used, nev = True, False, 0
         defer = SIDE_DEFER if self.name == "bwd" else 0
         pending = []            # deferred lane-1 launches: [index, main-stream convolutions still to enqueue before it]
+        nconv, batch = 0, max(1, SIDE_BATCH or self.side_batch)
 
         def side_launch(i):
             nonlocal dirty, used, nev
@@ -311,8 +319,10 @@ class Program:
             if pending and fn in _MAIN_CONVS:
                 for e in pending:
                     e[1] -= 1
-                while pending and pending[0][1] <= 0:
-                    side_launch(pending.pop(0)[0])
+                nconv += 1
+                if nconv % batch == 0:
+                    while pending and pending[0][1] <= 0:
+                        side_launch(pending.pop(0)[0])
         for j, _ in pending:
             side_launch(j)
         if join and self._side_busy:
