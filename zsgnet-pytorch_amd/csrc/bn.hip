@@ -245,9 +245,42 @@ __global__ __launch_bounds__(256) void bn_apply_inl_kernel(const float* __restri
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     const int c = (blockIdx.y * lanes + l) * 4;
-    if (c >= C) return;
+    // the block's row lanes share the reduction of the partial rows (row lane rl takes rows rl, rl + rowlanes, ...) and combine
+    // through LDS in row-lane order (fixed: deterministic): a rowlanes-times shorter chain of dependent L2 loads than every
+    // thread walking all rows (the prologue was most of these small launches)
+    __shared__ double sh[8][256];
     double s[4], ss[4];
-    bn_reduce_rows(part, chunks, C, c, s, ss);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = ss[e] = 0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = rl; k < chunks; k += rowlanes) {
+            const f32x4 a = *(const f32x4*)(part + (size_t)k * 2 * C + c);
+            const f32x4 b = *(const f32x4*)(part + (size_t)k * 2 * C + C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)a[e];
+                ss[e] += (double)b[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[e][threadIdx.x] = s[e];
+        sh[4 + e][threadIdx.x] = ss[e];
+    }
+    __syncthreads();
+    if (c >= C) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double a = 0, b = 0;
+        for (int r = 0; r < rowlanes; ++r) {
+            a += sh[e][r * lanes + l];
+            b += sh[4 + e][r * lanes + l];
+        }
+        s[e] = a;
+        ss[e] = b;
+    }
     const double n = (double)rows;
     f32x4 mu, is;
 #pragma unroll
