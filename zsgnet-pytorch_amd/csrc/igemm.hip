@@ -364,6 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     if (vec_ok) {
         constexpr int LDC = BN + 4;
         float* ct = smem;                             // [BM][LDC] — reuses the K-loop staging area
+        static_assert(BM * LDC <= 2 * (BM + BN) * LDR, "the transposed output tile must fit the K-loop staging area (a 256x128 tile does not)");
         constexpr int CG = BN / 4;                    // 16-byte column groups per row
         constexpr int RPP = NT / CG;                  // rows per pass
         constexpr int NR = BM / RPP;                  // rows per thread
