@@ -232,19 +232,7 @@ def shared_side_stream():
 
 
 def make_side_stream():
-    """The side stream of a Program.  ZSG_SIDE_PRIO=low creates it with the device's LEAST stream priority (torch only offers
-    normal and higher): the dispatcher then serves the main stream's blocks first and the side stream's weight-gradient
-    kernels fill what is left (experiment)."""
-    if os.environ.get("ZSG_SIDE_PRIO", "") != "low":
-        return torch.cuda.Stream()
-    hip = C.CDLL("libamdhip64.so")
-    lo, hi = C.c_int(0), C.c_int(0)
-    assert hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) == 0
-    st = C.c_void_p()
-    assert hip.hipStreamCreateWithPriority(C.byref(st), C.c_uint(1), lo) == 0          # 1 = hipStreamNonBlocking
-    if os.environ.get("ZSG_VERBOSE"):
-        print(f"[zsg] side stream priority {lo.value} (range least {lo.value} .. greatest {hi.value})")
-    return torch.cuda.ExternalStream(st.value)
+    return torch.cuda.Stream()
 
 
 class Program:
