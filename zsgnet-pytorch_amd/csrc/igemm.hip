@@ -77,7 +77,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     const int wmn = wave % (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
     const int g = tid & 7;               // 16-byte k-group staged by this thread
-    const int r0 = tid >> 3;             // first staged row
+    // first staged row.  BX: the three 8-byte plane stores of a split value go out in 16-lane groups = two rows; at the 52-word row
+    // pitch rows r and r + 1 overlap on 4 of the 32 store banks, rows r and r + 4 do not (4 x 52 = 16 mod 32) — so lane bit 3 selects
+    // row bit 2 (PMC: 15.3 M conflict cycles on the head-sized launch with the linear order)
+    const int r0 = BX ? ((tid >> 6) << 3) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3) : tid >> 3;
 
     const int n_tiles_mn = p.m_tiles * p.n_tiles;
     const int split = blockIdx.x / n_tiles_mn;
