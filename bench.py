@@ -169,7 +169,7 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss_val, acc = float(ls["loss"]), float(em["Acc"])
+    loss_val, acc = float(ls["loss"].detach()), float(em["Acc"])
     ips = a.bs * world * a.steps / dt
 
     # (forward-only and bf16x6 legs run BEFORE the per-kernel profiled legs: bracketing every launch with timing events leaves the
@@ -216,7 +216,7 @@ def main():
         fgf = FWD_GF.get(a.arch) if a.img == 300 else None
         bx = {"value": round(a.bs * world * a.steps / dtb, 2), "unit": "images/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
               "step_mfma_frac": round((a.bs * a.steps / dtb) * 3 * fgf * 1e9 / (PEAK_TF * 1e12), 4) if fgf else None,
-              "final_loss": round(float(ls_b["loss"]), 4), "launch_shapes_on_bf16x6": nbx,
+              "final_loss": round(float(ls_b["loss"].detach()), 4), "launch_shapes_on_bf16x6": nbx,
               "what": "same step with ZSG_MATRIX=bf16x6: implicit-GEMM forward/data-gradient launches may run the exact-split bf16x6 "
                       "matrix path where the autotuner finds it faster (fp32-grade results; algorithmic FLOPs / fp32-MFMA peak)"}
         os.environ["ZSG_MATRIX"] = "fp32"
