@@ -254,9 +254,12 @@ class Program:
         self.lanes.append(lane)
 
     def _run_lanes(self, stream: int, start: int, stop: int, join: bool = True):
-        """Replay with lane-1 launches on a side HIP stream: each one waits for everything enqueued on the main stream
-        before it (its inputs), and the main stream re-joins the side stream at the end of the range.  Weight-gradient
-        kernels are leaves of the backward graph, so they fill the CUs the critical path's small launches leave idle."""
+        """Replay with lane-1 launches on the side HIP stream: each one waits for everything enqueued on the main stream
+        before its release (its inputs), and the main stream re-joins the side stream at lane-2 launches and — unless
+        join=False (a DDP bucket boundary: the collective waits for both streams instead) — at the end of the range.
+        Weight-gradient kernels are leaves of the backward graph, so they fill the CUs the critical chain's small launches
+        leave idle; in the backward program their release is deferred (SIDE_DEFER) and batched (side_batch): every release
+        costs the main stream one event record."""
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream, "Program.run expects torch's current stream"
         if self._side is None:
@@ -264,13 +267,13 @@ class Program:
             self._ev_pool = []
         side = self._side
         st0, st1 = C.c_void_p(stream), C.c_void_p(side.cuda_stream)
-        dirty, used, nev = True, False, 0
+        dirty, nev = True, 0
         defer = SIDE_DEFER if self.name == "bwd" else 0
         pending = []            # deferred lane-1 launches: [index, main-stream convolutions still to enqueue before it]
         nconv, batch = 0, max(1, SIDE_BATCH or self.side_batch)
 
         def side_launch(i):
-            nonlocal dirty, used, nev
+            nonlocal dirty, nev
             fn, args, what = self.calls[i]
             if dirty:
                 if nev == len(self._ev_pool):
@@ -280,7 +283,6 @@ class Program:
                 ev.record(main)
                 side.wait_event(ev)
                 dirty = False
-            used = True
             self._side_busy = True              # (survives the call: a later range may have to join what this one started)
             rc = fn(*args, st1)
             if rc:
@@ -293,7 +295,7 @@ class Program:
                     side_launch(j)
                 pending.clear()
                 main.wait_stream(side)
-                used = self._side_busy = False
+                self._side_busy = False
             if self.lanes[i] == 1:
                 if defer:
                     pending.append([i, defer])
