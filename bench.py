@@ -36,9 +36,21 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FWD_GF = {"resnet50": 32.569, "resnet101": None, "resnet18": None, "ssd_vgg": 75.003}     # BASELINE.md §3 (conv 2*MAC per image @300^2)
+# forward conv 2*MAC per image, keyed by (arch, input size); a training step is 3x
+FWD_GF = {("resnet50", 300): 32.569, ("ssd_vgg", 300): 75.003, ("resnet50", 600): 85.911, ("resnet101", 600): 140.609}
 PEAK_TF = 157.3                                                         # fp32-input MFMA, MI355X_MICROARCH.md
-ROUND = "r02"
+ROUND = "r03"
+
+
+def config_label(arch: str, backbone: str, img: int, bs: int, world: int) -> str:
+    """Which BASELINE.json configs[] entry this run has the (per-GPU) shape of"""
+    if backbone == "ssd_vgg" and img == 300:
+        return f"BASELINE configs[3] shape{'' if bs == 32 else f' at per-GPU bs={bs} (configs[3]: 32)'}"
+    if arch == "resnet101" and img == 600:
+        return f"BASELINE configs[4] per-GPU shape{'' if bs == 32 else f' at per-GPU bs={bs} (configs[4]: 32)'}"
+    if arch == "resnet50" and img == 300 and bs == 16:
+        return "BASELINE configs[1] shape" if world == 1 else f"BASELINE configs[2] per-GPU shape, {world} ranks"
+    return "not a BASELINE configs[] shape"
 
 
 def exec_ratio(kernel: str) -> float:
@@ -73,7 +85,26 @@ def parse():
     ap.add_argument("--no-bx", action="store_true", help="skip the second measurement with the bf16x6 matrix path enabled")
     ap.add_argument("--prof-out", default="")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in the RCCL data-parallel reducer even at world size 1 (smoke test)")
+    ap.add_argument("--launch-check", action="store_true", help="only bring up the N-rank process group (backend ZSG_DIST_BACKEND, default "
+                    "nccl), all-reduce one tensor and print a JSON line: tests the launcher without a GPU (gloo)")
     return ap.parse_args()
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU of this node, env://
+    rendezvous on 127.0.0.1 at a free port (the reference does the same through `python -m torch.distributed.launch
+    --nproc_per_node=$ngpus code/main_dist.py`, README.md:69-76 / main_dist.py:70-77).  The children's stdout is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL / cross-process device memory on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(arch, img, tokens):
@@ -106,9 +137,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))                    # no launcher around us: become one (one rank per GPU)
+    if a.launch_check:
+        from zsgnet_pytorch_amd import dist as zdist
+        backend = os.environ.get("ZSG_DIST_BACKEND", "nccl")
+        zdist.init_process_group_from_env(backend)
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.ones(4, device=dev) * (rank + 1)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        ok = float(t[0]) == world * (world + 1) / 2
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": ok, "n_gpus": world, "backend": backend}), flush=True)
+        raise SystemExit(0 if ok else 1)
     local = local % max(1, torch.cuda.device_count())      # (a 1-GPU box can host a 2-rank gloo dry run of the N > 1 control flow)
     torch.cuda.set_device(local)
     from zsgnet_pytorch_amd import config, dist as zdist, evaluator, loss, mdl, optim
@@ -176,20 +221,23 @@ def main():
     # process ~3 % slower afterwards)
     fwd = None
     if not a.no_roofline:          # every rank (the training forward of a DDP model broadcasts the BatchNorm buffers)
+        # grad mode ON, as in a training step: the forward then also co-schedules the backward's weight preparation on the side
+        # stream (mdl._Plan.run_forward), which a no_grad forward would leave out.  (The 21 forwards advance the BatchNorm running
+        # statistics; nothing below depends on them.)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-        with torch.no_grad():
+        model(batch)
+        torch.cuda.synchronize()
+        evs[0].record()
+        for i in range(20):
             model(batch)
-            torch.cuda.synchronize()
-            evs[0].record()
-            for i in range(20):
-                model(batch)
-                evs[i + 1].record()
+            evs[i + 1].record()
         torch.cuda.synchronize()
         fm = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))[10]
-        fgf = FWD_GF.get(a.arch) if a.img == 300 else None
+        fgf = FWD_GF.get((a.arch, a.img))
         fwd = {"median_ms": round(fm, 3), "images_per_s": round(a.bs / fm * 1e3, 1),
                "mfma_frac": round(a.bs * fgf * 1e9 / (fm * 1e-3) / (PEAK_TF * 1e12), 4) if fgf else None,
-               "what": "train-mode ZSGNet.forward only (batch-statistics BatchNorm), algorithmic conv FLOPs / fp32-MFMA peak"}
+               "what": "train-mode ZSGNet.forward only, grad mode on (batch-statistics BatchNorm; the backward's weight preparation "
+                       "co-runs on the side stream as in a step), algorithmic conv FLOPs / fp32-MFMA peak"}
     bx = None
     if not a.no_bx and os.environ.get("ZSG_MATRIX", "fp32") == "fp32":
         # Second measurement, same step, same steps/warmup: the autotuner may also pick the kernels' bf16x6 variants (fp32
@@ -213,7 +261,7 @@ def main():
             dtb = float(t.item())
         from zsgnet_pytorch_amd import ops as zops2
         nbx = sum(1 for v in zops2._TUNE_CACHE.values() if v & zops2.BX_FLAG and not v & zops2.WINO_FLAG)
-        fgf = FWD_GF.get(a.arch) if a.img == 300 else None
+        fgf = FWD_GF.get((a.arch, a.img))
         bx = {"value": round(a.bs * world * a.steps / dtb, 2), "unit": "images/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
               "step_mfma_frac": round((a.bs * a.steps / dtb) * 3 * fgf * 1e9 / (PEAK_TF * 1e12), 4) if fgf else None,
               "final_loss": round(float(ls_b["loss"].detach()), 4), "launch_shapes_on_bf16x6": nbx,
@@ -276,25 +324,36 @@ def main():
         mfma_ms = sum(r["ms_per_step"] for r in iso_rows if r["tflops"])
         exe_all = sum((r["tflops"] or 0) * r["ms_per_step"] * exec_ratio(r["kernel"]) for r in iso_rows)
         if dom["tflops"]:
+            # `achieved` / `frac` are what the matrix pipe EXECUTES: algorithmic 2*MAC of the direct convolution x the kernel's
+            # executed share (Winograd F(2x2,3x3) / F(3x3,2x2): 16 multiplies per 2x2 tile and channel pair instead of 36 = 4/9),
+            # so frac <= 1 by construction; the algorithmic rate (what the direct convolution would have needed) is carried beside it.
             er = exec_ratio(dom["kernel"])
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": traffic, "traffic_note": tnote,
-                    "flops": "algorithmic 2*MAC of the direct convolution" + (" (Winograd F(2x2,3x3): 4/9 of them are executed)" if er < 1 else ""),
-                    "mfma_executed": {"achieved": round(dom["tflops"] * er, 2), "frac": round(dom["tflops"] * er / PEAK_TF, 4)},
+            share_exec = (exe_all / flops_all) if flops_all else 1.0       # FLOP-weighted executed share over all MFMA kernels
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"] * er, 2), "peak": PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(dom["tflops"] * er / PEAK_TF, 4), "traffic": traffic, "traffic_note": tnote,
+                    "flops": "EXECUTED MFMA FLOPs: algorithmic 2*MAC of the direct convolution" + (" x 4/9 (Winograd: 16 of 36 multiplies per 2x2 tile)" if er < 1 else ""),
+                    "executed_over_algorithmic": round(er, 4),
+                    "algorithmic_achieved": round(dom["tflops"], 2), "algorithmic_frac": round(dom["tflops"] / PEAK_TF, 4),
+                    "ceiling_algorithmic": round(1.0 / share_exec, 4),
+                    "ceiling_note": "algorithmic FLOPs / peak that the step's kernel mix permits at 100 % MFMA utilisation = 1 / sum(FLOP share x executed share)",
                     "avg_launch_ms": round(dom["ms_per_step"] / dom["launches_per_step"], 5), "launches_per_step": dom["launches_per_step"],
                     "kernel_ms_per_step": round(dom["ms_per_step"], 3), "all_kernels_ms_per_step": round(iso_tot, 3),
                     "rocprof_avg_launch_ms": rp_ser, "mode": "one stream (ZSG_SIDE_STREAM=0): every launch alone on the GPU",
-                    "as_timed": {"achieved": round(timed["tflops"], 2), "frac": round(timed["tflops"] / PEAK_TF, 4),
+                    "as_timed": {"achieved": round(timed["tflops"] * er, 2), "frac": round(timed["tflops"] * er / PEAK_TF, 4),
+                                 "algorithmic_frac": round(timed["tflops"] / PEAK_TF, 4),
                                  "avg_launch_ms": round(timed["ms_per_step"] / timed["launches_per_step"], 5),
                                  "rocprof_avg_launch_ms": rp_avg, "all_kernels_ms_per_step": round(tot, 3),
                                  "mode": "weight-gradient kernels co-running on the side stream"} if timed and timed["tflops"] else None,
-                    "all_mfma_kernels": {"achieved": round(flops_all / mfma_ms, 2) if mfma_ms else None,
-                                         "frac": round(flops_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
-                                         "mfma_executed_frac": round(exe_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
+                    "all_mfma_kernels": {"achieved": round(exe_all / mfma_ms, 2) if mfma_ms else None,
+                                         "frac": round(exe_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
+                                         "algorithmic_frac": round(flops_all / mfma_ms / PEAK_TF, 4) if mfma_ms else None,
                                          "ms_per_step": round(mfma_ms, 3)},
                     "top_kernels": [{"kernel": r["kernel"], "ms_per_step": round(r["ms_per_step"], 3), "launches_per_step": r["launches_per_step"],
-                                     "tflops": round(r["tflops"], 1) if r["tflops"] else None, "gbps": round(r["gbps"], 0) if r["gbps"] else None}
-                                    for r in iso_rows[:8]]}
+                                     "tflops_executed": round(r["tflops"] * exec_ratio(r["kernel"]), 1) if r["tflops"] else None,
+                                     "tflops_algorithmic": round(r["tflops"], 1) if r["tflops"] else None,
+                                     "frac": round(r["tflops"] * exec_ratio(r["kernel"]) / PEAK_TF, 3) if r["tflops"] else None,
+                                     "gbps": round(r["gbps"], 0) if r["gbps"] else None}
+                                    for r in iso_rows[:10]]}
         else:
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round((dom["gbps"] or 0) / 8000.0, 4), "traffic": traffic}
@@ -305,17 +364,27 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.arch, a.img, a.tokens)
 
+    rccl = None
+    if model is not net:               # the data-parallel exchange of this run
+        red = next((p.reducer for p in net._plans.values() if p.reducer is not None), None)
+        rccl = {"nranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+                "transport": "zsg_comm_* (RCCL inside libzsg.so)" if model.comm is not None else "torch.distributed all_reduce (ProcessGroupNCCL = RCCL)",
+                "buckets_per_step": len(red.buckets) if red else None,
+                "allreduce_bytes_per_step": int(sum(b.end - b.start for b in red.buckets) * 4) if red else None,
+                "bn_buffer_broadcast_bytes_per_step": int(net._rmv.numel() * 4)}
     if rank == 0:
-        fwd_gf = FWD_GF.get(a.arch) if a.img == 300 else None
+        fwd_gf = FWD_GF.get((a.arch, a.img))
         step_frac = (ips / world) * (3 * fwd_gf) * 1e9 / (PEAK_TF * 1e12) if fwd_gf else None
         out = {
             "metric": "train images/sec", "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "median_ms_per_step": round(median_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (img~U[0,1), qvec~N(0,.35), random boxes; random-init weights)",
             "config": {"workload": f"ZSGNet train step, {a.arch + '+FPN' if a.backbone == 'retina' else 'SSD-VGG16'}, {a.img}x{a.img}, per-GPU bs={a.bs}, {a.tokens}-token queries "
-                                   f"(BASELINE configs[{3 if a.backbone == 'ssd_vgg' else (1 if world == 1 else 2)}] shape)", "global_batch": a.bs * world,
+                                   f"({config_label(a.arch, a.backbone, a.img, a.bs, world)})", "global_batch": a.bs * world,
                        "parallelism": f"dp{world}", "step": "zero_grad+fwd+loss+bwd(+allreduce)+adam+eval"},
             "step_mfma_frac": round(step_frac, 4) if step_frac else None,
+            "step_mfma_frac_note": "whole step: ALGORITHMIC conv FLOPs (3 x forward 2*MAC) / time / fp32-MFMA peak; compare with roofline.ceiling_algorithmic, not with 1",
+            "rccl": rccl,
             "final_loss": round(loss_val, 4), "final_acc": acc,
             "forward": fwd, "source_stamp": source_stamp(),
             "bf16x6": bx, "roofline": roof, "cpu_baseline": cpu,

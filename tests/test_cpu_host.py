@@ -307,3 +307,22 @@ def test_optimizer_state_roundtrip_and_resume_rules(tmp_path):
     assert lrn2.num_it == 40 and lrn2.num_epoch == 2 and lrn2.best_met == 0.3
     assert lrn2.optimizer is not None and int(lrn2.optimizer.step_count) == 9 and lrn2.optimizer.param_groups[0]["lr"] == 1e-5
     assert float(lrn2.optimizer.m[0]) == 0.5 and lrn2.lr_scheduler.state_dict()["best"] == lrn.lr_scheduler.state_dict()["best"]
+
+
+def test_bench_self_launches_n_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher around it must become one (the reference is started by
+    `python -m torch.distributed.launch --nproc_per_node=N code/main_dist.py`, main_dist.py:70-77): two ranks come up over
+    env:// on 127.0.0.1 at a free port, all-reduce, and rank 0 prints ONE JSON line.  gloo here (no GPU); nccl on the GPU node."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ZSG_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"launch_check": True, "n_gpus": 2, "backend": "gloo"}

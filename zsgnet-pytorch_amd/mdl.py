@@ -333,9 +333,20 @@ class ZSGNet(nn.Module):
             self.store.view("att_box.5.bias").fill_(-4.0)
             self.store.view("reg_box.5.bias").zero_()
 
+    def join_weight_readers(self):
+        """Called before anything WRITES the flat weight buffer on the current stream (optimizer step, load_state_dict):
+        a training forward that was never back-propagated (metrics-only forward, discarded loss) leaves its backward weight
+        preparation running on the side stream, reading the weights — make the current stream wait for it."""
+        for plan in self._plans.values():
+            if plan._prep_pending:
+                torch.cuda.current_stream().wait_event(plan._prep_ev)
+                plan._prep_pending = False
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         """Accepts reference checkpoints: strips DDP's 'module.' prefix (utils.py:489) and tolerates torchvision's
         unused `backbone.encoder.fc.*`."""
+        if self.device.type == "cuda":
+            self.join_weight_readers()
         sd = {}
         for k, v in state_dict.items():
             k = k[7:] if k.startswith("module.") else k
@@ -423,7 +434,7 @@ class _Plan:
         self.dev = net.device
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
-        self._prep_stream, self._prep_ev, self._prep_fwd = None, None, -1
+        self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
         self.expect_backward = False
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
@@ -1378,7 +1389,7 @@ class _Plan:
             self._prep_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step that wrote the weights
             self.prep.run(self._prep_stream.cuda_stream)
             self._prep_ev.record(self._prep_stream)
-            self._prep_fwd = self.fwd_id
+            self._prep_fwd, self._prep_pending = self.fwd_id, True
         self.fwd.run(stream_ptr(), 1)
         return self.out5.buf.view(B, self.A, 5).clone()
 
@@ -1399,6 +1410,7 @@ class _Plan:
         ddp = getattr(net, "_ddp", None)
         if self._prep_fwd == self.fwd_id:
             torch.cuda.current_stream().wait_event(self._prep_ev)
+            self._prep_pending = False
         else:
             self.prep.run(st)
         if ddp is not None and ddp.active:

@@ -34,6 +34,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         g = self.param_groups[0]
         st = self.net.store
+        self.net.join_weight_readers()          # (a forward without backward may still be reading the weights on the side stream)
         check(lib.zsg_adam_step(st.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), st.flat.numel(),
                                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                 float(g["weight_decay"]), float(self.grad_scale), self.step_count.data_ptr(), stream_ptr()),
