@@ -118,6 +118,17 @@ int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, fl
 int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
                   const float* add_src, const float* mask_src, float* bn_partials, void* stream);
 
+/* The same two convolutions reading the INPUT of a train-mode BatchNorm + ReLU whose output they logically consume — the
+ * conv -> bn -> relu -> conv chains of fpn_resnet.py:86-97 (Bottleneck conv1/bn1/relu -> conv2, conv2/bn2/relu -> conv3) and
+ * :48-52 (BasicBlock): the operand loader stages max(fmaf(x, scale[c], shift[c]), 0) of every pixel it loads (zero padding is of
+ * the normalised activation and stays zero), src_affine = (scale[C] | shift[C]) from zsg_bn_affine_from_partials.  The
+ * nn.BatchNorm2d + nn.ReLU launches between the two convolutions leave the forward's dependent chain; zsg_bn_apply_affine
+ * materialises the same numbers (bit-identical) for the backward, off the chain. */
+int zsg_conv_igemm_pre(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
+                       const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream);
+int zsg_conv_wino_pre(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
+                      const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream);
+
 /* Data gradient that COMPLETES dout of a train-mode BatchNorm (out = dgrad [+ add_src]; autograd's conv backward followed by
  * native_batch_norm_backward of fpn_resnet.py:86-97's conv-bn-relu chains): the epilogue also reduces that BatchNorm's
  * backward sums per output tile — partials[m_tile][0][n] = sum g, partials[m_tile][1][n] = sum g * (x - mean) * invstd with
@@ -172,6 +183,14 @@ int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* in
                  float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
 int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
                                float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* zsg_bn_stats_from_partials + the BatchNorm as ONE fma per value: affine[c] = gamma[c] * invstd[c], affine[C + c] =
+ * beta[c] - mean[c] * affine[c] (nn.BatchNorm2d's y = (x - mean) / sqrt(var + eps) * gamma + beta, fpn_resnet.py:87,90). */
+int zsg_bn_affine_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, const float* gamma, const float* beta,
+                                float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
+                                float* affine, void* stream);
+/* out = [relu](fmaf(x, affine[c], affine[C + c])); relu_mask as zsg_bn_apply */
+int zsg_bn_apply_affine(const float* x, int64_t rows, int32_t C, const float* affine, int32_t relu, float* out, uint8_t* relu_mask,
+                        void* stream);
 /* BatchNorm apply straight from the convolution epilogue's partial rows when there are at most zsg_bn_inline_max_chunks()
  * of them (small maps: layer3 / layer4 / pyramid sizes): every block reduces the rows for its own channels (fp64, fixed
  * order), block 0 publishes mean / invstd / the running statistics — no separate finalize launch between the convolution

@@ -1,0 +1,196 @@
+"""BatchNorm + ReLU applied by the CONSUMER convolution's operand loader (zsg_conv_igemm_pre / zsg_conv_wino_pre,
+zsg_bn_affine_from_partials, zsg_bn_apply_affine) — the conv -> bn -> relu -> conv chains of fpn_resnet.py:86-97.
+
+Op level, through the C ABI, against torch-CPU fp32:  conv(relu(bn(y)))  with  y = conv0(x)  in train mode, for every tile
+variant of both kernels, with padding (zero padding is of the NORMALISED activation), strides, channel tails and ragged
+edges.  Network level: the fused plan and the unfused plan (ZSG_BN_CONSUMER_FUSE=0) agree on outputs and gradients within the
+rounding of one fma per activation, and the materialised activations the backward reads are bit-identical to what the forward
+multiplied."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_ops import assert_close, dev, nhwc, ohwi, pad4, view_of  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def Z():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import zsgnet_pytorch_amd._lib as L
+    import zsgnet_pytorch_amd.ops as ops
+    return L, ops
+
+
+def _affine_from_conv(L, ops, y_nhwc, B, H, W, Cc, gam, bet, g):
+    """partials through a real producer epilogue are covered in test_gpu_ops; here: one partial row per 64 pixels from torch sums"""
+    rows = B * H * W
+    yf = y_nhwc.reshape(rows, Cc)
+    chunks = (rows + 63) // 64
+    part = torch.zeros(chunks, 2, Cc)
+    for i in range(chunks):
+        blk = yf[i * 64:(i + 1) * 64]
+        part[i, 0], part[i, 1] = blk.sum(0), (blk * blk).sum(0)
+    pd, gd, bd = dev(part), dev(gam), dev(bet)
+    mean, invstd, aff = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda"), torch.empty(2 * Cc, device="cuda")
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    L.check(L.lib.zsg_bn_affine_from_partials(pd.data_ptr(), chunks, rows, Cc, gd.data_ptr(), bd.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                              rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, aff.data_ptr(), L.stream_ptr()), "bn_affine_from_partials")
+    return mean, invstd, aff, rm, rv
+
+
+PRE_CASES = [
+    # B, C, N, H, W, k, s, p
+    (2, 64, 64, 19, 19, 1, 1, 0),
+    (2, 64, 256, 20, 17, 1, 1, 0),
+    (2, 128, 128, 21, 21, 3, 2, 1),       # strided 3x3 (layer2.0.conv2): padding must stay zero AFTER the transform
+    (1, 256, 64, 9, 11, 3, 1, 1),         # Winograd-eligible
+    (2, 64, 64, 13, 10, 3, 1, 1),
+    (3, 36, 96, 7, 7, 3, 1, 1),           # channel tail (C % 32 != 0, C % 8 != 0)
+    (2, 512, 128, 5, 5, 1, 1, 0),
+]
+IG_TILES = [(64, 64, 0), (64, 64, 1), (128, 64, 0), (128, 64, 1), (128, 128, 0), (128, 128, 1)]
+WN_TILES = [(64, 64, 0), (32, 64, 0), (64, 32, 0), (32, 32, 0), (64, 64, 1), (32, 64, 1), (64, 32, 1), (32, 32, 1)]
+
+
+@pytest.mark.parametrize("case", PRE_CASES, ids=[f"p{i}" for i in range(len(PRE_CASES))])
+def test_conv_pre_matches_bn_relu_conv(Z, case):
+    L, ops = Z
+    B, Cc, N, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(7 + Cc + N + k + H)
+    y = torch.randn(B, Cc, H, W, generator=g) * 1.7 + 0.3 * torch.randn(1, Cc, 1, 1, generator=g)
+    gam, bet = torch.rand(Cc, generator=g) + 0.5, 0.5 * torch.randn(Cc, generator=g)
+    gam[::7] *= -1.0                                             # negative gammas too
+    w = torch.randn(N, Cc, k, k, generator=g) / (Cc * k * k) ** 0.5
+    a_ref = F.relu(F.batch_norm(y, None, None, gam, bet, True, 0.1, 1e-5))
+    out_ref = F.conv2d(a_ref, w, None, s, p)
+    Ho, Wo = out_ref.shape[2:]
+    st = L.stream_ptr()
+    cp = pad4(Cc)
+    yd, wd = dev(nhwc(y)), dev(ohwi(w))
+    gp, bp = torch.zeros(cp), torch.zeros(cp)
+    gp[:Cc], bp[:Cc] = gam, bet
+    mean, invstd, aff, rm, rv = _affine_from_conv(L, ops, nhwc(y), B, H, W, cp, gp, bp, g)
+    yf = y.permute(0, 2, 3, 1).reshape(-1, Cc).double()
+    assert_close(mean[:Cc], yf.mean(0), 1e-4, 1e-5, "mean")
+    assert_close(rm[:Cc], 0.1 * yf.mean(0), 1e-4, 1e-6, "running mean")
+    assert_close(rv[:Cc], 0.9 + 0.1 * yf.var(0, unbiased=True), 2e-4, 1e-6, "running var")
+    sc_ref = gam.double() / torch.sqrt(yf.var(0, unbiased=False) + 1e-5)
+    assert_close(aff[:Cc], sc_ref, 2e-4, 1e-6, "scale")
+    assert_close(aff[cp:cp + Cc], bet.double() - yf.mean(0) * sc_ref, 2e-4, 2e-5, "shift")
+
+    # the materialised activation (what the backward reads) and its packed ReLU mask
+    a_dev = torch.empty(B, H, W, cp, device="cuda")
+    mask = torch.zeros((a_dev.numel() // 4 + 3) // 4 * 4, dtype=torch.uint8, device="cuda")
+    L.check(L.lib.zsg_bn_apply_affine(yd.data_ptr(), B * H * W, cp, aff.data_ptr(), 1, a_dev.data_ptr(), mask.data_ptr(), st), "bn_apply_affine")
+    assert_close(a_dev[..., :Cc].permute(0, 3, 1, 2), a_ref, 5e-4, 5e-4, "bn_apply_affine")
+    bits = (a_dev.reshape(-1, 4) > 0).to(torch.uint8)
+    packed = bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)
+    assert torch.equal(mask[:packed.numel()], packed), "packed ReLU mask"
+
+    src = view_of(ops, yd, B, H, W, cp)
+    # reference for bit-level comparisons: the plain kernels on the materialised activation
+    for bm, bn_, w8 in IG_TILES:
+        if bn_ == 128 and N <= 64:
+            continue
+        out = torch.full((B, Ho, Wo, N), float("nan"), device="cuda")
+        ov = view_of(ops, out, B, Ho, Wo, N)
+        d = ops.fwd_desc(src, ov, cp, N, k, s, p, 1, wC=cp, tile_hint=ops.tile_hint(bm, bn_, 1, w8))
+        L.check(L.lib.zsg_conv_igemm_pre(C.byref(d), yd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, None, aff.data_ptr(), st),
+                f"igemm_pre {bm}x{bn_} w8={w8}")
+        assert_close(out.permute(0, 3, 1, 2), out_ref, 3e-4, 3e-4, f"igemm_pre {bm}x{bn_} w8={w8}")
+        plain = torch.empty_like(out)
+        pv = view_of(ops, plain, B, Ho, Wo, N)
+        d2 = ops.fwd_desc(view_of(ops, a_dev, B, H, W, cp), pv, cp, N, k, s, p, 1, wC=cp, tile_hint=ops.tile_hint(bm, bn_, 1, w8))
+        L.check(L.lib.zsg_conv_igemm(C.byref(d2), a_dev.data_ptr(), wd.data_ptr(), plain.data_ptr(), None, None, None, None, st), "igemm")
+        assert torch.equal(out, plain), f"igemm_pre {bm}x{bn_} w8={w8}: not bit-identical to the plain kernel on the materialised activation"
+        # with the fused BatchNorm statistics of the OUTPUT (the consumer is itself followed by a BatchNorm)
+        chunks = (B * Ho * Wo + bm - 1) // bm
+        part = torch.full((chunks, 2, N), float("nan"), device="cuda")
+        L.check(L.lib.zsg_conv_igemm_pre(C.byref(d), yd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), aff.data_ptr(), st),
+                "igemm_pre+stats")
+        of = out_ref.permute(0, 2, 3, 1).reshape(-1, N).double()
+        assert_close(part[:, 0].double().sum(0), of.sum(0), 2e-4, 2e-4 * float(of.abs().sum(0).max()), "pre: bn partial sums")
+    if k == 3 and s == 1 and p == 1:
+        jobs = ops.WinoJobs()
+        U = torch.zeros(L.lib.zsg_wino_u_elems(cp, N), device="cuda")
+        jobs.add(wd.data_ptr(), U.data_ptr(), N, cp, 9 * cp, cp, 0)
+        jobs.finish("cuda")
+        jobs.launch(st)
+        for tb, bn_, ps4 in WN_TILES:
+            out = torch.full((B, Ho, Wo, N), float("nan"), device="cuda")
+            ov = view_of(ops, out, B, Ho, Wo, N)
+            d = ops.fwd_desc(src, ov, cp, N, 3, 1, 1, 1, wC=cp, tile_hint=ops.tile_hint(tb, bn_, 1, ps4))
+            L.check(L.lib.zsg_conv_wino_pre(C.byref(d), yd.data_ptr(), U.data_ptr(), out.data_ptr(), None, None, None, None, aff.data_ptr(), st),
+                    f"wino_pre {tb}x{bn_} ps4={ps4}")
+            assert_close(out.permute(0, 3, 1, 2), out_ref, 5e-4, 5e-4, f"wino_pre {tb}x{bn_} ps4={ps4}")
+            plain = torch.empty_like(out)
+            d2 = ops.fwd_desc(view_of(ops, a_dev, B, H, W, cp), view_of(ops, plain, B, Ho, Wo, N), cp, N, 3, 1, 1, 1, wC=cp,
+                              tile_hint=ops.tile_hint(tb, bn_, 1, ps4))
+            L.check(L.lib.zsg_conv_wino(C.byref(d2), a_dev.data_ptr(), U.data_ptr(), plain.data_ptr(), None, None, None, None, st), "wino")
+            assert torch.equal(out, plain), f"wino_pre {tb}x{bn_} ps4={ps4}: not bit-identical to the plain kernel on the materialised activation"
+
+
+def _net_step(fuse: bool, arch: str, B: int, S: int, seed: int):
+    import os
+    os.environ["ZSG_BN_CONSUMER_FUSE"] = "1" if fuse else "0"       # (read when the plan is lowered)
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import config, loss, mdl
+    cfg = config.get_cfg(resnet_arch=arch)
+    net = mdl.get_default_net(9, cfg)
+    net.load_state_dict(O.seeded_state_dict(arch, seed))
+    net.to("cuda").train()
+    r, s = config.ratios_scales(cfg)
+    lf = loss.get_default_loss(r, s, cfg)
+    bt = O.synthetic_batch(B, S, S, seed=seed + 1)
+    gen = torch.Generator().manual_seed(0)
+    inp = {k: v.cuda() for k, v in bt.items()}
+    inp["h0"], inp["c0"] = torch.randn(2, B, 128, generator=gen), torch.randn(2, B, 128, generator=gen)
+    out = net(inp)
+    ls = lf(out, inp)
+    ls["loss"].mean().backward()
+    torch.cuda.synchronize()
+    plan = next(iter(net._plans.values()))
+    return net, plan, out["att_bbx_out"].detach().clone(), net.store.grad.clone(), net._rmv.clone()
+
+
+@pytest.mark.parametrize("arch,S", [("resnet50", 128), ("resnet18", 96)])
+def test_fused_plan_equals_unfused_plan(arch, S):
+    """Same weights, same batch: forward outputs, every gradient and the BatchNorm running statistics of the plan whose
+    convolutions apply bn1 / bn2 in their loaders against the plan with separate apply launches.  The two differ by the rounding
+    of fmaf(x, s, t) vs (x - m) * s + b per activation (1 ulp class), amplified through the network: rel 2e-4 of the tensor scale."""
+    import os
+    try:
+        n0, p0, o0, g0, r0 = _net_step(False, arch, 2, S, 11)
+        n1, p1, o1, g1, r1 = _net_step(True, arch, 2, S, 11)
+        fused = [w for _, _, w in p1.fwd.calls if w.endswith("+pre")]
+        applies = [w for _, _, w in p1.fwd.calls if w.startswith("apply:")]
+        nblk = len(n1.blocks)
+        per = 2 if n1.block_kind == "bottleneck" else 1
+        # (a producer for which the autotuner chose split-K has no fused statistics and keeps its separate BatchNorm launches)
+        assert len(fused) == len(applies) and per * nblk // 2 <= len(fused) <= per * nblk, (len(fused), len(applies))
+        assert not any(w.endswith("+pre") for _, _, w in p0.fwd.calls)
+        # the deferred applies leave the dependent chain: they are side-stream launches
+        assert all(p1.fwd.lanes[i] == 1 for i, (_, _, w) in enumerate(p1.fwd.calls) if w.startswith("apply:"))
+        assert_close(o1, o0, 0, 2e-4 * float(o0.abs().max()), "fused vs unfused forward")
+        assert_close(r1, r0, 1e-5, 1e-6, "running statistics")
+        ents = n1.store.entries
+        for name in n1._param_names:
+            e = ents[name]
+            a, b = g1[e.offset:e.offset + e.size], g0[e.offset:e.offset + e.size]
+            sc = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 1e-3 * sc + 1e-7, f"{name}: gradient differs: {float((a - b).abs().max())} vs scale {sc}"
+        # what the backward reads == what the forward multiplied: materialised a1 equals relu(fma(y1, scale, shift)) exactly
+        q = n1.blocks[0]["prefix"]
+        y1, a1 = p1.acts[q + "y1"], p1.acts[q + "a1"]
+        aff = a1.pre[1]
+        Cc = a1.C
+        ref = torch.clamp_min(torch.addcmul(aff[Cc:], y1.buf.view(-1, Cc), aff[:Cc]), 0)       # (torch's addcmul is not an fma: compare loosely)
+        assert_close(a1.buf.view(-1, Cc), ref, 1e-6, 1e-6, "materialised activation")
+    finally:
+        os.environ.pop("ZSG_BN_CONSUMER_FUSE", None)

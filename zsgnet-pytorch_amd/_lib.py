@@ -55,6 +55,10 @@ SIGNATURES = {
     "zsg_comm_wait": (I32, [P, P]),
     "zsg_comm_destroy": (I32, [P]),
     "zsg_conv_wino": (I32, [DP, P, P, P, P, P, P, P, P]),
+    "zsg_conv_igemm_pre": (I32, [DP, P, P, P, P, P, P, P, P, P]),
+    "zsg_conv_wino_pre": (I32, [DP, P, P, P, P, P, P, P, P, P]),
+    "zsg_bn_affine_from_partials": (I32, [P, I32, I64, I32, P, P, P, P, P, P, F32, F32, P, P]),
+    "zsg_bn_apply_affine": (I32, [P, I64, I32, P, I32, P, P, P]),
     "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_conv_wino_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_bn_backward_from_partials": (I32, [P, P, P, I64, I32, P, P, P, P, P, P, P, I32, P, I32, P, SZ, P]),

@@ -31,6 +31,8 @@ struct IgParams {
     const float* bias;
     const float* add_src;
     const float* mask_src;
+    const float* pre; // PRE kernels: (scale[C] | shift[C]) of the BatchNorm (+ ReLU) that produced the logical source: the A loader
+                      // stages max(fmaf(x, scale[c], shift[c]), 0) of what it loads (padding / dead rows stay exact zeros)
     float* stats;     // optional BatchNorm partials [m_tiles][2][N]: per-tile column sums / sums of squares of the output
     int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, relu, nseg;
     int m_tiles, n_tiles;
@@ -56,7 +58,12 @@ struct IgParams {
 // LDS rows hold the three planes side by side: 3 x 32 bf16 (64 B each) + 16 B pad = 52 floats (13 x 16 B: odd).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false>
+//
+// PRE: the source tensor is the INPUT of a train-mode BatchNorm + ReLU whose output this convolution logically consumes
+// (fpn_resnet.py:86-97: conv -> bn -> relu -> conv).  The registers->LDS stage applies the BatchNorm as one fma per value with the
+// per-channel (scale, shift) pair of zsg_bn_affine_from_partials and the ReLU as one max: the normalised activation is never
+// read from HBM on the forward's critical path (its materialisation for the backward runs off the chain on the side stream).
+template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams p) {
     constexpr int LDR = BX ? 52 : IG_LDK;     // floats per LDS tile row
     constexpr int NT = 64 * WM * WN * KS;     // threads
@@ -134,8 +141,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     }
 
     f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];      // two register stages: global loads run TWO K tiles ahead
+    struct PreStage { f32x4 sc, sh; int okm; };   // PRE: the tile's channel-group (scale, shift) and which of its rows are real pixels
+    PreStage ps0, ps1;
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.wt);
+    const rsrc_t rsrc_p = make_rsrc(PRE ? p.pre : p.src);
     // K-iteration counters of the NEXT tile to load (wave-uniform)
     int cc = it0 % n_cc;
     int jx = (it0 / n_cc) % n_jx;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
     // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
     // outstanding loads exactly (a branch made it wait for ALL of them, vmcnt(0), before parking the previous tile).
-    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], bool live) {
+    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], PreStage& ps, bool live) {
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
         int ws_, dxx, koff;
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             kok = live & (koff < Cdim);
         }
         const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
+        int okm = 0;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int yy = a_by[j] + dyy, xx = a_bx[j] + dxx;
@@ -169,6 +180,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             const bool ok = kok & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
             const unsigned off = 4u * (unsigned)(a_off[j] + (yy * srcW + xx) * src_ld + (MERGE_X ? 0 : koff));
             ra[j] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
+            if (PRE) okm |= ok ? (1 << j) : 0;
+        }
+        if (PRE) {
+            ps.okm = okm;
+            ps.sc = buf_load4(rsrc_p, kok ? 4u * (unsigned)koff : ZSG_OOB);
+            ps.sh = buf_load4(rsrc_p, kok ? 4u * (unsigned)(Cdim + koff) : ZSG_OOB);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
@@ -206,9 +223,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         *(u32x2*)(row + 16 + 2 * g) = q2;
         *(u32x2*)(row + 32 + 2 * g) = q3;
     };
-    auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
+    auto store_tile = [&](int buf, f32x4 (&ra)[RA], const f32x4 (&rb)[RB], const PreStage& ps) {
         float* a = As + buf * BM * LDR;
         float* b = Bs + buf * BN * LDR;
+        if (PRE) {
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const bool ok = (ps.okm >> j) & 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[j][e] = ok ? fmaxf(fmaf(ra[j][e], ps.sc[e], ps.sh[e]), 0.f) : 0.f;
+            }
+        }
         if (BX) {
 #pragma unroll
             for (int j = 0; j < RA; ++j) split_store(a + (r0 + RP * j) * LDR, ra[j]);
@@ -231,9 +256,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
-        load_tile(ra0, rb0, true);
-        store_tile(0, ra0, rb0);
-        load_tile(ra0, rb0, n_it > 1);               // tile 1 stays in flight across the first compute phase
+        load_tile(ra0, rb0, ps0, true);
+        store_tile(0, ra0, rb0, ps0);
+        load_tile(ra0, rb0, ps0, n_it > 1);          // tile 1 stays in flight across the first compute phase
     }
     __syncthreads();
 
@@ -243,8 +268,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
 
     // one K tile: prefetch tile it+2 into `nxt`, MFMA on LDS[it&1], then park tile it+1 (already in `cur`) in the other
     // LDS buffer.  The global->register latency is covered by two compute phases instead of one.
-    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB]) {
-        load_tile(nxt_a, nxt_b, it + 2 < n_it);
+    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p) {
+        load_tile(nxt_a, nxt_b, nxt_p, it + 2 < n_it);
         const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
         const float* b = Bs + (it & 1) * BN * LDR + b_row * LDR + 4 * lh;
         if (BX) {
@@ -288,12 +313,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
-        store_tile((it + 1) & 1, cur_a, cur_b);      // (after the last tile: zeros into the idle buffer)
+        store_tile((it + 1) & 1, cur_a, cur_b, cur_p);      // (after the last tile: zeros into the idle buffer)
         __syncthreads();
     };
     for (int it = 0; it < n_it; it += 2) {
-        k_step(it, ra0, rb0, ra1, rb1);
-        if (it + 1 < n_it) k_step(it + 1, ra1, rb1, ra0, rb0);
+        k_step(it, ra0, rb0, ps0, ra1, rb1, ps1);
+        if (it + 1 < n_it) k_step(it + 1, ra1, rb1, ps1, ra0, rb0, ps0);
     }
 
     // ---- K groups: sum the accumulators into group 0 (fixed order) -----------------------------------------------------------
@@ -545,19 +570,31 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int WM, int WN, bool MX, int KS = 1, bool BX = false>
-static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const char* kname) {
+template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE>
+static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     const size_t lds = (size_t)2 * (BM + BN) * (BX ? 52 : IG_LDK) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;      // idempotent; a benign race sets it twice
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
+}
+// p.pre != nullptr selects the PRE instantiation (profile name = kname + "+pre")
+template <int BM, int BN, int WM, int WN, bool MX, int KS = 1, bool BX = false>
+static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const char* kname) {
+    if constexpr (!MX) {
+        if (p.pre) {
+            static char nm[96];
+            snprintf(nm, sizeof(nm), "%s+pre", kname);
+            return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, true>(p, st, flops, nm);
+        }
+    }
+    return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false>(p, st, flops, kname);
 }
 
 // tile_hint = BM | (BN << 8) | (splits << 16); 0 = heuristic.  The Python lowering autotunes the hint per layer on
@@ -594,7 +631,8 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int
 }
 
 static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
+                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
+                           const float* src_affine = nullptr) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
     int BM = 64, BN = 64, splits = 1, w8 = 0, bx = 0;
     pick_tile(d, &BM, &BN, &splits, &w8, &bx);
@@ -609,6 +647,10 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
     p.stats = bn_partials;
+    if (src_affine) {
+        ZSG_REQUIRE(!d->merge_x && ((uintptr_t)src_affine & 15) == 0, "conv_igemm_pre: needs a 16-byte aligned (scale | shift) pair and no merge_x");
+        p.pre = src_affine;
+    }
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
         for (int s = 0; s < d->nseg; ++s) v = v && (d->seg[s].out_off % 4) == 0 && (d->seg[s].out_bstride % 4) == 0;
@@ -674,4 +716,12 @@ extern "C" int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, cons
                                   float* partials, void* stream) {
     BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
     return conv_igemm_impl(d, src, wt, out, nullptr, add_src, nullptr, partials, &b, stream);
+}
+
+// Convolution whose logical input is relu(batchnorm(src)): src is the BatchNorm's INPUT and src_affine = (scale[C] | shift[C]) from
+// zsg_bn_affine_from_partials; the A loader applies max(fmaf(x, scale, shift), 0) to the pixels it stages (zero padding stays zero).
+extern "C" int zsg_conv_igemm_pre(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
+                                  const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream) {
+    ZSG_REQUIRE(src_affine, "conv_igemm_pre: null src_affine");
+    return conv_igemm_impl(d, src, wt, out, bias, add_src, mask_src, bn_partials, nullptr, stream, src_affine);
 }

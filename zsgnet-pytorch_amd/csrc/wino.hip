@@ -39,6 +39,7 @@ struct WnParams {
     const float* bias;
     const float* add_src;
     const float* mask_src;
+    const float* pre;    // PRE kernels: (scale[C] | shift[C]): the A loader transforms max(fmaf(x, scale[c], shift[c]), 0) instead of x
     float* stats;        // optional BatchNorm partials [m_blocks][2][N]
     BnbDev bnb;          // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (common.h)
     int C, N, Npad, src_ld, out_ld, relu, nseg;
@@ -55,7 +56,11 @@ __device__ __forceinline__ float quad_other(float v) {
 
 // PS position groups per 32x32 sub-block: wave (ph, wm, wn) holds the 16/PS positions with i in {2ph, 2ph+1} (PS = 2) or
 // i = ph (PS = 4).  PS = 4 doubles the waves per SIMD for the same tile (64 instead of 128 accumulator registers each).
-template <int TM, int TN, int PS>
+// PRE: the source tensor is the INPUT of a train-mode BatchNorm + ReLU whose output this convolution logically consumes (Bottleneck
+// conv1 -> bn1 -> relu -> conv2, fpn_resnet.py:86-91): the loader applies the BatchNorm (one fma with the per-channel (scale, shift)
+// pair of zsg_bn_affine_from_partials, staged once per block into LDS) and the ReLU between the pixel loads and the row transform;
+// out-of-image pixels stay exact zeros (the padding is of the normalised activation, not of its input).
+template <int TM, int TN, int PS, bool PRE = false>
 __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams p) {
     constexpr int NT = 64 * PS * TM * TN;        // PS position groups x TM x TN waves
     constexpr int NP = 16 / PS;                  // positions (accumulator tiles) per wave
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     float* As = smem;                            // [2][16][SA]
     float* Bs = smem + 2 * 16 * SA;              // [2][16][SB]
     int* rowinfo = (int*)(smem + 2 * 16 * (SA + SB));   // [TB][2]: output offset of pixel (2ty, 2tx) | -1 ; validity bits
+    float* aff = (float*)(rowinfo + 2 * TB);            // PRE: [2][chunks * 8] (scale | shift), zero beyond C
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -141,6 +147,14 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
         nc = min(per, p.chunks - c0);
     }
 
+    const int aff_ld = p.chunks * WN_CK;
+    if (PRE) {
+        for (int i = threadIdx.x; i < 2 * aff_ld; i += NT) {
+            const int h = i >= aff_ld, c = i - h * aff_ld;
+            aff[i] = (c < p.C) ? p.pre[h * p.C + c] : 0.f;
+        }
+        __syncthreads();
+    }
     f32x4 ra[IA][4];
     auto load_a = [&](int c, bool live) {
         if (!a_thr) return;
@@ -167,9 +181,21 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     // V'[3] = t3 - t1 = -V[3] (zsg_wino_weights negates row 3 of U to match): every lane computes own + sgn * other with
     // ONE cross-lane operand, i.e. one v_fmac_f32 with a DPP source per value.
     const float sgn = (q == 1) ? 1.f : -1.f;
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, int c) {           // c: the chunk held in ra (PRE: selects the channel group's scale / shift)
         if (!a_thr) return;
         float* a = As + buf * 16 * SA;
+        if (PRE) {
+            const int ko = min(c, p.chunks - 1) * WN_CK + 4 * g;
+            const f32x4 sc = *(const f32x4*)(aff + ko), sh = *(const f32x4*)(aff + aff_ld + ko);
+#pragma unroll
+            for (int ia = 0; ia < IA; ++ia)
+#pragma unroll
+                for (int col = 0; col < 4; ++col) {
+                    const bool ok = (a_mask[ia] >> col) & 1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[ia][col][e] = ok ? fmaxf(fmaf(ra[ia][col][e], sc[e], sh[e]), 0.f) : 0.f;
+                }
+        }
 #pragma unroll
         for (int ia = 0; ia < IA; ++ia) {
             f32x4 t[4];                            // row transform (d B): this lane's patch row q
@@ -196,7 +222,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     if (nc > 0) {
         load_b(c0, 0);
         load_a(c0, true);
-        store_a(0);
+        store_a(0, c0);
         if (ph & 1) load_a(c0 + 1, nc > 1);        // the late groups transform FIRST in every chunk: their next chunk is prefetched here
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pl = NP1; pl < NP; ++pl) mfma_pos(a, b, pl);
-            store_a((it + 1) & 1);                 // (after the last chunk: zeros into the idle buffer)
+            store_a((it + 1) & 1, c0 + it + 1);    // (after the last chunk: into the idle buffer, never read)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
             const float* a = As + (it & 1) * 16 * SA + frag_a;
             const float* b = Bs + (it & 1) * 16 * SB + frag_b;
             if (it + 1 < nc) load_b(c0 + it + 1, (it + 1) & 1);
-            store_a((it + 1) & 1);
+            store_a((it + 1) & 1, c0 + it + 1);
             load_a(c0 + it + 2, it + 2 < nc);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -500,29 +526,42 @@ extern "C" int zsg_wino_weights(const void* jobs_dev, int32_t njobs, int32_t tot
     return 0;
 }
 
-template <int TM, int TN, int PS>
-static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
+template <int TM, int TN, int PS, bool PRE>
+static int wino_launch1(const WnParams& p, hipStream_t st, double flops, const char* kname) {
     constexpr int TB = 32 * TM, BN = 32 * TN, NT = 64 * PS * TM * TN;
     constexpr int SA = TB * 8 + 8, SB = BN * 8;
-    size_t lds = (size_t)2 * 16 * (SA + SB) * sizeof(float) + TB * 2 * sizeof(int);
-    const size_t epi = ((size_t)TB * 4 * (BN + 4) + 2 * (NT / (BN / 4)) * BN) * sizeof(float);
-    if (epi > (size_t)2 * 16 * (SA + SB) * sizeof(float)) lds = epi + TB * 2 * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    constexpr size_t stage = (size_t)2 * 16 * (SA + SB) * sizeof(float);
+    constexpr size_t epi = ((size_t)TB * 4 * (BN + 4) + 2 * (NT / (BN / 4)) * BN) * sizeof(float);
+    static_assert(epi <= stage, "the epilogue's transposed tile + statistics rows reuse the K-loop staging area (rowinfo sits behind it)");
+    // (PRE: the (scale | shift) table sits behind rowinfo; the epilogue no longer needs it)
+    const size_t lds = stage + TB * 2 * sizeof(int) + (PRE ? (size_t)2 * p.chunks * WN_CK * sizeof(float) : 0);
+    ZSG_REQUIRE(lds <= 160 * 1024, "conv_wino: %zu bytes of LDS (C = %d is too large for the source-transform variant)", lds, p.C);
+    static size_t attr_lds = 0;         // (PRE: grows with C; a benign race sets it twice)
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_lds = lds;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((wino_kernel<TM, TN, PS>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((wino_kernel<TM, TN, PS, PRE>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_wino");
     return 0;
+}
+template <int TM, int TN, int PS>
+static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
+    if (p.pre) {
+        static char nm[64];
+        snprintf(nm, sizeof(nm), "%s+pre", kname);
+        return wino_launch1<TM, TN, PS, true>(p, st, flops, nm);
+    }
+    return wino_launch1<TM, TN, PS, false>(p, st, flops, kname);
 }
 
 // tile_hint = TB | (BN << 8) | (split_k << 16) | (four position groups << 24), TB (tiles per block) and BN in {32, 64};
 // 0 = 64x64, two position groups, no split
 static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
-                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
+                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
+                          const float* src_affine = nullptr) {
     ZSG_REQUIRE(d && src && U && out, "conv_wino: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0, "conv_wino: C=%d src_ld=%d must be multiples of 4", d->C, d->src_ld);
@@ -534,6 +573,7 @@ static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float*
     WnParams p;
     memset(&p, 0, sizeof(p));
     p.src = src; p.U = U; p.out = out; p.bias = bias; p.add_src = add_src; p.mask_src = mask_src; p.stats = bn_partials;
+    p.pre = src_affine;
     p.C = d->C; p.N = d->N; p.Npad = (d->N + 63) / 64 * 64; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.relu = d->relu;
     p.nseg = d->nseg; p.chunks = (d->C + WN_CK - 1) / WN_CK; p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
@@ -607,4 +647,11 @@ extern "C" int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const
                                  float* partials, void* stream) {
     BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
     return conv_wino_impl(d, src, U, out, nullptr, add_src, nullptr, partials, &b, stream);
+}
+
+// see zsg_conv_igemm_pre: the logical input is relu(batchnorm(src)), applied by the loader from src_affine = (scale[C] | shift[C])
+extern "C" int zsg_conv_wino_pre(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
+                                 const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream) {
+    ZSG_REQUIRE(src_affine, "conv_wino_pre: null src_affine");
+    return conv_wino_impl(d, src, U, out, bias, add_src, mask_src, bn_partials, nullptr, stream, src_affine);
 }

@@ -67,6 +67,15 @@ class BnL:
 
 
 BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward sums in the epilogue of the data gradient that completes dout
+# conv -> bn -> relu -> conv chains: the second convolution applies the BatchNorm + ReLU while it loads the first one's output
+# (zsg_conv_*_pre); the normalised activation the backward needs is materialised off the forward's dependent chain (side stream)
+def bn_consumer_fuse() -> bool:
+    """ZSG_BN_CONSUMER_FUSE=1 (read when a plan is lowered; default OFF).  Built and measured in round 3 (profiles/
+    r03_prefuse_ab.txt): the fused loaders cost the consumer convolution 3-6 us (Winograd: the transform is redone by up to four
+    overlapping tiles; strided 3x3: 12-14 us) against 7-11 us per apply launch taken off the chain — and the materialising applies
+    do NOT overlap the head's Winograd launches on the side stream (those blocks own a CU's whole register file), so the forward
+    went 5.22 -> 5.39 ms and the step 14.32 -> 14.49 ms.  Kept as an opt-in, parity-tested path (tests/test_gpu_prefuse.py)."""
+    return os.environ.get("ZSG_BN_CONSUMER_FUSE", "0") == "1"
 
 
 class Act(TView):
@@ -556,9 +565,14 @@ class _Plan:
         tb = d.tile_hint & 0xff
         return sum((B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) + tb - 1) // tb for i in range(d.nseg))
 
-    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None, bn_fuse: Optional[BnL] = None) -> Act:
+    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None, bn_fuse: Optional[BnL] = None,
+             bn_defer: bool = False) -> Act:
         """bn_fuse: the output feeds a train-mode BatchNorm — let the epilogue emit the per-tile (sum, sum^2) partials
-        (no extra pass over the activation) unless the autotuner chose split-K for this layer."""
+        (no extra pass over the activation) unless the autotuner chose split-K for this layer.
+        bn_defer: that BatchNorm (+ ReLU) will be applied by the NEXT convolution's operand loader: finalize the statistics into a
+        (scale | shift) pair right here (see bn()).
+        src.pre = (y, affine): src is such a deferred BatchNorm output — the forward launch reads y and transforms it on the fly
+        (zsg_conv_igemm_pre / zsg_conv_wino_pre); the backward (tape) sees src itself, materialised off the critical chain."""
         if out is None:
             lv = src.levels
             assert len(lv) == 1
@@ -566,6 +580,10 @@ class _Plan:
                            conv_out(lv[0].W, L.k, L.stride, L.pad, L.dil), L.cout)
         d = fwd_desc(src, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
         bias = self.P(L.name + ".bias") if L.bias else None
+        pre = getattr(src, "pre", None) if self.training else None
+        rd = pre[0] if pre else src                    # the tensor the forward launch reads
+        tail = (pre[1],) if pre else ()
+        ig_fn, wn_fn = (lib.zsg_conv_igemm_pre, lib.zsg_conv_wino_pre) if pre else (lib.zsg_conv_igemm, lib.zsg_conv_wino)
         # a split-K choice would cost this layer its fused BatchNorm statistics: a statistics pass over the output at
         # ~4 TB/s plus two more dependent launches
         pen = 0.0
@@ -575,12 +593,12 @@ class _Plan:
         wargs = None
         if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
             U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
-            wargs = (src.buf, U, out.buf, bias, None, None, None)
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, (src.buf, wt, out.buf, bias, None, None, None), stream_ptr(),
-                      split_penalty_ms=pen, wino_args=wargs)
-        fn = lib.zsg_conv_igemm
+            wargs = (rd.buf, U, out.buf, bias, None, None, None) + tail
+        autotune_conv("igemm", ig_fn, d, (rd.buf, wt, out.buf, bias, None, None, None) + tail, stream_ptr(),
+                      split_penalty_ms=pen, wino_args=wargs, wino_fn=wn_fn)
+        fn = ig_fn
         if d.use_wino:
-            fn, wt = lib.zsg_conv_wino, U
+            fn, wt = wn_fn, U
             self.wino_jobs["fwd"].add(*job)
         partials = None
         out.bn_chunks = 0
@@ -592,9 +610,17 @@ class _Plan:
                 chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
                 partials, out.bn_chunks = self._ws_now(), chunks
-        self.fwd.add(fn, d, src.buf, wt, out.buf, bias, None, None, partials, what=L.name, lane=self._lane)
-        out.bn_inline = None
-        if partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
+        self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, None, None, partials, *tail, what=L.name + ("+pre" if pre else ""), lane=self._lane)
+        out.bn_inline = out.bn_affine = None
+        if partials is not None and bn_defer and bn_consumer_fuse():
+            # finalize at once into mean / invstd AND the (scale | shift) pair the consumer convolution's loader applies
+            Lb = bn_fuse
+            rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
+            out.bn_mean, out.bn_invstd, out.bn_affine = self._buf(Lb.c), self._buf(Lb.c), self._buf(2 * Lb.c)
+            rm, rv = self.net._rm[Lb.index:Lb.index + Lb.c], self.net._rv[Lb.index:Lb.index + Lb.c]
+            self.fwd.add(lib.zsg_bn_affine_from_partials, partials, out.bn_chunks, rows, Lb.c, self.P(Lb.name + ".weight"), self.P(Lb.name + ".bias"),
+                         out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5, out.bn_affine, what="affine:" + Lb.name, lane=self._lane)
+        elif partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
             # few partial rows: the BatchNorm apply launch (the very next launch on this stream: the workspace is still intact)
             # reduces them itself — no finalize launch
             out.bn_inline = partials
@@ -614,13 +640,15 @@ class _Plan:
         self.tape.append(lambda: self._conv_bwd(L, src, out, completes_bn=completes))
         return out
 
-    def conv_bn(self, L: ConvL, Lb: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, yname=None) -> Act:
+    def conv_bn(self, L: ConvL, Lb: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, yname=None,
+                defer: bool = False) -> Act:
         """conv -> BatchNorm [-> + residual] [-> ReLU].  Training: the two lowered ops (batch statistics from the conv
         epilogue).  Eval: ONE convolution with the BatchNorm folded into its weights / bias (zsg_bn_fold refreshes the
         folded copies at the start of every eval forward), residual add and ReLU in its epilogue."""
         if self.training:
-            y = self.conv(L, x, name=yname or (L.name + ".y"), bn_fuse=Lb)
-            return self.bn(Lb, y, relu, residual=residual, name=name)
+            defer = defer and relu and residual is None
+            y = self.conv(L, x, name=yname or (L.name + ".y"), bn_fuse=Lb, bn_defer=defer)
+            return self.bn(Lb, y, relu, residual=residual, name=name, defer=defer)
         net = self.net
         n_w = L.cout * L.k * L.k * L.cpad
         w_off = self.fold_used
@@ -741,8 +769,11 @@ class _Plan:
         covers_all = not d.zero_fill and mask is None and ((d.tile_hint >> 16) & 0xff) <= 1 and d.tile_hint and dx.ld == n and n % 4 == 0
         dx.last_writer = (len(self.bwd.calls) - 1, d, wargs if d.use_wino else args, "dgrad:" + L.name) if covers_all else None
 
-    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False) -> Act:
-        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2)"""
+    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False, defer: bool = False) -> Act:
+        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2).
+        defer: the only forward consumer is the next convolution, which applies this BatchNorm + ReLU in its operand loader
+        (out.pre); the apply launch that materialises `out` and the packed ReLU mask for the BACKWARD is queued and released on the
+        side stream later (_flush_deferred) — it leaves the forward's dependent chain."""
         net = self.net
         lv = x.levels[0]
         out = self.act(name or L.name, x.B, lv.H, lv.W, L.c)
@@ -761,7 +792,11 @@ class _Plan:
         rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
         lane = 2 if (join and self.training) else self._lane
         inl = getattr(x, "bn_inline", None) if fused else None
-        if inl is not None:
+        aff = getattr(x, "bn_affine", None) if (fused and defer and relu and residual is None) else None
+        if aff is not None:
+            self._deferred.append((x.buf, rows, L.c, aff, 1, out.buf, rmask, "apply:" + L.name))
+            out.pre = (x, aff)
+        elif inl is not None:
             self.fwd.add(lib.zsg_bn_apply_from_partials, x.buf, rows, L.c, inl, x.bn_chunks, gam, bet, residual.buf if residual is not None else None,
                          int(relu), out.buf, rmask, mean, invstd, rm, rv, 0.1, 1e-5, what=L.name, lane=lane)
         else:
@@ -825,6 +860,7 @@ class _Plan:
         self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
         self.tune_dw = self._buf(max(e.size for e in net.store.entries.values()) + 64)
+        self._deferred = []              # BatchNorm applies whose forward consumer reads the BatchNorm's input (see bn(defer=True))
 
         # ---- static inputs ------------------------------------------------------------------------------------------
         self.in_qvec = self._buf(B * T * net.emb_dim)
@@ -880,6 +916,7 @@ class _Plan:
         self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
         self.tape.extend(lstm_tape)
         self._lower_head(feats, we)
+        self._flush_deferred()
         # image-independent head launches (language / grid maps of conv0) go to the side stream BEHIND the query encoder: a
         # side-stream launch waits for the main-stream work enqueued before it, so its place in the program decides what
         # it can overlap — here the whole image encoder
@@ -896,6 +933,13 @@ class _Plan:
             for emit in reversed(self.tape):
                 emit()
         self.tape = []
+
+    def _flush_deferred(self):
+        """Release the queued BatchNorm applies (activations + ReLU masks only the backward reads) as consecutive side-stream
+        launches: ONE event edge from the main stream for all of them; the forward's closing join waits for them."""
+        for (*args, what) in self._deferred:
+            self.fwd.add(lib.zsg_bn_apply_affine, *args, what=what, lane=1 if self.training else 0)
+        self._deferred = []
 
     # ---- generic pooling / normalisation lowering (SSD-VGG trunk) -------------------------------------------------
     def _grad_sink(self, a: Act):
@@ -1006,13 +1050,13 @@ class _Plan:
                 rd = self.conv_bn(C[q + "downsample.0"], BN[q + "downsample.1"], x, False, name=q + "rd", yname=q + "yd")
         join = blk["ds"]
         if net.block_kind == "bottleneck":
-            a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
-            a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2")
+            a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1", defer=True)
+            a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2", defer=True)
             if self.training:
                 y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
                 return self.bn(BN[q + "bn3"], y3, True, residual=rd, name=q + "out", join=join)
             return self.conv_bn(C[q + "conv3"], BN[q + "bn3"], a2, True, residual=rd, name=q + "out", yname=q + "y3")
-        a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
+        a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1", defer=True)
         if self.training:
             y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
             return self.bn(BN[q + "bn2"], y2, True, residual=rd, name=q + "out", join=join)
@@ -1278,6 +1322,7 @@ class _Plan:
             self.fwd.add(lib.zsg_bn_apply, lmap.buf, h1.rows(), 256, zero, one, one, self.P(L0.name + ".bias"), None, 1, h1.buf, None,
                          what=L0.name)
         h1.needs_mask = True
+        self._flush_deferred()       # (behind the head's first convolution: the applies run under the head's remaining five)
 
         def head0_back():
             dy = h1.grad

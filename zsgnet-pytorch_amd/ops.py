@@ -214,7 +214,7 @@ SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
 SIDE_BATCH = int(os.environ.get("ZSG_SIDE_BATCH", "0"))
 
 
-_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb)
+_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb, lib.zsg_conv_igemm_pre, lib.zsg_conv_wino_pre)
 
 
 _SIDE = {}
@@ -482,13 +482,14 @@ def wino_default_hint(d: ConvDesc) -> int:
 
 
 def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0, split_penalty_ms: float = 0.0,
-                  wino_args: Optional[Sequence] = None) -> int:
+                  wino_args: Optional[Sequence] = None, wino_fn=None) -> int:
     """Pick d.tile_hint for `fn(d, *args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the real
     buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic.
     split_penalty_ms: what a split-K choice costs elsewhere (a convolution feeding BatchNorm loses the statistics fused
     in its epilogue: a separate statistics pass + finalize launch), added to the measured time of split candidates.
     wino_args: the same launch through zsg_conv_wino (args with the transformed filter image in place of the weight):
-    its tile candidates are timed too; the result carries WINO_FLAG and d.use_wino is set when one of them wins."""
+    its tile candidates are timed too; the result carries WINO_FLAG and d.use_wino is set when one of them wins.
+    wino_fn: the Winograd entry point that goes with `fn` (zsg_conv_wino_pre for zsg_conv_igemm_pre; default zsg_conv_wino)."""
     d.use_wino = False
     mode = wino_mode() if wino_args is not None else "0"
     if mode == "0":
@@ -501,7 +502,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         return 0
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
-                         mode if wino_args is not None else "", deterministic(), matrix_mode()))
+                         mode if wino_args is not None else "", deterministic(), matrix_mode(), fn.__name__))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -546,8 +547,9 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                             cands.append(tile_hint(bm, bn, sp, 1, 1))
     trials = [] if mode == "force" else [(fn, marshal(fn, (d,) + tuple(args)), h, 0) for h in cands]
     if wino_args is not None and kind == "igemm":
-        wconv = marshal(lib.zsg_conv_wino, (d,) + tuple(wino_args))
-        trials += [(lib.zsg_conv_wino, wconv, h, WINO_FLAG) for h in _wino_cands(d)]
+        wfn = wino_fn or lib.zsg_conv_wino
+        wconv = marshal(wfn, (d,) + tuple(wino_args))
+        trials += [(wfn, wconv, h, WINO_FLAG) for h in _wino_cands(d)]
     elif wino_args is not None:           # weight gradient: zsg_conv_wgrad_wino, split-K over 8-tile stages
         wconv = marshal(lib.zsg_conv_wgrad_wino, (d,) + tuple(wino_args))
         tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
