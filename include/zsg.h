@@ -105,6 +105,21 @@ int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, fl
 size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                    size_t ws_bytes, void* stream);
+/* The same launch WITHOUT its slab reduction (also zsg_conv_wgrad_wino_partial below): when the launch splits K
+ * (*n_slabs > 1, written on the host before the call returns) the partial tiles stay in ws as [n_slabs][N][taps*C] and dw is
+ * untouched; *n_slabs == 1 means dw was written / accumulated directly.  A step gives every such launch its own workspace
+ * region and sums the slabs of MANY layers in one launch — autograd's per-parameter AccumulateGrad of utils.py:412
+ * (`loss.backward()`) as a handful of batched reductions instead of one tiny dependent launch per convolution:
+ *   blocks = zsg_wgrad_reduce_job(d, ws, dw, accumulate, n_slabs, blk0, job)   fills one job record (host memory,
+ *            zsg_wgrad_reduce_job_bytes() bytes) from the launch's descriptor; returns its block count (blk0 accumulates),
+ *   zsg_wgrad_reduce_batched(jobs_dev, njobs, total_blocks, bytes_for_profile, stream)   dw (+)= sum over slabs for every job
+ *            of the device array; fixed summation order per element (deterministic). */
+int zsg_conv_wgrad_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                           size_t ws_bytes, int32_t* n_slabs, void* stream);
+int32_t zsg_wgrad_reduce_job_bytes(void);
+int32_t zsg_wgrad_reduce_job(const zsg_conv_desc* d, const float* ws, float* dw, int32_t accumulate, int32_t n_slabs, int32_t blk0,
+                             void* job_out);
+int zsg_wgrad_reduce_batched(const void* jobs_dev, int32_t njobs, int32_t total_blocks, double total_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Winograd F(2x2,3x3) convolution on fp32 MFMA: the 3x3 / stride 1 / pad 1 convolutions (forward and data gradient)
@@ -156,6 +171,8 @@ int zsg_wino_weights(const void* jobs, int32_t njobs, int32_t total_blocks, void
 size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                         size_t ws_bytes, void* stream);
+int zsg_conv_wgrad_wino_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                                size_t ws_bytes, int32_t* n_slabs, void* stream);
 
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */
@@ -305,6 +322,8 @@ int zsg_lstm_bwd(const float* dwe, int32_t we_ld, int32_t we_off, const float* w
  * losses[3] = (loss, cls_ls, box_ls);  grad5 [B][A][5] = d loss / d out5 (already includes lamb_reg, 1/B, 1/#pos).
  * match_idx [B] int32 = arg-max-IoU anchor (lowest index wins; bit-exact IoU: no FMA contraction, IEEE divide).
  * flags: bit0 use_focal, bit1 use_multi, bit2 use_softmax.  NaN branch (loss.py:128-133) is taken on device.
+ * Limit: B <= 512 samples per call (one LDS record per sample in the merge kernel); larger batches are rejected with -1
+ * (the reference's per-GPU batches are 16-32, BASELINE configs; split a larger batch over calls and sum the losses).
  * ------------------------------------------------------------------------------------------------------------- */
 size_t zsg_loss_workspace_bytes(int32_t B, int32_t A);
 int zsg_loss_fwd_bwd(const float* out5, const float* annot, const float* anchors, int32_t B, int32_t A, float alpha,

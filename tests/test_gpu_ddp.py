@@ -119,12 +119,15 @@ def test_comm_cabi_single_rank():
     assert lib.zsg_comm_destroy(h) == 0
 
 
-@pytest.mark.parametrize("comm", ["torch", "native"])
-def test_ddp_wrapper_on_the_nccl_backend_world1(comm, tmp_path):
+@pytest.mark.parametrize("comm,shape", [("torch", "r18_96"), ("native", "r18_96"), ("torch", "r50_300_b16"), ("native", "r50_300_b16")])
+def test_ddp_wrapper_on_the_nccl_backend_world1(comm, shape, tmp_path):
     """The shipping configuration of main_dist.py:36-40 — backend 'nccl' (= RCCL) — in a 1-rank group with every
     collective forced: C3 parameter broadcast, C2 buffer broadcast per forward, bucketed gradient all-reduce overlapped with
     backward, through torch's ProcessGroupNCCL ('torch') and through zsg_comm_* ('native').  The gradients must equal the
-    un-wrapped model's bit for bit (a 1-rank sum, pre-scale 1/1)."""
+    un-wrapped model's bit for bit (a 1-rank sum, pre-scale 1/1).  Shapes: a small ResNet-18 and the benchmark's own —
+    ResNet-50 FPN 300x300, per-GPU batch 16 (BASELINE configs[1] / the per-rank shape of configs[2]) with the DEFAULT bucket
+    plan (~32 MB buckets in completion order, ~4 MB exposed tail over the 142 MB flat gradient buffer, 53 BatchNorm buffers in
+    one broadcast), collectives issued from the side stream between the backward's launch ranges."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     ctx = mp.get_context("spawn")
@@ -133,17 +136,25 @@ def test_ddp_wrapper_on_the_nccl_backend_world1(comm, tmp_path):
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
-    p = ctx.Process(target=_nccl_worker, args=(port, comm, str(tmp_path)))
+    p = ctx.Process(target=_nccl_worker, args=(port, comm, str(tmp_path), shape))
     p.start()
-    p.join(600)
+    p.join(900)
     assert p.exitcode == 0, "the nccl-backend rank failed or hung"
     r = torch.load(tmp_path / "nccl.pt")
     assert r["nb"] >= 3
     assert torch.equal(r["g_ddp"], r["g_plain"]), "1-rank reduced gradients must equal the plain backward's"
     assert r["finite"]
+    if shape == "r50_300_b16":
+        b = r["buckets"]                       # (start, end, ready) in launch order
+        total = sum(e - s for s, e, _ in b)
+        assert total == r["flat"] and 140e6 < 4 * total < 160e6, f"buckets must cover the flat gradient buffer once: {4 * total} bytes"
+        assert all(b[i][2] <= b[i + 1][2] for i in range(len(b) - 1)), "buckets are launched in completion order"
+        assert 4 <= len(b) <= 12, len(b)
+        assert 4 * (b[-1][1] - b[-1][0]) <= 8 << 20, "the last (exposed) bucket must be the small tail"
+        assert max(e - s for s, e, _ in b) * 4 <= 48 << 20, "no bucket far above the 32 MB target"
 
 
-def _nccl_worker(port, comm, out_dir):
+def _nccl_worker(port, comm, out_dir, shape="r18_96"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0", ZSG_DETERMINISTIC="1")
     import torch.distributed as dist
@@ -151,24 +162,29 @@ def _nccl_worker(port, comm, out_dir):
     from zsgnet_pytorch_amd import config, dist as zdist, loss, mdl, optim
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
-    cfg = config.get_cfg(resnet_arch="resnet18")
-    sd = O.seeded_state_dict("resnet18", 41)
+    arch, B, S, kw = ("resnet18", 2, 96, dict(bucket_mb=4.0)) if shape == "r18_96" else ("resnet50", 16, 300, {})
+    cfg = config.get_cfg(resnet_arch=arch)
+    sd = O.seeded_state_dict(arch, 41)
     r, s = config.ratios_scales(cfg)
     lf = loss.get_default_loss(r, s, cfg)
-    bt = {k: v.cuda() for k, v in O.synthetic_batch(2, 96, 96, seed=72).items()}
-    bt["h0"], bt["c0"] = torch.zeros(2, 2, 128), torch.zeros(2, 2, 128)
+    bt = {k: v.cuda() for k, v in O.synthetic_batch(B, S, S, seed=72).items()}
+    bt["h0"], bt["c0"] = torch.zeros(2, B, 128), torch.zeros(2, B, 128)
+    info = {}
 
     def run(wrap):
         net = mdl.get_default_net(9, cfg)
         net.load_state_dict(sd)
         net.to("cuda").train()
-        model = zdist.DistributedDataParallel(net, device_ids=[0], bucket_mb=4.0, comm=comm, force_collectives=True) if wrap else net
+        model = zdist.DistributedDataParallel(net, device_ids=[0], comm=comm, force_collectives=True, **kw) if wrap else net
         opt = optim.FusedAdam(net, lr=1e-3)
         opt.zero_grad()
         lf(model(bt), bt)["loss"].backward()
         torch.cuda.synchronize()
         g = net.store.grad.clone().cpu()
         nb = len(net._plans[list(net._plans)[0]].reducer.buckets) if wrap else 0
+        if wrap:
+            info["buckets"] = [(b.start, b.end, b.ready) for b in net._plans[list(net._plans)[0]].reducer.buckets]
+            info["flat"] = int(net.store.grad.numel())
         opt.step()
         opt.zero_grad()
         ls = lf(model(bt), bt)["loss"]
@@ -179,6 +195,6 @@ def _nccl_worker(port, comm, out_dir):
         return g, nb, bool(torch.isfinite(ls)) and bool(torch.isfinite(net.store.grad).all())
     g_plain, _, _ = run(False)
     g_ddp, nb, fin = run(True)
-    torch.save(dict(g_plain=g_plain, g_ddp=g_ddp, nb=nb, finite=fin), os.path.join(out_dir, "nccl.pt"))
+    torch.save(dict(g_plain=g_plain, g_ddp=g_ddp, nb=nb, finite=fin, **info), os.path.join(out_dir, "nccl.pt"))
     dist.barrier()
     dist.destroy_process_group()

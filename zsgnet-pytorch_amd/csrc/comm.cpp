@@ -23,6 +23,7 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "missing symbols";       // what went wrong while loading (dlerror() is captured once, right after the failed dlopen)
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -37,7 +38,11 @@ void load_rccl() {
         if (g_rccl.h) break;
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
-    if (!g_rccl.h) return;
+    if (!g_rccl.h) {
+        const char* e = dlerror();               // (one call: it clears the error)
+        snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen failed");
+        return;
+    }
 #define ZSG_SYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.h, name)
     ZSG_SYM(GetUniqueId, "ncclGetUniqueId");
     ZSG_SYM(CommInitRank, "ncclCommInitRank");
@@ -50,7 +55,7 @@ void load_rccl() {
 }
 int need_rccl() {
     std::call_once(g_rccl_once, load_rccl);
-    if (!g_rccl.ok) ZSG_FAIL(-4, "zsg_comm: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+    if (!g_rccl.ok) ZSG_FAIL(-4, "zsg_comm: librccl.so.1 could not be loaded (%s)", g_rccl.why);
     return 0;
 }
 #define ZSG_RCCL(call, what)                                                                         \
@@ -101,7 +106,11 @@ extern "C" int zsg_comm_init(zsg_comm** out, const void* id128, int32_t nranks, 
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; e == hipSuccess && i < kEvents; ++i) e = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
-    if (e != hipSuccess) {
+    if (e != hipSuccess) {                       // undo what was created (the struct was zeroed: null handles mark the rest)
+        for (int i = 0; i < kEvents; ++i)
+            if (c->ready[i]) hipEventDestroy(c->ready[i]);
+        if (c->done) hipEventDestroy(c->done);
+        if (c->stream) hipStreamDestroy(c->stream);
         g_rccl.CommDestroy(c->comm);
         delete c;
         ZSG_FAIL(-3, "comm_init: %s", hipGetErrorString(e));

@@ -15,6 +15,82 @@
 
 #include "wgrad_common.h"
 
+// Fixed summation order (deterministic).  A block of 256 threads covers 256/KL float4 elements with KL "split lanes" each
+// (lane l sums slabs l, l+KL, ...), then an LDS tree over the lanes, so many-split launches (small weights, huge pixel counts)
+// are not one serial latency chain per element.
+template <int KL>
+__device__ __forceinline__ void wgrad_reduce_body(const WgReduceJob& p, int block, f32x4* sm_) {
+    constexpr int EL = 256 / KL;
+    f32x4 (*sm)[EL] = (f32x4 (*)[EL])sm_;
+    const int q4 = p.ncols / 4;
+    const int64_t total = (int64_t)p.N * q4;
+    const size_t slab = (size_t)p.N * p.ncols;
+    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+    const int64_t i = (int64_t)block * EL + el;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int n = 0, q = 0;
+    if (i < total) {
+        n = (int)(i / q4);
+        q = (int)(i % q4) * 4;
+        const float* src = p.ws + (size_t)n * p.ncols + q;
+#pragma unroll 4
+        for (int k = kl; k < p.splits; k += KL) s += *(const f32x4*)(src + k * slab);
+    }
+    sm[kl][el] = s;
+    __syncthreads();
+    for (int o = KL / 2; o > 0; o >>= 1) {
+        if (kl < o) sm[kl][el] += sm[kl + o][el];
+        __syncthreads();
+    }
+    if (kl == 0 && i < total) {
+        s = sm[0][el];
+        const int tapi = q / p.C;
+        const int c = q - tapi * p.C;
+        const int jy = tapi / p.txn, jx = tapi - jy * p.txn;
+        const int wr = p.ty_w0 + jy * p.ty_wstep, ws_ = p.tx_w0 + jx * p.tx_wstep;
+        float* o = p.dw + (size_t)n * p.wt_ld + (wr * p.wS + ws_) * p.wC + p.wc0 + c;
+        if (p.accumulate) s += *(const f32x4*)o;
+        *(f32x4*)o = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgReduceJob p) {
+    __shared__ f32x4 sm[256];
+    if (p.kl == 16) wgrad_reduce_body<16>(p, blockIdx.x, sm);
+    else wgrad_reduce_body<4>(p, blockIdx.x, sm);
+}
+
+
+// Batched form: ONE launch reduces the slabs of several weight-gradient launches (each left its partial tiles in its own
+// workspace region: zsg_conv_wgrad_partial / zsg_conv_wgrad_wino_partial).  A block finds its job by its index range.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceJob* __restrict__ jobs, int njobs) {
+    __shared__ f32x4 sm[256];
+    int lo = 0, hi = njobs - 1;                      // last job whose blk0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgReduceJob jb = jobs[lo];
+    if (jb.kl == 16) wgrad_reduce_body<16>(jb, blockIdx.x - jb.blk0, sm);
+    else wgrad_reduce_body<4>(jb, blockIdx.x - jb.blk0, sm);
+}
+
+void wg_reduce_job_fill(WgReduceJob& j, const zsg_conv_desc* d, const float* ws, float* dw, int accumulate, int splits) {
+    memset(&j, 0, sizeof(j));
+    j.ws = ws; j.dw = dw; j.accumulate = accumulate ? 1 : 0; j.splits = splits;
+    j.N = d->N; j.C = d->C; j.wS = d->wS; j.wC = d->wC; j.wc0 = d->wc0; j.wt_ld = d->wt_ld;
+    j.txn = d->seg[0].tx.n;
+    j.ncols = d->seg[0].ty.n * d->seg[0].tx.n * d->C;
+    j.ty_w0 = d->seg[0].ty.w0; j.ty_wstep = d->seg[0].ty.wstep; j.tx_w0 = d->seg[0].tx.w0; j.tx_wstep = d->seg[0].tx.wstep;
+    j.kl = wg_reduce_kl(j.N, j.ncols, splits);
+}
+
+int wg_reduce_launch(const WgReduceJob& j, hipStream_t st) {
+    ZSG_PROF("wgrad_reduce_kernel", st, 0, (double)(j.splits + 1) * j.N * j.ncols * 4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wg_reduce_blocks(j.N, j.ncols, j.kl)), dim3(256), 0, st, j);
+    return 0;
+}
+
 // Block tile (32*TM*WM) x (32*TN*WN) computed by WM x WN waves, each TM x TN MFMA tiles of 32x32.
 // AVEC: dY rows are 16-byte addressable (out_ld % 4 == 0; a ragged channel count just reads the row's own padding).
 template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true>
@@ -213,8 +289,8 @@ extern "C" size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d) {
     return (size_t)splits * d->N * ncols * sizeof(float);
 }
 
-extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                              size_t ws_bytes, void* stream) {
+static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                           size_t ws_bytes, void* stream, int32_t* n_slabs) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0,
@@ -313,14 +389,51 @@ extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const fl
     }
 #undef WG_LAUNCH
 #undef WG_LAUNCH_A
-    if (p.splits > 1) {
-        const int64_t total4 = (int64_t)d->N * (p.ncols / 4);
-        ZSG_PROF("wgrad_reduce_kernel", st, 0, (double)(p.splits + 1) * d->N * p.ncols * 4);
-        if (p.splits >= 32 || total4 < 65536)
-            hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((int)cdiv(total4, 16)), dim3(256), 0, st, p);
-        else
-            hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((int)cdiv(total4, 64)), dim3(256), 0, st, p);
+    if (n_slabs) {
+        *n_slabs = p.splits;                        // the caller reduces (zsg_wgrad_reduce_batched)
+    } else if (p.splits > 1) {
+        WgReduceJob j;
+        wg_reduce_job_fill(j, d, p.ws, dw, p.accumulate, p.splits);
+        wg_reduce_launch(j, st);
     }
     ZSG_CHECK_LAUNCH("conv_wgrad");
+    return 0;
+}
+
+extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                              size_t ws_bytes, void* stream) {
+    return conv_wgrad_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
+// The same launch WITHOUT its slab reduction: when the K dimension is split (*n_slabs > 1) the partial tiles stay in ws as
+// [n_slabs][N][ncols] and dw is untouched — the caller sums them later, many layers at a time (zsg_wgrad_reduce_batched);
+// *n_slabs == 1: the result was written / accumulated into dw directly.
+extern "C" int zsg_conv_wgrad_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                                      size_t ws_bytes, int32_t* n_slabs, void* stream) {
+    ZSG_REQUIRE(n_slabs, "conv_wgrad_partial: null n_slabs");
+    return conv_wgrad_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, n_slabs);
+}
+
+extern "C" int32_t zsg_wgrad_reduce_job_bytes(void) { return (int32_t)sizeof(WgReduceJob); }
+
+// Fills one job record (host memory, zsg_wgrad_reduce_job_bytes() bytes) for the slabs a *_partial launch with the same
+// descriptor left in ws; returns the number of blocks the job needs (the caller accumulates blk0 over the jobs of a launch).
+extern "C" int32_t zsg_wgrad_reduce_job(const zsg_conv_desc* d, const float* ws, float* dw, int32_t accumulate, int32_t n_slabs,
+                                        int32_t blk0, void* job_out) {
+    if (!d || !ws || !dw || !job_out || n_slabs < 2) return -1;
+    WgReduceJob j;
+    wg_reduce_job_fill(j, d, ws, dw, accumulate, n_slabs);
+    j.blk0 = blk0;
+    memcpy(job_out, &j, sizeof(j));
+    return wg_reduce_blocks(j.N, j.ncols, j.kl);
+}
+
+// dw (+)= sum over slabs, for every job of the device array, in ONE launch (fixed summation order per element: deterministic).
+extern "C" int zsg_wgrad_reduce_batched(const void* jobs_dev, int32_t njobs, int32_t total_blocks, double total_bytes, void* stream) {
+    ZSG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "wgrad_reduce_batched: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("wgrad_reduce_kernel", st, 0, total_bytes);
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, st, (const WgReduceJob*)jobs_dev, njobs);
+    ZSG_CHECK_LAUNCH("wgrad_reduce_batched");
     return 0;
 }

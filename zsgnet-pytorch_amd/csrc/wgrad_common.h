@@ -34,42 +34,23 @@ __device__ __forceinline__ int fdiv(int a, int d, float rcp) {   // a < 2^24, ex
     return q;
 }
 
-// dw[n][col(q)] (+)= sum_s ws[s][n][q]   — fixed summation order (deterministic).  A block of 256 threads covers
-// 256/KL float4 elements with KL "split lanes" each (lane l sums slabs l, l+KL, ...), then an LDS tree over the lanes, so
-// many-split launches (small weights, huge pixel counts) are not one serial latency chain per element.
-template <int KL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgParams p) {
-    constexpr int EL = 256 / KL;
-    __shared__ f32x4 sm[KL][EL];
-    const int q4 = p.ncols / 4;
-    const int64_t total = (int64_t)p.N * q4;
-    const size_t slab = (size_t)p.N * p.ncols;
-    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
-    const int64_t i = (int64_t)blockIdx.x * EL + el;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int n = 0, q = 0;
-    if (i < total) {
-        n = (int)(i / q4);
-        q = (int)(i % q4) * 4;
-        const float* src = p.ws + (size_t)n * p.ncols + q;
-#pragma unroll 4
-        for (int k = kl; k < p.splits; k += KL) s += *(const f32x4*)(src + k * slab);
-    }
-    sm[kl][el] = s;
-    __syncthreads();
-    for (int o = KL / 2; o > 0; o >>= 1) {
-        if (kl < o) sm[kl][el] += sm[kl + o][el];
-        __syncthreads();
-    }
-    if (kl == 0 && i < total) {
-        s = sm[0][el];
-        const int tapi = q / p.C;
-        const int c = q - tapi * p.C;
-        const int jy = tapi / p.txn, jx = tapi - jy * p.txn;
-        const int wr = p.ty.w0 + jy * p.ty.wstep, ws_ = p.tx.w0 + jx * p.tx.wstep;
-        float* o = p.dw + (size_t)n * p.wt_ld + (wr * p.wS + ws_) * p.wC + p.wc0 + c;
-        if (p.accumulate) s += *(const f32x4*)o;
-        *(f32x4*)o = s;
-    }
-}
+// One slab reduction: dw[n][col(q)] (+)= sum_s ws[s][n][q].  (Also the job record of zsg_wgrad_reduce_batched: plain data, filled
+// on the host by zsg_wgrad_reduce_job.)
+struct WgReduceJob {
+    const float* ws;
+    float* dw;
+    int N, ncols, splits, C, txn, wS, wC, wc0, wt_ld, accumulate;
+    int ty_w0, ty_wstep, tx_w0, tx_wstep;
+    int kl;           // split lanes per element (16 | 4)
+    int blk0;         // first block of this job in a batched launch
+};
 
+static inline int wg_reduce_kl(int N, int ncols, int splits) {
+    return (splits >= 32 || (int64_t)N * (ncols / 4) < 65536) ? 16 : 4;
+}
+static inline int wg_reduce_blocks(int N, int ncols, int kl) { return (int)(((int64_t)N * (ncols / 4) + 256 / kl - 1) / (256 / kl)); }
+
+// fills the job from the convolution descriptor (is_wino: the 3x3 Winograd kernel's slab layout = the direct kernel's with ncols = 9 C)
+void wg_reduce_job_fill(WgReduceJob& j, const zsg_conv_desc* d, const float* ws, float* dw, int accumulate, int splits);
+// one reduction as its own launch (zsg_conv_wgrad / zsg_conv_wgrad_wino); defined in wgrad.hip
+int wg_reduce_launch(const WgReduceJob& j, hipStream_t st);

@@ -235,17 +235,31 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     }
 }
 
-extern "C" size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d) {
-    if (!d) return 0;
+// split-K factor of a launch: tile_hint's, else enough K slices for one block per CU — ONE rule for the launch and for the
+// workspace query (so a caller that sizes its workspace from the query never gets "workspace too small")
+static int ww_pick_splits(const zsg_conv_desc* d, int stages) {
+    const int nmn = cdiv(d->N, 64) * cdiv(d->C, 64);
     int splits = (d->tile_hint >> 16) & 0xff;
-    if (splits <= 0) splits = 64;
-    return (size_t)splits * d->N * 9 * d->C * sizeof(float);
+    if (splits <= 0) splits = (ZSG_NUM_CU + nmn - 1) / nmn;
+    if (splits > stages / 2) splits = stages / 2;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+extern "C" size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d) {
+    if (!d || d->nseg < 1 || d->nseg > ZSG_MAX_SEG) return 0;
+    int st = 0;
+    for (int s = 0; s < d->nseg; ++s) st += cdiv((int64_t)d->B * ((d->seg[s].src_H + 1) / 2) * ((d->seg[s].src_W + 1) / 2), WW_KT);
+    const int splits = ww_pick_splits(d, st);
+    const int chunk = cdiv(st, splits);
+    const int eff = cdiv(st, chunk);
+    return eff > 1 ? (size_t)eff * d->N * 9 * d->C * sizeof(float) : 0;
 }
 
 // Same contract as zsg_conv_wgrad (forward descriptor, dy in the "out" geometry, accumulate flag, split-K workspace,
 // deterministic slab reduction); 3x3 / stride 1 / pad 1 only.  tile_hint: split_k << 16 (0: heuristic).
-extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                                   size_t ws_bytes, void* stream) {
+static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                                size_t ws_bytes, void* stream, int32_t* n_slabs) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad_wino: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0 && (d->out_ld % 4) == 0,
@@ -283,10 +297,7 @@ extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, con
     p.m_tiles = cdiv(d->N, 64);
     p.n_tiles = cdiv(d->C, 64);
     const int nmn = p.m_tiles * p.n_tiles;
-    int splits = (d->tile_hint >> 16) & 0xff;
-    if (splits <= 0) splits = (ZSG_NUM_CU + nmn - 1) / nmn;
-    if (splits > st / 2) splits = st / 2;
-    if (splits < 1) splits = 1;
+    const int splits = ww_pick_splits(d, st);
     p.st_chunk = cdiv(st, splits);
     p.splits = cdiv(st, p.st_chunk);
     if (p.splits > 1) {
@@ -306,20 +317,25 @@ extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, con
         ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, 0);
         hipLaunchKernelGGL(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
     }
-    if (p.splits > 1) {        // fixed-order slab sum -> dw (shared with the direct kernel)
-        WgParams r;
-        memset(&r, 0, sizeof(r));
-        r.dw = dw; r.ws = p.ws; r.accumulate = p.accumulate;
-        r.C = d->C; r.N = d->N; r.wS = 3; r.wC = d->wC; r.wc0 = d->wc0; r.wt_ld = d->wt_ld;
-        r.ncols = 9 * d->C; r.txn = 3; r.splits = p.splits;
-        r.ty = d->seg[0].ty; r.tx = d->seg[0].tx;
-        const int64_t total4 = (int64_t)d->N * (r.ncols / 4);
-        ZSG_PROF("wgrad_reduce_kernel", stq, 0, (double)(p.splits + 1) * d->N * r.ncols * 4);
-        if (p.splits >= 32 || total4 < 65536)
-            hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((int)cdiv(total4, 16)), dim3(256), 0, stq, r);
-        else
-            hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((int)cdiv(total4, 64)), dim3(256), 0, stq, r);
+    if (n_slabs) {
+        *n_slabs = p.splits;       // the caller reduces (zsg_wgrad_reduce_batched)
+    } else if (p.splits > 1) {     // fixed-order slab sum -> dw (shared with the direct kernel)
+        WgReduceJob r;
+        wg_reduce_job_fill(r, d, p.ws, dw, p.accumulate, p.splits);
+        wg_reduce_launch(r, stq);
     }
     ZSG_CHECK_LAUNCH("conv_wgrad_wino");
     return 0;
+}
+
+extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    return conv_wgrad_wino_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
+// see zsg_conv_wgrad_partial
+extern "C" int zsg_conv_wgrad_wino_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
+                                           size_t ws_bytes, int32_t* n_slabs, void* stream) {
+    ZSG_REQUIRE(n_slabs, "conv_wgrad_wino_partial: null n_slabs");
+    return conv_wgrad_wino_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, n_slabs);
 }

@@ -218,6 +218,19 @@ class DistributedDataParallel(nn.Module):
             self._sync_buffers()
         return self.module(inp)
 
+    def close(self):
+        """Releases the native communicator (its RCCL communicator, stream and events); the wrapper is unusable afterwards."""
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+            self.active = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def make_reducer(self, spans) -> BucketReducer:
         return BucketReducer(self.module.store.grad, plan_buckets(spans, self.bucket_elems, self.tail_elems), self.group, self.comm)
 

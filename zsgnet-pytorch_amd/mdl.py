@@ -69,6 +69,15 @@ class BnL:
 BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward sums in the epilogue of the data gradient that completes dout
 # conv -> bn -> relu -> conv chains: the second convolution applies the BatchNorm + ReLU while it loads the first one's output
 # (zsg_conv_*_pre); the normalised activation the backward needs is materialised off the forward's dependent chain (side stream)
+WG_BATCH_MAX = int(os.environ.get("ZSG_WG_BATCH_MAX", "8"))       # weight gradients per batched slab reduction ...
+WG_BATCH_MB = int(os.environ.get("ZSG_WG_BATCH_MB", "128"))      # ... or this many MB of slabs, whichever comes first
+
+
+def wg_batch() -> bool:
+    """ZSG_WG_BATCH=0: every weight-gradient launch reduces its own split-K slabs (one small launch each)"""
+    return os.environ.get("ZSG_WG_BATCH", "1") != "0"
+
+
 def bn_consumer_fuse() -> bool:
     """ZSG_BN_CONSUMER_FUSE=1 (read when a plan is lowered; default OFF).  Built and measured in round 3 (profiles/
     r03_prefuse_ab.txt): the fused loaders cost the consumer convolution 3-6 us (Winograd: the transform is redone by up to four
@@ -729,7 +738,45 @@ class _Plan:
         wino = (d.wR == 3 and d.wS == 3 and s0.sy == 1 and s0.ty.d0 == -1 and s0.ty.dstep == 1 and not d.merge_x
                 and dy.ld % 4 == 0 and wino_mode() != "0")       # 3x3 / stride 1 / pad 1: Winograd F(3x3,2x2) candidates
         autotune_conv("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
-        self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
+        if not wg_batch():
+            self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
+            return
+        # Batched slab reduction: the launch leaves its split-K partial tiles in a workspace region of its own and ONE reduce launch
+        # sums the slabs of several layers (a per-layer reduce is a 3-10 us dependent launch between two weight-gradient kernels on
+        # the side stream: 69 of them per ResNet-50 step).  288 GB of HBM: no slab region is ever reused within a step.
+        import ctypes as C_
+        fn = lib.zsg_conv_wgrad_wino_partial if d.use_wino else lib.zsg_conv_wgrad_partial
+        need = int((lib.zsg_conv_wgrad_wino_workspace_bytes if d.use_wino else lib.zsg_conv_wgrad_workspace_bytes)(C_.byref(d)))
+        ws_own = self._buf(max(need // 4, 4))
+        ns = C_.c_int32(0)
+        check(fn(C_.byref(d), src.buf.data_ptr(), dy.buf.data_ptr(), self.tune_dw.data_ptr(), 0, ws_own.data_ptr(), need, C_.addressof(ns),
+                 C_.c_void_p(stream_ptr())), what)          # (one real launch into scratch: learns the effective slab count)
+        self.bwd.add(fn, d, src.buf, dy.buf, gw, 1, ws_own, need, C_.addressof(self._nslab_sink), what=what, lane=1)
+        if ns.value > 1:
+            self._wg_pending.append((d, ws_own, gw, ns.value, pname))
+            self._wg_pending_bytes += ns.value * d.N * d.seg[0].ty.n * d.seg[0].tx.n * d.C * 4
+            if len(self._wg_pending) >= WG_BATCH_MAX or self._wg_pending_bytes >= (WG_BATCH_MB << 20):
+                self._wg_flush()
+
+    def _wg_flush(self):
+        """ONE launch sums the slabs of every pending weight gradient into the flat gradient buffer (side stream, behind them)."""
+        if not self._wg_pending:
+            return
+        import ctypes as C_
+        jb = int(lib.zsg_wgrad_reduce_job_bytes())
+        host = (C_.c_char * (jb * len(self._wg_pending)))()
+        blk, nbytes = 0, 0.0
+        at = len(self.bwd.calls)                  # index of the reduce launch: the gradients below are complete only after it
+        for i, (d, ws_own, gw, nsl, pname) in enumerate(self._wg_pending):
+            nb = lib.zsg_wgrad_reduce_job(C_.byref(d), ws_own.data_ptr(), gw.data_ptr(), 1, nsl, blk, C_.addressof(host) + i * jb)
+            assert nb > 0, pname
+            blk += nb
+            nbytes += (nsl + 1) * d.N * d.seg[0].ty.n * d.seg[0].tx.n * d.C * 4.0
+            self.grad_ready[pname] = at
+            self.bwd.keep.append(ws_own)
+        jobs_dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.dev)
+        self.bwd.add(lib.zsg_wgrad_reduce_batched, jobs_dev, len(self._wg_pending), blk, nbytes, what=f"wgrad reduce x{len(self._wg_pending)}", lane=1)
+        self._wg_pending, self._wg_pending_bytes = [], 0
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None, completes_bn: bool = False):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
@@ -861,6 +908,8 @@ class _Plan:
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
         self.tune_dw = self._buf(max(e.size for e in net.store.entries.values()) + 64)
         self._deferred = []              # BatchNorm applies whose forward consumer reads the BatchNorm's input (see bn(defer=True))
+        import ctypes as C_
+        self._wg_pending, self._wg_pending_bytes, self._nslab_sink = [], 0, C_.c_int32(0)      # batched slab reduction (wgrad())
 
         # ---- static inputs ------------------------------------------------------------------------------------------
         self.in_qvec = self._buf(B * T * net.emb_dim)
@@ -932,6 +981,7 @@ class _Plan:
         if self.training:
             for emit in reversed(self.tape):
                 emit()
+            self._wg_flush()
         self.tape = []
 
     def _flush_deferred(self):
