@@ -98,6 +98,13 @@ CONV_CASES = [
     (2, 64, 256, 16, 16, 3, 1, 1, 1, True, True, False, 128 | (128 << 8) | (1 << 24)),
     (2, 96, 64, 16, 16, 3, 1, 1, 1, True, False, False, 128 | (64 << 8) | (1 << 24)),
     (16, 300, 512, 1, 20, 1, 1, 0, 1, True, False, False, 0),
+    # 64-deep K tiles (tile_hint bit 27): every tile variant, taps + padding + stride, K = 64 (one step) .. 576
+    (2, 64, 256, 16, 16, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 27)),
+    (2, 128, 256, 16, 16, 1, 1, 0, 1, True, True, False, 64 | (64 << 8) | (1 << 24) | (1 << 27)),
+    (2, 192, 128, 17, 15, 3, 1, 1, 1, False, False, False, 128 | (64 << 8) | (1 << 27)),
+    (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 128 | (64 << 8) | (1 << 24) | (1 << 27)),
+    (2, 256, 256, 9, 9, 1, 1, 0, 1, False, False, False, 128 | (128 << 8) | (1 << 24) | (1 << 27)),
+    (3, 128, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 27)),
 ]
 
 
@@ -131,10 +138,10 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
     assert_close(out.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, "conv fwd")
     if not bias and not relu:
         # fused BatchNorm statistics: per-tile (sum, sum^2) partials from the epilogue -> mean / invstd
-        for bm, bn_, w8 in ((64, 64, 0), (128, 64, 0), (128, 128, 1)):
-            if bn_ == 128 and (Co <= 64 or mx):
+        for bm, bn_, w8, k64 in ((64, 64, 0, 0), (128, 64, 0, 0), (128, 128, 1, 0), (64, 64, 1, 1), (128, 64, 1, 1), (128, 128, 1, 1)):
+            if (bn_ == 128 and (Co <= 64 or mx)) or (k64 and (mx or cp % 64)):
                 continue
-            d4 = ops.fwd_desc(src, ov, cp, Co, k, s, p, d, wC=cp, merge_x=mx, tile_hint=ops.tile_hint(bm, bn_, 1, w8))
+            d4 = ops.fwd_desc(src, ov, cp, Co, k, s, p, d, wC=cp, merge_x=mx, tile_hint=ops.tile_hint(bm, bn_, 1, w8) | (k64 << 27))
             chunks = (B * Ho * Wo + bm - 1) // bm
             part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
             L.check(L.lib.zsg_conv_igemm(C.byref(d4), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "igemm+stats")

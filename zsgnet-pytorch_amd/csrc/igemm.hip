@@ -39,6 +39,7 @@ struct IgParams {
     int splits;       // split-K factor (1: plain stores; >1: fp32 atomic accumulation into a zeroed / pre-filled output)
     int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
+    int bk64;         // tile_hint bit 27: 64-deep K tiles
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     IgSegDev seg[ZSG_MAX_SEG];
@@ -63,11 +64,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (fpn_resnet.py:86-97: conv -> bn -> relu -> conv).  The registers->LDS stage applies the BatchNorm as one fma per value with the
 // per-channel (scale, shift) pair of zsg_bn_affine_from_partials and the ReLU as one max: the normalised activation is never
 // read from HBM on the forward's critical path (its materialisation for the backward runs off the chain on the side stream).
-template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false>
+//
+// BK: K-tile depth.  32 = one barrier per 32 reduction elements; 64 halves the number of K steps — each step carries ~0.3-0.4 us
+// that no MFMA overlaps (address arithmetic, load issue, fragment-read latency, the barrier: tools/igemm_model.py, profiles/
+// r03_igemm_model_*.txt), which at one or two resident blocks per CU is 25-45 % of a step — at twice the LDS per block.
+template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK>
 __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams p) {
-    constexpr int LDR = BX ? 52 : IG_LDK;     // floats per LDS tile row
+    static_assert(BK == 32 || (BK == 64 && !BX && !MERGE_X), "K tile depth");
+    constexpr int LDR = BX ? 52 : BK + 4;     // floats per LDS tile row (an odd number of 16-byte units: conflict-free b128 fragment reads)
     constexpr int NT = 64 * WM * WN * KS;     // threads
-    constexpr int RP = NT / 8;           // tile rows staged per pass (8 threads x 16 B cover one 32-float row)
+    constexpr int KG = BK / 4;           // threads (16-byte groups) per tile row
+    constexpr int RP = NT / KG;          // tile rows staged per pass
     constexpr int RA = BM / RP;          // A rows staged per thread
     constexpr int RB = BN / RP;          // B rows staged per thread
     constexpr int TM = BM / WM / 32;     // 32x32 MFMA tiles per wave along M
@@ -83,11 +90,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     const int kg = wave / (WM * WN);     // K group of this wave
     const int wmn = wave % (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
-    const int g = tid & 7;               // 16-byte k-group staged by this thread
+    const int g = tid % KG;              // 16-byte k-group staged by this thread
     // first staged row.  BX: the three 8-byte plane stores of a split value go out in 16-lane groups = two rows; at the 52-word row
     // pitch rows r and r + 1 overlap on 4 of the 32 store banks, rows r and r + 4 do not (4 x 52 = 16 mod 32) — so lane bit 3 selects
     // row bit 2 (PMC: 15.3 M conflict cycles on the head-sized launch with the linear order)
-    const int r0 = BX ? ((tid >> 6) << 3) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3) : tid >> 3;
+    const int r0 = BX ? ((tid >> 6) << 3) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3) : tid / KG;
 
     const int n_tiles_mn = p.m_tiles * p.n_tiles;
     const int split = blockIdx.x / n_tiles_mn;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     const int n0 = nt * BN;
 
     // ---- per-row gather state (fixed for the whole K loop) --------------------------------------------------
-    int a_by[RA], a_bx[RA], a_off[RA];
+    int a_by[RA], a_bx[RA], a_off[RA];   // a_off: element offset of the row's tap (0, 0) pixel — a tap adds a WAVE-UNIFORM offset
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int m = m0 + r0 + RP * j;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         const int x = rem - y * sg.rows_x;
         a_by[j] = ok ? (y * sg.sy + sg.ty.d0) : -(1 << 28);      // invalid rows fail the bounds test for every tap
         a_bx[j] = x * sg.sx + sg.tx.d0;
-        a_off[j] = sg.src_off + b * sg.src_bstride;
+        a_off[j] = ok ? sg.src_off + b * sg.src_bstride + (a_by[j] * sg.src_W + a_bx[j]) * p.src_ld : 0;
         if (g == 0)
             rowout[r0 + RP * j] =
                 ok ? sg.out_off + b * sg.out_bstride + ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         b_off[j] = (n < p.N) ? n * p.wt_ld + p.wc0 : -1;
     }
 
-    const int n_cc = MERGE_X ? 1 : (p.C + IG_BK - 1) / IG_BK;
+    const int n_cc = MERGE_X ? 1 : (p.C + BK - 1) / BK;
     const int n_jx = MERGE_X ? 1 : sg.tx.n;
     const int n_it_all = sg.ty.n * n_jx * n_cc;
     int it0 = 0, n_it = n_it_all;
@@ -167,10 +174,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         } else {
             ws_ = sg.tx.w0 + jx * sg.tx.wstep;
             dxx = jx * sg.tx.dstep;
-            koff = cc * IG_BK + 4 * g;
+            koff = cc * BK + 4 * g;
             kok = live & (koff < Cdim);
         }
         const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
+        const int toff = (dyy * srcW + (MERGE_X ? 0 : dxx)) * src_ld + (MERGE_X ? 4 * g : koff);      // (scalar part + this lane's k group)
         int okm = 0;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             // branch-free validity (bitwise &): out-of-image taps / dead rows / channel tail get an out-of-range
             // buffer offset, for which the hardware returns zeros
             const bool ok = kok & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
-            const unsigned off = 4u * (unsigned)(a_off[j] + (yy * srcW + xx) * src_ld + (MERGE_X ? 0 : koff));
+            const unsigned off = 4u * (unsigned)(a_off[j] + toff);
             ra[j] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
             if (PRE) okm |= ok ? (1 << j) : 0;
         }
@@ -298,13 +306,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             }
         } else
 #pragma unroll
-        for (int kk = 0; kk < IG_BK / 8 / KS; ++kk) {
-            const int kq = kg * (IG_BK / 8 / KS) + kk;
+        for (int kk = 0; kk < BK / 8 / KS; ++kk) {
+            const int kq = kg * (BK / 8 / KS) + kk;
             f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * IG_LDK + kq * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * IG_LDK + kq * 8);
+            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -570,17 +578,17 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE>
+template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE, int BK>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
-    const size_t lds = (size_t)2 * (BM + BN) * (BX ? 52 : IG_LDK) * sizeof(float) + BM * sizeof(int);
+    const size_t lds = (size_t)2 * (BM + BN) * (BX ? 52 : BK + 4) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;      // idempotent; a benign race sets it twice
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
@@ -591,10 +599,17 @@ static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const cha
         if (p.pre) {
             static char nm[96];
             snprintf(nm, sizeof(nm), "%s+pre", kname);
-            return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, true>(p, st, flops, nm);
+            return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, true, IG_BK>(p, st, flops, nm);
+        }
+        if constexpr (!BX) {
+            if (p.bk64) {
+                static char nm[96];
+                snprintf(nm, sizeof(nm), "%s+k64", kname);
+                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, 64>(p, st, flops, nm);
+            }
         }
     }
-    return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false>(p, st, flops, kname);
+    return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK>(p, st, flops, kname);
 }
 
 // tile_hint = BM | (BN << 8) | (splits << 16); 0 = heuristic.  The Python lowering autotunes the hint per layer on
@@ -651,6 +666,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
         ZSG_REQUIRE(!d->merge_x && ((uintptr_t)src_affine & 15) == 0, "conv_igemm_pre: needs a 16-byte aligned (scale | shift) pair and no merge_x");
         p.pre = src_affine;
     }
+    p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x && !bx && !src_affine;
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
         for (int s = 0; s < d->nseg; ++s) v = v && (d->seg[s].out_off % 4) == 0 && (d->seg[s].out_bstride % 4) == 0;

@@ -444,6 +444,7 @@ def wino_mode() -> str:
 
 
 BX_FLAG = 1 << 26            # tile_hint bit: the bf16x6 matrix path of the kernel
+K64_FLAG = 1 << 27           # tile_hint bit (igemm): 64-deep K tiles — half the K steps (barriers) at twice the LDS per block
 
 
 def matrix_mode() -> str:
@@ -518,6 +519,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands.append(tile_hint(bm, bn, 1))
             if not d.merge_x and (bm == 128 or bn == 64):
                 cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup (64x64: two K groups)
+        if not d.merge_x and d.C % 64 == 0 and os.environ.get("ZSG_K64", "1") != "0":
+            cands += [tile_hint(bm, bn, 1, w8) | K64_FLAG for bm, bn in tiles for w8 in (0, 1) if not (bm == 128 and bn == 128 and not w8)]
         if matrix_mode() == "bf16x6" and not d.merge_x:
             cands += [tile_hint(bm, bn, 1, w8) | BX_FLAG for bm, bn in tiles for w8 in (0, 1)]
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
@@ -526,6 +529,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if sp <= n_it and blocks64 * sp <= 3072:
                     cands.append(tile_hint(64, 64, sp))
+                    if d.C % 64 == 0 and 2 * sp <= n_it and os.environ.get("ZSG_K64", "1") != "0":
+                        cands.append(tile_hint(64, 64, sp, 1) | K64_FLAG)
                     if matrix_mode() == "bf16x6":
                         cands.append(tile_hint(64, 64, sp, 1) | BX_FLAG)
                     if blocks64 * sp < 256:
