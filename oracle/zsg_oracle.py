@@ -445,6 +445,27 @@ def synthetic_batch(B: int, H: int = 300, W: int = 300, T: int = 20, seed: int =
                 img_size=torch.tensor([[360.0, 480.0]]).repeat(B, 1))
 
 
+def learnable_batch(B: int, S: int = 128, T: int = 20, seed: int = 0):
+    """A LEARNABLE synthetic grounding task (no dataset is reachable offline): the annotated box is a bright rectangle on a dim
+    noisy background — the box is tied to an image feature, unlike synthetic_batch()'s random boxes — with noise queries.
+    Same batch contract (dat_loader.py:136-144,187-196; annot = y1x1y2x2 in [-1, 1] as synthetic_batch).  A ZSGNet trained on it
+    with Adam (lr 1e-3) for ~150 steps of 16 reaches Acc@IoU0.5 ~ 1.0 in eval mode: tests/test_gpu_fullshape.py trains the
+    HIP path and this oracle side by side on it and compares the accuracies they reach."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, S, S, generator=g) * 0.25
+    qvec = torch.randn(B, T, 300, generator=g) * 0.35
+    qlens = torch.randint(1, T + 1, (B,), generator=g).float()
+    qlens[0] = float(T)
+    c = torch.rand(B, 2, generator=g) * 1.0 - 0.5
+    s = torch.rand(B, 2, generator=g) * 0.5 + 0.3
+    annot = torch.cat([c - s / 2, c + s / 2], dim=1).clamp(-1, 1)
+    for b in range(B):
+        p0, q0, p1, q1 = [int(round((float(v) + 1) / 2 * (S - 1))) for v in annot[b]]
+        img[b, :, p0:p1 + 1, q0:q1 + 1] += 0.6
+    return dict(img=img.clamp(0, 1), qvec=qvec, qlens=qlens, annot=annot, idxs=torch.arange(B).float(),
+                img_size=torch.tensor([[360.0, 480.0]]).repeat(B, 1))
+
+
 # ----------------------------------------------------------------------------------------------
 # mdl.py / fpn_resnet.py restatement (torch CPU functional, fp32)
 # ----------------------------------------------------------------------------------------------
