@@ -147,9 +147,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         n_it = min(per, n_it_all - it0);
     }
 
-    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];      // two register stages: global loads run TWO K tiles ahead
+    // Register stages: the global loads run NS K tiles ahead of the MFMAs.  A K step of a 64x64 tile is ~0.45 us of matrix-pipe
+    // time, the operands come from the Infinity Cache / HBM with ~2 us of latency under load, and only (tiles in flight) x
+    // (BM + BN) x BK x 4 bytes per block are outstanding at any time: with one or two resident blocks per CU (the 180-730-tile grids
+    // of the encoder's 1x1 layers) two tiles ahead cap the operand stream at 7-12 B/clk/CU where the MFMAs want 12-16 — the K loop
+    // ran at 53-75 % of the pipe rate (profiles/r03_igemm_model_bk32.txt).  Four stages where a stage is <= 16 registers.
+    constexpr int NS = (RA + RB <= 4) ? 4 : ((RA + RB <= 6) ? 3 : 2);
+    f32x4 ra[NS][RA], rb[NS][RB];
     struct PreStage { f32x4 sc, sh; int okm; };   // PRE: the tile's channel-group (scale, shift) and which of its rows are real pixels
-    PreStage ps0, ps1;
+    PreStage ps[NS];
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.wt);
     const rsrc_t rsrc_p = make_rsrc(PRE ? p.pre : p.src);
@@ -264,9 +270,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
-        load_tile(ra0, rb0, ps0, true);
-        store_tile(0, ra0, rb0, ps0);
-        load_tile(ra0, rb0, ps0, n_it > 1);          // tile 1 stays in flight across the first compute phase
+        load_tile(ra[0], rb[0], ps[0], true);
+        store_tile(0, ra[0], rb[0], ps[0]);
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st) load_tile(ra[st], rb[st], ps[st], n_it > st + 1);      // tiles 1 .. NS-1 stay in flight
     }
     __syncthreads();
 
@@ -274,10 +281,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     const int a_row = wm * (BM / WM) + li;
     const int b_row = wn * (BN / WN) + li;
 
-    // one K tile: prefetch tile it+2 into `nxt`, MFMA on LDS[it&1], then park tile it+1 (already in `cur`) in the other
-    // LDS buffer.  The global->register latency is covered by two compute phases instead of one.
+    // one K tile: prefetch tile it+NS into `nxt` (the stage tile `it` has left), MFMA on LDS[it&1], then park tile it+1 (in `cur`,
+    // requested NS-1 steps ago) in the other LDS buffer.
     auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p) {
-        load_tile(nxt_a, nxt_b, nxt_p, it + 2 < n_it);
+        load_tile(nxt_a, nxt_b, nxt_p, it + NS < n_it);
         const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
         const float* b = Bs + (it & 1) * BN * LDR + b_row * LDR + 4 * lh;
         if (BX) {
@@ -324,9 +331,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         store_tile((it + 1) & 1, cur_a, cur_b, cur_p);      // (after the last tile: zeros into the idle buffer)
         __syncthreads();
     };
-    for (int it = 0; it < n_it; it += 2) {
-        k_step(it, ra0, rb0, ps0, ra1, rb1, ps1);
-        if (it + 1 < n_it) k_step(it + 1, ra1, rb1, ps1, ra0, rb0, ps0);
+    for (int it = 0; it < n_it; it += NS) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+            if (it + st < n_it) k_step(it + st, ra[st], rb[st], ps[st], ra[(st + NS - 1) % NS], rb[(st + NS - 1) % NS], ps[(st + NS - 1) % NS]);
     }
 
     // ---- K groups: sum the accumulators into group 0 (fixed order) -----------------------------------------------------------

@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     WgSegDev sg = p.seg[si];
     int kt_next = kt_begin;
 
-    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];      // two register stages: global loads run two K tiles ahead
+    // register stages: the global loads run NS K tiles ahead (see igemm.hip: with (tiles in flight) x tile bytes outstanding per
+    // block and ~2 us of memory latency under load, two tiles ahead starve a block that has the CU to itself)
+    constexpr int NS = (NA + NB <= 4) ? 4 : 2;
+    f32x4 ra[NS][NA], rb[NS][NB];
     // live == false (past this block's last K tile): every lane gets an out-of-range offset — the loads still issue and
     // return zeros without touching memory, so the K loop has no branch around them and the compiler counts the
     // outstanding loads exactly (with a branch it waited for ALL of them, vmcnt(0), before parking the previous tile).
@@ -210,9 +213,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
 
     const int n_kt = kt_end - kt_begin;
     if (n_kt > 0) {
-        load_tile(ra0, rb0, true);
-        store_tile(0, ra0, rb0);
-        load_tile(ra0, rb0, n_kt > 1);
+        load_tile(ra[0], rb[0], true);
+        store_tile(0, ra[0], rb[0]);
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st) load_tile(ra[st], rb[st], n_kt > st + 1);
     }
     __syncthreads();
 
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     const int bn = wn * (32 * TN) + TN * li;
     auto k_step = [&](int it, f32x4 (&cur_a)[NA], f32x4 (&cur_b)[NB], f32x4 (&nxt_a)[NA], f32x4 (&nxt_b)[NB]) {
         const int buf = it & 1;
-        load_tile(nxt_a, nxt_b, it + 2 < n_kt);
+        load_tile(nxt_a, nxt_b, it + NS < n_kt);
         __builtin_amdgcn_sched_barrier(0);           // keep the global loads AHEAD of the MFMA phase (the scheduler sinks them otherwise)
 #pragma unroll
         for (int kk = 0; kk < WG_BK / 2; ++kk) {
@@ -243,9 +247,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
         store_tile(buf ^ 1, cur_a, cur_b);           // (after the last tile: zeros into the idle buffer)
         __syncthreads();
     };
-    for (int it = 0; it < n_kt; it += 2) {
-        k_step(it, ra0, rb0, ra1, rb1);
-        if (it + 1 < n_kt) k_step(it + 1, ra1, rb1, ra0, rb0);
+    for (int it = 0; it < n_kt; it += NS) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+            if (it + st < n_kt) k_step(it + st, ra[st], rb[st], ra[(st + NS - 1) % NS], rb[(st + NS - 1) % NS]);
     }
     if (kt_begin >= kt_end) return;
 
