@@ -147,12 +147,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         n_it = min(per, n_it_all - it0);
     }
 
-    // Register stages: the global loads run NS K tiles ahead of the MFMAs.  A K step of a 64x64 tile is ~0.45 us of matrix-pipe
-    // time, the operands come from the Infinity Cache / HBM with ~2 us of latency under load, and only (tiles in flight) x
-    // (BM + BN) x BK x 4 bytes per block are outstanding at any time: with one or two resident blocks per CU (the 180-730-tile grids
-    // of the encoder's 1x1 layers) two tiles ahead cap the operand stream at 7-12 B/clk/CU where the MFMAs want 12-16 — the K loop
-    // ran at 53-75 % of the pipe rate (profiles/r03_igemm_model_bk32.txt).  Four stages where a stage is <= 16 registers.
-    constexpr int NS = (RA + RB <= 4) ? 4 : ((RA + RB <= 6) ? 3 : 2);
+    // Register stages: the global loads run NS K tiles ahead of the MFMAs.  NS = 2.  Deeper prefetch (4 stages where a stage is
+    // <= 16 registers, 3 up to 24) was measured in round 3 on the hypothesis that one or two resident blocks per CU are
+    // latency-starved: single launches did not move (M=1600 N=512 K=2048 64x64: 59.0 -> 59.0 us, 8-wave 52.0 -> 52.4; tools/
+    // igemm_model.py) and the step lost 1.6 % to the registers (14.32 -> 14.55 ms): not what the K loop waits for.
+    constexpr int NS = 2;
     f32x4 ra[NS][RA], rb[NS][RB];
     struct PreStage { f32x4 sc, sh; int okm; };   // PRE: the tile's channel-group (scale, shift) and which of its rows are real pixels
     PreStage ps[NS];

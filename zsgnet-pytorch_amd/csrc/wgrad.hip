@@ -146,9 +146,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
     WgSegDev sg = p.seg[si];
     int kt_next = kt_begin;
 
-    // register stages: the global loads run NS K tiles ahead (see igemm.hip: with (tiles in flight) x tile bytes outstanding per
-    // block and ~2 us of memory latency under load, two tiles ahead starve a block that has the CU to itself)
-    constexpr int NS = (NA + NB <= 4) ? 4 : 2;
+    // register stages: the global loads run NS K tiles ahead
+    constexpr int NS = 2;            // (4 stages measured together with igemm.hip's: no gain, see there)
     f32x4 ra[NS][NA], rb[NS][NB];
     // live == false (past this block's last K tile): every lane gets an out-of-range offset — the loads still issue and
     // return zeros without touching memory, so the K loop has no branch around them and the compiler counts the
