@@ -10,9 +10,16 @@
 // LDS rows are padded to 36 floats (9 x 16 B: odd) so the b128 reads of 16 distinct rows are conflict-free.
 // Pipeline: global->registers for tile t+1 is issued before the MFMAs of tile t; registers->LDS after them into
 // the other buffer; one barrier per K-tile.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define IG_BK 32
+// IG_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong) — 1 no MFMAs, 2 no global loads
+// in the K loop, 4 no LDS stores, 8 no fragment reads, 16 no barrier.  tools/igemm_ablation.sh builds one library per value.
+#ifndef IG_ABL
+#define IG_ABL 0
+#endif
 #define IG_LDK 36
 
 struct IgSegDev {
@@ -163,10 +170,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     int jx = (it0 / n_cc) % n_jx;
     int jy = it0 / (n_cc * n_jx);
 
+    bool in_loop = false;
     // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
     // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
     // outstanding loads exactly (a branch made it wait for ALL of them, vmcnt(0), before parking the previous tile).
     auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], PreStage& ps, bool live) {
+        if ((IG_ABL & 2) && in_loop) return;
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
         int ws_, dxx, koff;
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         *(u32x2*)(row + 32 + 2 * g) = q3;
     };
     auto store_tile = [&](int buf, f32x4 (&ra)[RA], const f32x4 (&rb)[RB], const PreStage& ps) {
+        if ((IG_ABL & 4) && in_loop) return;
         float* a = As + buf * BM * LDR;
         float* b = Bs + buf * BN * LDR;
         if (PRE) {
@@ -268,6 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    in_loop = false;
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
         load_tile(ra[0], rb[0], ps[0], true);
         store_tile(0, ra[0], rb[0], ps[0]);
@@ -315,21 +326,36 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         for (int kk = 0; kk < BK / 8 / KS; ++kk) {
             const int kq = kg * (BK / 8 / KS) + kk;
             f32x4 fa[TM], fb[TN];
+            if (!(IG_ABL & 8)) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
+                for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
+                for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < TM; ++i) fa[i] = acc[i][0].xyzw;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = acc[0][j].xyzw;
+            }
+            if (!(IG_ABL & 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j][0] += fa[i][0] * fb[j][0];      // (keeps the fragment reads alive)
+            }
         }
         store_tile((it + 1) & 1, cur_a, cur_b, cur_p);      // (after the last tile: zeros into the idle buffer)
-        __syncthreads();
+        if (!(IG_ABL & 16)) __syncthreads();
     };
+    in_loop = true;
     for (int it = 0; it < n_it; it += NS) {
 #pragma unroll
         for (int st = 0; st < NS; ++st)
@@ -674,6 +700,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
         p.pre = src_affine;
     }
     p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x && !bx && !src_affine;
+
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
         for (int s = 0; s < d->nseg; ++s) v = v && (d->seg[s].out_off % 4) == 0 && (d->seg[s].out_bstride % 4) == 0;
