@@ -2,7 +2,7 @@
 # Round profile on the GPU box: (1) tune once, (2) rocprofv3 --kernel-trace --stats of the bench command,
 # (2b) the same with every launch on one stream (ZSG_SIDE_STREAM=0: per-kernel durations undisturbed by co-running kernels),
 # (3) separate --pmc passes for FETCH_SIZE / WRITE_SIZE (HBM traffic), all on the tuned steady state.
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}; OUT=$R/gpurun_out/rp_$TAG; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; OUT=$R/gpurun_out/rp_$TAG; mkdir -p $OUT
 export ZSG_TUNE_CACHE=$OUT/tune_cache.json
 cd $R && python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-bx > $OUT/tune_run.log 2>&1
 cd /tmp && export TMPDIR=/tmp
