@@ -54,7 +54,9 @@ def _worker(rank, world, port, cfg_kw, out_dir):
     opt.zero_grad()
     lf(ddp(bt), bt)["loss"].backward()                                         # a second step: reducer / plan reuse
     torch.cuda.synchronize()
-    torch.save(dict(g1=g1, w=net.store.flat.clone().cpu(), rm=net._rm.clone().cpu(), nb=nb), os.path.join(out_dir, f"r{rank}.pt"))
+    from zsgnet_pytorch_amd import ops
+    torch.save(dict(g1=g1, w=net.store.flat.clone().cpu(), rm=net._rm.clone().cpu(), nb=nb, tune={repr(k): v for k, v in ops._TUNE_CACHE.items()}),
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +80,7 @@ def test_two_rank_gradient_average_on_one_gpu(tmp_path):
         assert p.exitcode == 0, "a rank failed or hung"
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert a["nb"] >= 3, "the flat gradient buffer should be reduced in several buckets"
+    assert a["tune"] and a["tune"] == b["tune"], "every rank must run rank 0's tile choices (tuning table broadcast at the first forward)"
     assert torch.equal(a["g1"], b["g1"]), "both ranks must hold the same reduced gradients"
     assert torch.equal(a["w"], b["w"]), "parameters must stay identical across ranks"
     # (running statistics are per-GPU between syncs, as in the reference: rank 0's are broadcast at the START of a forward)

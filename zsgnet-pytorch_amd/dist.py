@@ -193,6 +193,7 @@ class DistributedDataParallel(nn.Module):
         if kind not in ("torch", "native"):
             raise ValueError(f"comm={kind!r}: expected 'torch' or 'native'")
         self.comm = NativeComm(process_group) if (kind == "native" and self.active) else None
+        self._tuned = set()
         object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a cycle
         if self.active:
             self._bcast(module.store.flat)
@@ -213,7 +214,27 @@ class DistributedDataParallel(nn.Module):
         if counters:
             dist.broadcast(m._nbt, src=0, group=self.group)
 
+    def _sync_tuning(self, inp):
+        """Rank 0 lowers (and autotunes) the launch plan of a new input geometry first and broadcasts its tile choices; the other
+        ranks lower from that table.  Every rank then runs the SAME kernel variant for the same layer (each rank tuning on its own
+        would pick by its own timing noise — harmless for the all-reduced gradients, but not reproducible, and 8x the tuning time)."""
+        if not hasattr(self.module, "plan_geometry"):
+            return
+        from . import ops
+        key = self.module.plan_geometry(inp) + (self.module.training,)
+        if key in self._tuned:
+            return
+        self._tuned.add(key)
+        if get_rank() == 0 and key not in self.module._plans:
+            self.module._plan_for(*key[:4])
+        payload = [dict(ops._TUNE_CACHE) if get_rank() == 0 else None]
+        dist.broadcast_object_list(payload, src=0, group=self.group)
+        if get_rank() != 0:
+            ops._TUNE_CACHE.update(payload[0])
+
     def forward(self, inp):
+        if self.world > 1:
+            self._sync_tuning(inp)
         if self.active and self.broadcast_buffers and self.module.training:
             self._sync_buffers()
         return self.module(inp)

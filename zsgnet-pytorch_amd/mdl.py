@@ -394,6 +394,16 @@ class ZSGNet(nn.Module):
             self._plist = [mods[n.rsplit(".", 1)[0]]._parameters[n.rsplit(".", 1)[1]] for n in self._param_names]
         return self._plist
 
+    def plan_geometry(self, inp: Dict[str, Any]) -> Tuple[int, int, int, int]:
+        """(B, H, W, T_plan) of the launch plan forward(inp) will use (T is bucketed: see forward)"""
+        img = inp["img"]
+        if img.dtype == torch.uint8:
+            B, H, W, _ = img.shape
+        else:
+            B, _, H, W = img.shape
+        T = inp["qvec"].shape[1]
+        return B, H, W, (20 if T <= 20 else (50 if T <= 50 else T))
+
     def _plan_for(self, B, H, W, T) -> "_Plan":
         key = (B, H, W, T, self.training)
         if key not in self._plans:
@@ -405,15 +415,11 @@ class ZSGNet(nn.Module):
         img, qvec, qlens = inp["img"], inp["qvec"], inp["qlens"]
         if img.device.type != "cuda" or self.device.type != "cuda":
             raise RuntimeError("ZSGNet.forward needs the model and the batch on the MI355X (no CPU fallback)")
-        if img.dtype == torch.uint8:           # [B, H, W, 3] as PIL decodes (dat_loader gpu_normalise): /255 happens on the GPU
-            B, H, W, _ = img.shape
-        else:
-            B, _, H, W = img.shape
+        # (img may be uint8 [B, H, W, 3] as PIL decodes (dat_loader gpu_normalise): /255 then happens on the GPU.)
         # The collater cuts qvec to the longest query of the batch (dat_loader.py:187-196), so T changes from batch to batch;
         # a launch plan (and its buffers) is built per geometry, so T is bucketed: the plan processes T_plan >= T tokens of
         # zero-padded input — the LSTM kernels stop at each query's own length, so the result does not depend on T_plan.
-        T = qvec.shape[1]
-        Tp = 20 if T <= 20 else (50 if T <= 50 else T)
+        B, H, W, Tp = self.plan_geometry(inp)
         plan = self._plan_for(B, H, W, Tp)
         if "h0" in inp:
             h0, c0 = inp["h0"], inp["c0"]
