@@ -208,6 +208,18 @@ int zsg_bn_affine_from_partials(const float* partials, int32_t chunks, int64_t r
 /* out = [relu](fmaf(x, affine[c], affine[C + c])); relu_mask as zsg_bn_apply */
 int zsg_bn_apply_affine(const float* x, int64_t rows, int32_t C, const float* affine, int32_t relu, float* out, uint8_t* relu_mask,
                         void* stream);
+/* Stem: nn.BatchNorm2d -> nn.ReLU -> nn.MaxPool2d(3, 2, 1) (mdl.py:149-152 on fpn_resnet.py's conv1 / bn1) in ONE pass over the
+ * stem activation x [B][H][W][C] (the network's largest tensor): out [B][Ho][Wo][C] = maxpool(relu(bn(x))), idx = window position
+ * of the first maximum (uint8, as zsg_maxpool_fwd).  The backward takes d(out): per-channel sums over the pooled gradient (the only
+ * non-zero entries of the BatchNorm's grad_output), then dx per input pixel; dgamma / dbeta as zsg_bn_backward.
+ * ws >= zsg_bn_workspace_bytes(B * Ho * Wo, C). */
+int zsg_bn_relu_maxpool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int32_t k, int32_t s, int32_t p, int32_t Ho, int32_t Wo, float* out,
+                            uint8_t* idx, void* stream);
+int zsg_bn_relu_maxpool_bwd(const float* dout, const uint8_t* idx, const float* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t k, int32_t s, int32_t p,
+                            int32_t Ho, int32_t Wo, float* dx, float* dgamma, float* dbeta, int32_t accumulate, void* ws, size_t ws_bytes,
+                            void* stream);
 /* BatchNorm apply straight from the convolution epilogue's partial rows when there are at most zsg_bn_inline_max_chunks()
  * of them (small maps: layer3 / layer4 / pyramid sizes): every block reduces the rows for its own channels (fp64, fixed
  * order), block 0 publishes mean / invstd / the running statistics — no separate finalize launch between the convolution
@@ -332,9 +344,10 @@ int zsg_loss_fwd_bwd(const float* out5, const float* annot, const float* anchors
 
 /* Evaluator.forward, evaluator.py:48-117 (reg_params_to_bbox anchors.py:182-197): arg-max score anchor -> decode ->
  * IoU >= thr.  metrics[2] = (Acc, MaxPos); pred_boxes [B][4] pixels x1y1x2y2; pred_scores [B]; pred_idx [B] int32. */
+size_t zsg_eval_workspace_bytes(int32_t B);
 int zsg_eval(const float* out5, const float* annot, const float* anchors, const float* img_size, int32_t B, int32_t A,
              float acc_thr, float* metrics, float* pred_boxes, float* pred_scores, int32_t* pred_idx, int32_t* best_idx,
-             float* ws_ok /* [2*B] */, void* stream);
+             float* ws /* zsg_eval_workspace_bytes(B): per-sample, per-anchor-range arg-max records */, void* stream);
 /* IoU table [B][A] (tests / diagnostics) */
 int zsg_iou(const float* boxes, const float* anchors, int32_t B, int32_t A, float* iou, void* stream);
 

@@ -633,3 +633,74 @@ def test_lstm_against_golden_and_oracle(Z, gold):
         assert_close(dwhh[::4, ::3], torch.from_numpy(gz["grad_weight_hh_" + tag]), 1e-3, 1e-5, "d w_hh" + suf)
         assert_close(db, torch.from_numpy(gz["grad_bias_ih_" + tag]), 1e-3, 1e-5, "d b_ih" + suf)
         assert_close(db, torch.from_numpy(gz["grad_bias_hh_" + tag]), 1e-3, 1e-5, "d b_hh" + suf)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 37, 41), (3, 16, 12, 12), (1, 64, 150, 150)], ids=["odd", "small", "stem"])
+def test_stem_bn_relu_maxpool_fused(Z, shape):
+    """zsg_bn_relu_maxpool_fwd / _bwd == nn.BatchNorm2d(train) -> ReLU -> MaxPool2d(3, 2, 1) (mdl.py:149-152) and its autograd
+    backward: pooled values rel 5e-4, window indices exact wherever the window's top two values differ by more than rounding,
+    dx / dgamma / dbeta rel 1e-3 of their scale (fp32 sums)."""
+    L, ops = Z
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(31 + H)
+    x = (torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.4).requires_grad_()
+    gam = (torch.rand(Cc, generator=g) + 0.5).requires_grad_()
+    bet = (0.3 * torch.randn(Cc, generator=g)).requires_grad_()
+    a = F.relu(F.batch_norm(x, None, None, gam, bet, True, 0.1, 1e-5))
+    out_ref, idx_ref = F.max_pool2d(a, 3, 2, 1, return_indices=True)
+    Ho, Wo = out_ref.shape[2:]
+    gy = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(gy)
+    st = L.stream_ptr()
+    xd = dev(nhwc(x.detach()))
+    xf = x.detach().permute(0, 2, 3, 1).reshape(-1, Cc).double()
+    mean, invstd = dev(xf.mean(0).float()), dev((1 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).float())
+    gd, bd = dev(gam.detach()), dev(bet.detach())
+    out = torch.full((B, Ho, Wo, Cc), float("nan"), device="cuda")
+    idx = torch.zeros(B * Ho * Wo * Cc, dtype=torch.uint8, device="cuda")
+    L.check(L.lib.zsg_bn_relu_maxpool_fwd(xd.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 3, 2, 1, Ho, Wo,
+                                          out.data_ptr(), idx.data_ptr(), st), "bn_relu_maxpool_fwd")
+    assert_close(out.permute(0, 3, 1, 2), out_ref, 5e-4, 5e-4, "fused stem forward")
+    # window code -> flat input index, compared with torch's where the maximum is unique beyond rounding
+    code = idx.view(B, Ho, Wo, Cc).permute(0, 3, 1, 2).cpu().long()
+    ho = torch.arange(Ho).view(1, 1, Ho, 1)
+    wo = torch.arange(Wo).view(1, 1, 1, Wo)
+    flat = (ho * 2 - 1 + code // 3) * W + (wo * 2 - 1 + code % 3)
+    ap = F.pad(a.detach(), (1, 1, 1, 1), value=-1.0)
+    win = ap.unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, Cc, Ho, Wo, 9)
+    top2 = win.topk(2, dim=-1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert torch.equal(flat[sure], idx_ref[sure]), "arg-max window positions"
+    # backward
+    gyd = dev(nhwc(gy))
+    dx = torch.full((B, H, W, Cc), float("nan"), device="cuda")
+    dgam, dbet = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    wsb = L.lib.zsg_bn_workspace_bytes(B * Ho * Wo, Cc)
+    ws = torch.empty(wsb // 4 + 16, device="cuda")
+    L.check(L.lib.zsg_bn_relu_maxpool_bwd(gyd.data_ptr(), idx.data_ptr(), xd.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+                                          bd.data_ptr(), 3, 2, 1, Ho, Wo, dx.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), 0, ws.data_ptr(), wsb, st),
+            "bn_relu_maxpool_bwd")
+    assert_close(dx.permute(0, 3, 1, 2), x.grad, 1e-3, 1e-3 * float(x.grad.abs().max()), "fused stem dx")
+    assert_close(dgam, gam.grad, 1e-3, 1e-3 * float(gam.grad.abs().max()), "fused stem dgamma")
+    assert_close(dbet, bet.grad, 1e-3, 1e-3 * float(bet.grad.abs().max()), "fused stem dbeta")
+
+
+@pytest.mark.parametrize("case", [(2, 3, 64, 45, 37, 7, 2, 3, 40), (2, 256, 64, 20, 17, 1, 1, 0, 9), (1, 20, 48, 13, 13, 3, 1, 1, 1)],
+                         ids=["stem7x7", "l1conv1", "ragged"])
+def test_wgrad_256_column_tile(Z, case):
+    """zsg_conv_wgrad with the 256-column tile (tile_hint BN field 255): all weight columns of a <= 64-output-channel layer from one
+    block — the 7x7x4 stem (196 columns), layer1's 256 -> 64 1x1, a ragged 48 x 180 case — vs torch's weight gradient."""
+    L, ops = Z
+    B, Ci, Co, H, W, k, s, p, splits = case
+    g = torch.Generator().manual_seed(3 + Ci + k)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    Ho, Wo = ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p)
+    gy = torch.randn(B, Co, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, k, k), gy, stride=s, padding=p)
+    cp, Cop = pad4(Ci), pad4(Co)
+    xd, dyd = dev(nhwc(x)), dev(nhwc(gy, Cop))
+    src, dyv = view_of(ops, xd, B, H, W, cp), view_of(ops, dyd, B, Ho, Wo, Cop)
+    d = ops.fwd_desc(src, dyv, cp, Co, k, s, p, 1, wC=cp, tile_hint=ops.tile_hint(64, 255, splits))
+    dw = torch.zeros(Co, k, k, cp, device="cuda")
+    L.check(L.lib.zsg_conv_wgrad(C.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad 64x256")
+    assert_close(dw[..., :Ci].permute(0, 3, 1, 2), ref, 5e-4, 5e-4 * float(ref.abs().max()), "wgrad, 256-column tile")

@@ -59,6 +59,8 @@ SIGNATURES = {
     "zsg_conv_wino_pre": (I32, [DP, P, P, P, P, P, P, P, P, P]),
     "zsg_bn_affine_from_partials": (I32, [P, I32, I64, I32, P, P, P, P, P, P, F32, F32, P, P]),
     "zsg_bn_apply_affine": (I32, [P, I64, I32, P, I32, P, P, P]),
+    "zsg_bn_relu_maxpool_fwd": (I32, [P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P]),
+    "zsg_bn_relu_maxpool_bwd": (I32, [P, P, P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, I32, P, SZ, P]),
     "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_conv_wino_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_bn_backward_from_partials": (I32, [P, P, P, I64, I32, P, P, P, P, P, P, P, I32, P, I32, P, SZ, P]),
@@ -108,6 +110,7 @@ SIGNATURES = {
     "zsg_lstm_bwd": (I32, [P, I32, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "zsg_loss_workspace_bytes": (SZ, [I32, I32]),
     "zsg_loss_fwd_bwd": (I32, [P, P, P, I32, I32, F32, F32, F32, F32, I32, F32, P, P, P, P, P, SZ, P]),
+    "zsg_eval_workspace_bytes": (SZ, [I32]),
     "zsg_eval": (I32, [P, P, P, P, I32, I32, F32, P, P, P, P, P, P, P]),
     "zsg_iou": (I32, [P, P, I32, I32, P, P]),
     "zsg_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, P]),

@@ -2,12 +2,15 @@
 // reads p,g,m,v and writes p,m,v once: 28 B per parameter.
 #include "common.h"
 
-__global__ void adam_tick_kernel(int* step) { *step += 1; }
+// The step counter lives on the device (the launch is hipGraph-capturable).  Every block reads it when it starts and uses t = count + 1;
+// the block that FINISHES last (ticket) publishes t and clears the ticket — by then every block has read the old value.  (A separate
+// one-thread "tick" launch ahead of the update was 8 us of dependent launch at the end of every step.)
+__device__ int g_adam_done;
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n4, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float gs, const int* __restrict__ step) {
-    const int t = *step;                                  // already incremented for this step
+                                                   float wd, float gs, int* step) {
+    const int t = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const float bc1 = 1.f - powf(b1, (float)t);
     const float bc2s = sqrtf(1.f - powf(b2, (float)t));
     const float step_size = lr / bc1;
@@ -36,6 +39,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mm;
         v[i] = vv;
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&g_adam_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(&g_adam_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(step, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 extern "C" int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
@@ -43,7 +51,6 @@ extern "C" int zsg_adam_step(float* p, const float* g, float* m, float* v, int64
     ZSG_REQUIRE(p && g && m && v && step_count && n > 0, "adam_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("adam_step", st, 0, (double)n * 28);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_count);
     const int64_t n4 = n / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > ZSG_NUM_CU * 8) blocks = ZSG_NUM_CU * 8;

@@ -393,6 +393,154 @@ extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks,
     return 0;
 }
 
+// ---- stem: BatchNorm + ReLU + max-pool in one pass (fpn_resnet.py / mdl.py:149-152: conv1 -> bn1 -> relu -> maxpool(3, 2, 1)) ------------
+// The 150x150x64 stem activation is the largest tensor of the network (92 MB at B=16).  Separate launches read and write it three
+// times in the forward (BatchNorm apply: x -> a; pool: a -> out) and six times in the backward (pool backward writes a dense d(a),
+// BatchNorm backward reads it twice beside x).  Fused, the normalised activation never exists: the forward reads x once and writes
+// the pooled map + window indices; the backward's statistics pass walks the POOLED gradient (the only non-zero entries of d(a) sit at
+// the arg-max positions) and its apply pass gathers them per input pixel.  bn_pool_val is the one expression both directions use
+// for relu(bn(x)), so the forward's arg-max / ReLU decisions and the backward's are the same bits.
+__device__ __forceinline__ f32x4 bn_pool_val(const f32x4 x, const f32x4 mu, const f32x4 sc, const f32x4 be) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(x[e] - mu[e], sc[e], be[e]), 0.f);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int k, int s,
+                                                                  int p, int Ho, int Wo, float* __restrict__ out, uint8_t* __restrict__ idx) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const f32x4 mu = *(const f32x4*)(mean + 4 * c4);
+        const f32x4 sc = *(const f32x4*)(invstd + 4 * c4) * *(const f32x4*)(gamma + 4 * c4);
+        const f32x4 be = *(const f32x4*)(beta + 4 * c4);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * s - p + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wi = wo * s - p + q;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = bn_pool_val(*(const f32x4*)(x + (((int64_t)b * H + hi) * W + wi) * C4 * 4 + c4 * 4), mu, sc, be);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) {      // first maximum wins; NaN propagates (torch rule)
+                        best[e] = v[e];
+                        bi[e] = r * k + q;
+                    }
+            }
+        }
+        *(f32x4*)(out + i * 4) = best;
+        *(uchar4*)(idx + i * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    }
+}
+
+// partial (sum g, sum g * xhat) over a chunk of POOLED pixels: g = dout * (relu(bn(x)) > 0) at the window's arg-max position
+__global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                  const float* __restrict__ x, int H, int W, int C, int k, int s, int p, int Ho,
+                                                                  int Wo, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
+                                                                  int lanes, int rpb, float* __restrict__ part) {
+    __shared__ f32x4 red[2][256];
+    const int rowlanes = 256 / lanes;
+    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int c = (blockIdx.y * lanes + l) * 4;
+    const bool cok = c < C;
+    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (cok) {
+        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+        const f32x4 sc = is * *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+        for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
+            const int wo = (int)(r % Wo);
+            const int64_t t = r / Wo;
+            const int ho = (int)(t % Ho);
+            const int64_t b = t / Ho;
+            const uchar4 u = *(const uchar4*)(idx + r * C + c);
+            const f32x4 g = *(const f32x4*)(dout + r * C + c);
+            const unsigned code[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hi = ho * s - p + (int)(code[e] / k), wi = wo * s - p + (int)(code[e] % k);
+                const float xv = x[((b * H + hi) * W + wi) * C + c + e];
+                const float v = fmaxf(fmaf(xv - mu[e], sc[e], be[e]), 0.f);
+                const float ge = v > 0.f ? g[e] : 0.f;
+                s0[e] += ge;
+                s1[e] += ge * ((xv - mu[e]) * is[e]);
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0 && cok) {
+        for (int kk = 1; kk < rowlanes; ++kk) {
+            s0 += red[0][kk * lanes + l];
+            s1 += red[1][kk * lanes + l];
+        }
+        float* o = part + (size_t)blockIdx.x * 2 * C;
+        *(f32x4*)(o + c) = s0;
+        *(f32x4*)(o + C + c) = s1;
+    }
+}
+
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) per INPUT pixel; g gathered from the (<= ceil(k/s)^2) windows that contain it
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                const float* __restrict__ x, int H, int W, int C, int k, int s, int p, int Ho,
+                                                                int Wo, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ coef, int64_t rows, float* __restrict__ dx, int lanes,
+                                                                int rpb) {
+    const int rowlanes = 256 / lanes;
+    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int c = (blockIdx.y * lanes + l) * 4;
+    if (c >= C) return;
+    const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+    const f32x4 sc = is * *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+    const f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + C + c);
+    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
+    for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
+        const int wi = (int)(r % W);
+        const int64_t t = r / W;
+        const int hi = (int)(t % H);
+        const int64_t b = t / H;
+        const f32x4 xv = *(const f32x4*)(x + r * C + c);
+        const f32x4 v = bn_pool_val(xv, mu, sc, be);
+        f32x4 g = {0, 0, 0, 0};
+        for (int rr = 0; rr < k; ++rr) {
+            const int hn = hi + p - rr;
+            if (hn < 0 || (hn % s) != 0 || hn / s >= Ho) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wn = wi + p - q;
+                if (wn < 0 || (wn % s) != 0 || wn / s >= Wo) continue;
+                const int64_t o = ((b * Ho + hn / s) * Wo + wn / s) * C + c;
+                const uchar4 u = *(const uchar4*)(idx + o);
+                const f32x4 d = *(const f32x4*)(dout + o);
+                const unsigned code = rr * k + q;
+                g[0] += (u.x == code) ? d[0] : 0.f;
+                g[1] += (u.y == code) ? d[1] : 0.f;
+                g[2] += (u.z == code) ? d[2] : 0.f;
+                g[3] += (u.w == code) ? d[3] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
+        const f32x4 xh = (xv - mu) * is;
+        *(f32x4*)(dx + r * C + c) = sc * (g - c1 - xh * c2);
+    }
+}
+
 // Finalize + the (scale | shift) pair for consumers that apply this BatchNorm (+ ReLU) while they load its input.
 extern "C" int zsg_bn_affine_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, const float* gamma, const float* beta,
                                            float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
@@ -415,6 +563,46 @@ extern "C" int zsg_bn_apply_affine(const float* x, int64_t rows, int32_t C, cons
     ZSG_PROF("bn_apply", st, 0, (double)rows * C * (8 + (relu_mask && relu ? 0.25 : 0)));
     hipLaunchKernelGGL(bn_apply_affine_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, affine, relu, out, relu_mask, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_apply_affine");
+    return 0;
+}
+
+extern "C" int zsg_bn_relu_maxpool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, int32_t k, int32_t s, int32_t p, int32_t Ho, int32_t Wo, float* out,
+                                       uint8_t* idx, void* stream) {
+    ZSG_REQUIRE(x && mean && invstd && gamma && beta && out && idx && B > 0 && C > 0 && (C % 4) == 0 && k > 0 && k <= 15 && s > 0,
+                "bn_relu_maxpool_fwd: bad argument");
+    const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_relu_maxpool_fwd", st, 0, ((double)B * H * W + (double)B * Ho * Wo * 1.25) * C * 4);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > ZSG_NUM_CU * 16) blocks = ZSG_NUM_CU * 16;
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((int)blocks), dim3(256), 0, st, x, B, H, W, C / 4, mean, invstd, gamma, beta, k, s, p, Ho, Wo,
+                       out, idx);
+    ZSG_CHECK_LAUNCH("bn_relu_maxpool_fwd");
+    return 0;
+}
+
+// ws: >= zsg_bn_workspace_bytes(B * Ho * Wo, C)
+extern "C" int zsg_bn_relu_maxpool_bwd(const float* dout, const uint8_t* idx, const float* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                                       const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t k, int32_t s,
+                                       int32_t p, int32_t Ho, int32_t Wo, float* dx, float* dgamma, float* dbeta, int32_t accumulate, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(dout && idx && x && mean && invstd && gamma && beta && dx && ws && B > 0 && C > 0 && (C % 4) == 0 && k > 0 && k <= 15 && s > 0,
+                "bn_relu_maxpool_bwd: bad argument");
+    const int64_t prow = (int64_t)B * Ho * Wo, rows = (int64_t)B * H * W;
+    if (ws_bytes < zsg_bn_workspace_bytes(prow, C)) ZSG_FAIL(-2, "bn_relu_maxpool_bwd: workspace too small");
+    const BnGeom gp = bn_geom(prow, C), g = bn_geom(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_backward", st, 0, ((double)prow * 2.25 + (double)rows * 2) * C * 4);
+    float* part = (float*)ws;
+    float* coef = part + (size_t)gp.chunks * 2 * C;
+    hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(gp.chunks, gp.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd,
+                       gamma, beta, prow, gp.lanes, gp.rpb, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, part, gp.chunks, C, rows, coef, dgamma, dbeta,
+                       accumulate);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd, gamma,
+                       beta, coef, rows, dx, g.lanes, g.rpb);
+    ZSG_CHECK_LAUNCH("bn_relu_maxpool_bwd");
     return 0;
 }
 

@@ -310,7 +310,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     int kt = 0;
     double rows_all = 0;
     const bool avec = (d->out_ld & 3) == 0;                       // else: the single scalar-load variant (64x64 tile, BK 16)
-    const int BKsel = (avec && ((d->tile_hint >> 25) & 1)) ? 32 : 16;       // tile_hint bit 25: 32-pixel K tiles
+    const int BKsel = (avec && ((d->tile_hint >> 25) & 1) && ((d->tile_hint >> 8) & 0xff) != 255) ? 32 : 16;       // tile_hint bit 25: 32-pixel K tiles
     p.bk = BKsel;
     for (int s = 0; s < d->nseg; ++s) {
         const zsg_seg& a = d->seg[s];
@@ -340,6 +340,9 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     if (d->tile_hint) {
         TM = ((d->tile_hint & 0xff) >= 128) ? 2 : 1;
         TN = (((d->tile_hint >> 8) & 0xff) >= 128) ? 2 : 1;
+        // BN field 255 = a 256-column tile (TM = 1 only): the 64-output-channel layers whose weight rows are <= 256 columns wide (the
+        // 7x7x4 stem: 196) get ALL columns from one block, so dY — the large operand there — is read once instead of once per column tile
+        if (((d->tile_hint >> 8) & 0xff) == 255 && TM == 1) TN = 4;
         want_splits = (d->tile_hint >> 16) & 0xff;
         w8 = ((d->tile_hint >> 24) & 1) && TM == 2 && TN == 2;      // 8-wave workgroup: 128x128 tile only
     }
@@ -386,7 +389,8 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
         else if (TM == 1 && TN == 2) WG_LAUNCH(1, 2, 32, 2, 2);
         else WG_LAUNCH(1, 1, 32, 2, 2);
     } else {
-        if (TM == 2 && TN == 2) WG_LAUNCH(2, 2, 16, 2, 2);
+        if (TN == 4) WG_LAUNCH(1, 4, 16, 2, 2);
+        else if (TM == 2 && TN == 2) WG_LAUNCH(2, 2, 16, 2, 2);
         else if (TM == 2 && TN == 1) WG_LAUNCH(2, 1, 16, 2, 2);
         else if (TM == 1 && TN == 2) WG_LAUNCH(1, 2, 16, 2, 2);
         else WG_LAUNCH(1, 1, 16, 2, 2);

@@ -43,7 +43,7 @@ class Evaluator(nn.Module):
         pred_scores = torch.empty(B, device=dev)
         self.pred_idx = torch.empty(B, dtype=torch.int32, device=dev)
         self.best_idx = torch.empty(B, dtype=torch.int32, device=dev)
-        ws = torch.empty(2 * B, device=dev)
+        ws = torch.empty((int(lib.zsg_eval_workspace_bytes(B)) + 3) // 4, device=dev)
         check(lib.zsg_eval(out5.data_ptr(), annot.data_ptr(), self.anchs.data_ptr(), img_size.data_ptr(), B, A,
                            float(self.acc_iou_threshold), metrics.data_ptr(), pred_boxes.data_ptr(), pred_scores.data_ptr(),
                            self.pred_idx.data_ptr(), self.best_idx.data_ptr(), ws.data_ptr(), stream_ptr()), "zsg_eval")

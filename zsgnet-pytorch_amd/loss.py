@@ -27,12 +27,18 @@ class _LossFn(torch.autograd.Function):
                                    grad5.data_ptr(), mod.match_idx.data_ptr(), mod.npos.data_ptr(), ws.data_ptr(), wsb,
                                    stream_ptr()), "zsg_loss_fwd_bwd")
         ctx.save_for_backward(grad5)
+        ctx.g5_buf = getattr(out5, "_zsg_g5", None)      # the network plan's incoming-gradient buffer, when out5 came from ZSGNet
         mod._last_losses = losses
         return losses[0].clone()
 
     @staticmethod
     def backward(ctx, g):
         (grad5,) = ctx.saved_tensors
+        buf = ctx.g5_buf
+        if buf is not None and buf.numel() == grad5.numel() and buf.device == grad5.device:
+            out = buf.view_as(grad5)             # one launch writes g * grad5 where the network's backward reads it
+            torch.mul(grad5, g, out=out)
+            return out, None, None
         return grad5 * g, None, None
 
 

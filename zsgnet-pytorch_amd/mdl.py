@@ -432,6 +432,8 @@ class ZSGNet(nn.Module):
             self._anchor = torch.zeros(1, device=img.device, requires_grad=True)
         plan.expect_backward = torch.is_grad_enabled()      # (grad mode is off inside autograd.Function.forward: decide here)
         out5 = _NetFn.apply(self, plan, img, qvec, qlens, h0, c0, self._anchor)
+        if plan.training:
+            out5._zsg_g5 = plan.g5_in           # where the loss may write d(loss)/d(out5) directly (loss._LossFn.backward): no copy
         return dict(att_out=out5[..., 4:5], bbx_out=out5[..., :4], feat_sizes=plan.feat_sizes_t,
                     num_f_out=plan.num_f_out_t, att_bbx_out=out5)
 
@@ -480,7 +482,15 @@ class _Plan:
         self.wino_jobs = {"fwd": WinoJobs(), "bwd": WinoJobs()}     # filter transforms of the Winograd convolutions (one launch each)
         self._lower()
         wj = self.wino_jobs["fwd"]
-        if wj.jobs:          # U = G g G^T of every Winograd forward convolution: first launch after the image conversion
+        self.prep_u, self._u_ev, self._first_wino = Program("fwd-prep"), None, 0
+        if wj.jobs and training and os.environ.get("ZSG_U_ON_SIDE", "1") != "0":
+            # U = G g G^T of every Winograd forward convolution depends on the weights only: in training it runs on the side stream
+            # while the main stream converts the image and runs the stem (it was 47 us at the head of the forward's dependent
+            # chain); the main stream waits for it (an event wait, no marker of its own) right before its first Winograd launch
+            self.prep_u.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
+            wfns = (lib.zsg_conv_wino, lib.zsg_conv_wino_pre)
+            self._first_wino = next(i for i, c in enumerate(self.fwd.calls) if c[0] in wfns)
+        elif wj.jobs:        # eval (after the BatchNorm fold): first launch after the image conversion
             self.fwd.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
             self.fwd.calls.insert(1, self.fwd.calls.pop())
             self.fwd.lanes.insert(1, self.fwd.lanes.pop())
@@ -925,8 +935,8 @@ class _Plan:
         self.in_qvec = self._buf(B * T * net.emb_dim)
         self.in_qlens = self._buf(B)
         nd = 2 if net.bid else 1
-        self.in_h0 = self._buf(nd * B * net.lstm_dim)
-        self.in_c0 = self._buf(nd * B * net.lstm_dim)
+        self.in_hc = self._buf(2 * nd * B * net.lstm_dim)            # (h0 | c0: ONE host-to-device copy per step when both come from the host)
+        self.in_h0, self.in_c0 = self.in_hc[:nd * B * net.lstm_dim], self.in_hc[nd * B * net.lstm_dim:]
         self.img_slot = len(self.fwd.calls)
         x0 = self.act("img_nhwc4", B, H, W, 4, requires_grad=False)
         self.fwd.add(lib.zsg_nchw_to_nhwc4, self.in_qvec, B, 3, H, W, x0.buf, what="img")     # src pointer patched per call
@@ -950,20 +960,23 @@ class _Plan:
         if net.backbone_kind == "ssd_vgg":
             feats = self._lower_ssd(x0)
         else:
-            a = self.conv_bn(C[e + "conv1"], BN[e + "bn1"], x0, True, name="stem.a", yname="stem.y")
             H2, W2 = conv_out(H1, 3, 2, 1), conv_out(W1, 3, 2, 1)
-            x = self.act("pool", B, H2, W2, 64)
-            idx = self._buf((B * H2 * W2 * 64 + 3) // 4)      # uint8 indices, stored in a float-sized buffer
-            self.fwd.add(lib.zsg_maxpool_fwd, a.buf, B, H1, W1, 64, 3, 2, 1, H2, W2, x.buf, idx, what="maxpool")
-            pool_in, pool_out = a, x
+            if self.training and os.environ.get("ZSG_STEM_FUSE", "1") != "0":
+                x = self._lower_stem_fused(C[e + "conv1"], BN[e + "bn1"], x0, H1, W1, H2, W2)
+            else:
+                a = self.conv_bn(C[e + "conv1"], BN[e + "bn1"], x0, True, name="stem.a", yname="stem.y")
+                x = self.act("pool", B, H2, W2, 64)
+                idx = self._buf((B * H2 * W2 * 64 + 3) // 4)      # uint8 indices, stored in a float-sized buffer
+                self.fwd.add(lib.zsg_maxpool_fwd, a.buf, B, H1, W1, 64, 3, 2, 1, H2, W2, x.buf, idx, what="maxpool")
+                pool_in, pool_out = a, x
 
-            def pool_back():
-                if pool_out.grad is None:
-                    return
-                dx = self.grad_of(pool_in)
-                self.bwd.add(lib.zsg_maxpool_bwd, self.base(pool_out.grad), idx, B, H1, W1, 64, 3, 2, 1, H2, W2, dx.buf, what="maxpool_bwd")
-                dx.gfilled = True
-            self.tape.append(pool_back)
+                def pool_back():
+                    if pool_out.grad is None:
+                        return
+                    dx = self.grad_of(pool_in)
+                    self.bwd.add(lib.zsg_maxpool_bwd, self.base(pool_out.grad), idx, B, H1, W1, 64, 3, 2, 1, H2, W2, dx.buf, what="maxpool_bwd")
+                    dx.gfilled = True
+                self.tape.append(pool_back)
             taps = {}
             for blk in net.blocks:
                 x = self._lower_block(blk, x)
@@ -1000,6 +1013,37 @@ class _Plan:
         for (*args, what) in self._deferred:
             self.fwd.add(lib.zsg_bn_apply_affine, *args, what=what, lane=1 if self.training else 0)
         self._deferred = []
+
+    def _lower_stem_fused(self, L: ConvL, Lb: BnL, x0: Act, H1: int, W1: int, H2: int, W2: int) -> Act:
+        """conv1 -> bn1 -> relu -> maxpool (mdl.py:149-152) in training: the BatchNorm + ReLU + max-pool are ONE pass over the stem
+        activation (zsg_bn_relu_maxpool_fwd / _bwd) — the normalised 150x150x64 map, its ReLU mask and the dense pool gradient
+        never exist (the stem activation is 92 MB at B=16: 311 -> 121 MB forward, 552 -> 236 MB backward)."""
+        net, B = self.net, self.B
+        y = self.conv(L, x0, name="stem.y", bn_fuse=Lb)
+        rows = B * H1 * W1
+        rm, rv = net._rm[Lb.index:Lb.index + Lb.c], net._rv[Lb.index:Lb.index + Lb.c]
+        gam, bet = self.P(Lb.name + ".weight"), self.P(Lb.name + ".bias")
+        self.ws_need = max(getattr(self, "ws_need", 0), lib.zsg_bn_workspace_bytes(rows, Lb.c))
+        if getattr(y, "bn_chunks", 0) > 0:
+            mean, invstd = y.bn_mean, y.bn_invstd
+            if y.bn_inline is not None:          # few partial rows (small inputs): nobody else will finalize them
+                self.fwd.add(lib.zsg_bn_stats_from_partials, y.bn_inline, y.bn_chunks, rows, Lb.c, mean, invstd, rm, rv, 0.1, 1e-5, what="stats:" + Lb.name)
+        else:
+            mean, invstd = self._buf(Lb.c), self._buf(Lb.c)
+            self.fwd.add(lib.zsg_bn_stats, y.buf, rows, Lb.c, mean, invstd, rm, rv, 0.1, 1e-5, self.ws, self.ws_bytes, what=Lb.name)
+        x = self.act("pool", B, H2, W2, Lb.c)
+        idx = self._buf((B * H2 * W2 * Lb.c + 3) // 4)      # uint8 indices, stored in a float-sized buffer
+        self.fwd.add(lib.zsg_bn_relu_maxpool_fwd, y.buf, B, H1, W1, Lb.c, mean, invstd, gam, bet, 3, 2, 1, H2, W2, x.buf, idx, what="bn1+relu+maxpool")
+
+        def back():
+            if x.grad is None:
+                return
+            dy = self.grad_of(y)
+            self.bwd.add(lib.zsg_bn_relu_maxpool_bwd, self.base(x.grad), idx, y.buf, B, H1, W1, Lb.c, mean, invstd, gam, bet, 3, 2, 1, H2, W2, dy.buf,
+                         self.G(Lb.name + ".weight"), self.G(Lb.name + ".bias"), 1, self.ws, self.ws_bytes, what="bnbwd+maxpool_bwd:" + Lb.name)
+            dy.gfilled = True
+        self.tape.append(back)
+        return x
 
     # ---- generic pooling / normalisation lowering (SSD-VGG trunk) -------------------------------------------------
     def _grad_sink(self, a: Act):
@@ -1468,8 +1512,11 @@ class _Plan:
             qbuf[:, T:].zero_()
         self.in_qlens.copy_(qlens.reshape(B), non_blocking=True)
         nd = 2 if net.bid else 1
-        self.in_h0.view(nd, B, net.lstm_dim).copy_(h0, non_blocking=True)
-        self.in_c0.view(nd, B, net.lstm_dim).copy_(c0, non_blocking=True)
+        if h0.device.type == "cpu" and c0.device.type == "cpu":     # lstm_init_hidden's two host draws: one transfer
+            self.in_hc.view(2, nd, B, net.lstm_dim).copy_(torch.stack([h0.float(), c0.float()]), non_blocking=True)
+        else:
+            self.in_h0.view(nd, B, net.lstm_dim).copy_(h0, non_blocking=True)
+            self.in_c0.view(nd, B, net.lstm_dim).copy_(c0, non_blocking=True)
         # patch the one dynamic pointer (the caller's image tensor)
         fn, args, what = self.fwd.calls[self.img_slot]
         import ctypes as C_
@@ -1486,16 +1533,26 @@ class _Plan:
             check(lib.zsg_u8hwc_to_nhwc4(img.data_ptr(), B * self.H * self.W, self.fwd.calls[self.img_slot][1][5], stream_ptr()), "u8hwc_to_nhwc4")
         else:
             self.fwd.run(stream_ptr(), 0, 1, graph=False)          # the one launch with a per-call pointer (the caller's image)
-        if self.training and self.expect_backward and len(self.prep):
-            # the backward's weight images (transposed filters of the data gradients, their Winograd transforms) depend on
-            # the weights only: produced here on the side stream, under the forward, instead of heading the backward
+        do_prep = self.training and self.expect_backward and len(self.prep)
+        if do_prep or len(self.prep_u):
+            # the forward's Winograd filter transforms and the backward's weight images (transposed filters of the data gradients,
+            # their Winograd transforms) depend on the weights only: produced here on the side stream, under the forward
             if self._prep_stream is None:
-                self._prep_stream, self._prep_ev = shared_side_stream(), torch.cuda.Event()
+                self._prep_stream, self._prep_ev, self._u_ev = shared_side_stream(), torch.cuda.Event(), torch.cuda.Event()
             self._prep_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step that wrote the weights
-            self.prep.run(self._prep_stream.cuda_stream)
-            self._prep_ev.record(self._prep_stream)
-            self._prep_fwd, self._prep_pending = self.fwd_id, True
-        self.fwd.run(stream_ptr(), 1)
+            if len(self.prep_u):
+                self.prep_u.run(self._prep_stream.cuda_stream)
+                self._u_ev.record(self._prep_stream)
+            if do_prep:
+                self.prep.run(self._prep_stream.cuda_stream)
+                self._prep_ev.record(self._prep_stream)
+                self._prep_fwd, self._prep_pending = self.fwd_id, True
+        if len(self.prep_u):
+            self.fwd.run(stream_ptr(), 1, self._first_wino, join=False)
+            torch.cuda.current_stream().wait_event(self._u_ev)
+            self.fwd.run(stream_ptr(), self._first_wino)
+        else:
+            self.fwd.run(stream_ptr(), 1)
         return self.out5.buf.view(B, self.A, 5).clone()
 
     def run_backward(self, g5: torch.Tensor):
@@ -1511,7 +1568,8 @@ class _Plan:
             lib.zsg_memset_f32(net.store.grad.data_ptr(), net.store.grad.numel(), 0.0, st)
             for n, p in zip(net._param_names, params):
                 p.grad = net.store.view(n, net.store.grad)
-        self.g5_in.view_as(g5).copy_(g5)
+        if g5.data_ptr() != self.g5_in.data_ptr():        # (the loss wrote it in place: see ZSGNet.forward)
+            self.g5_in.view_as(g5).copy_(g5)
         ddp = getattr(net, "_ddp", None)
         if self._prep_fwd == self.fwd_id:
             torch.cuda.current_stream().wait_event(self._prep_ev)

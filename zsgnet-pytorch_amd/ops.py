@@ -538,8 +538,9 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     else:
         ncols = d.seg[0].ty.n * d.seg[0].tx.n * d.C
         for bm in ((64, 128) if d.N > 64 else (64,)):
-            for bn in ((64, 128) if ncols > 64 else (64,)):
-                nmn = ((d.N + bm - 1) // bm) * ((ncols + bn - 1) // bn)
+            # (bn 255 = the 256-column tile of the 64-channel layers: every column from one block, dY read once)
+            for bn in (((64, 128) if ncols > 64 else (64,)) + ((255,) if (bm == 64 and d.N <= 64 and 128 < ncols <= 256 and d.out_ld % 4 == 0) else ())):
+                nmn = ((d.N + bm - 1) // bm) * ((ncols + (256 if bn == 255 else bn) - 1) // (256 if bn == 255 else bn))
                 seen = set()
                 for target in (256, 384, 512, 768, 1024, 2048):
                     sp = max(1, min(target // nmn, rows // 64, 255))
