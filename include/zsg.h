@@ -357,6 +357,11 @@ int zsg_iou(const float* boxes, const float* anchors, int32_t B, int32_t A, floa
  * ------------------------------------------------------------------------------------------------------------- */
 int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, int32_t* step_count, void* stream);
+/* The same step as several launches over disjoint ranges (pointers offset by the caller, 16-byte aligned): every launch computes with
+ * t = counter + 1; exactly the last one passes publish = 1.  Lets the update of the parameters whose gradients are complete overlap
+ * the tail of the backward (the stem's weight gradient). */
+int zsg_adam_step_range(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float grad_scale, int32_t* step_count, int32_t publish, void* stream);
 
 int zsg_memset_f32(float* p, int64_t n, float value, void* stream);
 

@@ -28,15 +28,16 @@ opt = optim.FusedAdam(net, lr=1e-4)
 bt = {{k: v.cuda() for k, v in O.synthetic_batch(3, 160, 128, seed=9).items()}}
 bt["h0"], bt["c0"] = torch.zeros(2, 3, 128), torch.zeros(2, 3, 128)
 res = {{}}
-for step in range(2):
+for step in range(4):
     opt.zero_grad()
     out = net(bt)
     ls = lf(out, bt)
     ls["loss"].backward()
-    torch.cuda.synchronize()
-    res[f"out{{step}}"] = out["att_bbx_out"].detach().cpu()
-    res[f"loss{{step}}"] = ls["loss"].detach().cpu()
-    res[f"grad{{step}}"] = net.store.grad.clone().cpu()
+    if step < 2:                  # (the last two steps run without any host synchronisation between backward and the optimizer:
+        torch.cuda.synchronize()  #  with ZSG_ADAM_OVERLAP=1 FusedAdam updates most parameters UNDER the backward's last weight gradients)
+        res[f"out{{step}}"] = out["att_bbx_out"].detach().cpu()
+        res[f"loss{{step}}"] = ls["loss"].detach().cpu()
+        res[f"grad{{step}}"] = net.store.grad.clone().cpu()
     opt.step()
 res["w"] = net.store.flat.clone().cpu()
 torch.save(res, sys.argv[1])
@@ -50,12 +51,13 @@ def test_two_processes_bit_identical(tmp_path):
     script.write_text(SCRIPT.format(root=ROOT))
     env = dict(os.environ, ZSG_DETERMINISTIC="1", ZSG_TUNE_CACHE=str(tmp_path / "tune.json"))
     outs = []
-    for i in range(2):
+    for i in range(3):            # the third process: the optimizer update split around the backward's tail (ZSG_ADAM_OVERLAP=1) — same bits
         out = tmp_path / f"r{i}.pt"
-        subprocess.run([sys.executable, str(script), str(out)], check=True, env=env, timeout=900)
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=dict(env, ZSG_ADAM_OVERLAP="1") if i == 2 else env, timeout=900)
         outs.append(torch.load(out))
     assert (tmp_path / "tune.json").exists(), "the first process must persist its tile choices"
-    a, b = outs
+    a, b, c = outs
     for k in a:
         assert torch.equal(a[k], b[k]), f"{k} differs between two deterministic runs (max |d| {float((a[k] - b[k]).abs().max()):.3g})"
+        assert torch.equal(a[k], c[k]), f"{k}: overlapped optimizer update differs from the joined one (max |d| {float((a[k] - c[k]).abs().max()):.3g})"
     assert torch.isfinite(a["grad1"]).all() and float(a["grad1"].abs().sum()) > 0

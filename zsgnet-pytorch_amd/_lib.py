@@ -114,6 +114,7 @@ SIGNATURES = {
     "zsg_eval": (I32, [P, P, P, P, I32, I32, F32, P, P, P, P, P, P, P]),
     "zsg_iou": (I32, [P, P, I32, I32, P, P]),
     "zsg_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, P]),
+    "zsg_adam_step_range": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, I32, P]),
     "zsg_memset_f32": (I32, [P, I64, F32, P]),
     "zsg_prof_enable": (I32, [I32]),
     "zsg_prof_collect": (I32, [C.POINTER(ProfEntry), I32]),

@@ -9,7 +9,7 @@ __device__ int g_adam_done;
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n4, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float gs, int* step) {
+                                                   float wd, float gs, int* step, int tick) {
     const int t = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const float bc1 = 1.f - powf(b1, (float)t);
     const float bc2s = sqrtf(1.f - powf(b2, (float)t));
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mm;
         v[i] = vv;
     }
+    if (!tick) return;          // (a partial update of the step: the launch that covers the rest publishes the counter)
     __syncthreads();
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(&g_adam_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
         __hip_atomic_store(&g_adam_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-extern "C" int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float grad_scale, int32_t* step_count, void* stream) {
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float grad_scale, int32_t* step_count, int tick, void* stream) {
     ZSG_REQUIRE(p && g && m && v && step_count && n > 0, "adam_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("adam_step", st, 0, (double)n * 28);
@@ -56,7 +57,20 @@ extern "C" int zsg_adam_step(float* p, const float* g, float* m, float* v, int64
     if (blocks > ZSG_NUM_CU * 8) blocks = ZSG_NUM_CU * 8;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, st, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, grad_scale,
-                       step_count);
+                       step_count, tick);
     ZSG_CHECK_LAUNCH("adam_step");
     return 0;
+}
+
+extern "C" int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_scale, int32_t* step_count, void* stream) {
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_count, 1, stream);
+}
+
+// One optimizer step as several launches over disjoint ranges of the flat buffer (so that the part whose gradients are complete can
+// be updated while the last weight gradients are still being computed): every launch of the step computes with t = counter + 1;
+// exactly the LAST one passes publish = 1 and advances the counter.
+extern "C" int zsg_adam_step_range(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, float grad_scale, int32_t* step_count, int32_t publish, void* stream) {
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_count, publish ? 1 : 0, stream);
 }

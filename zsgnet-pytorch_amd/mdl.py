@@ -82,6 +82,14 @@ def wg_batch() -> bool:
     return os.environ.get("ZSG_WG_BATCH", "0") == "1"
 
 
+def adam_overlap() -> bool:
+    """ZSG_ADAM_OVERLAP=1 (default OFF): with FusedAdam attached the backward does not join the side stream at its end; FusedAdam.step
+    updates every parameter behind the stem / first block under the side stream's last weight gradients and the rest after the join
+    (bit-identical: tests/test_gpu_determinism.py).  Measured in round 3: 14.30 vs 14.28 ms — the 2048-block HBM-bound update and the
+    stem's weight gradient do not overlap to any profit; off by default (the plain join has the simpler contract)."""
+    return os.environ.get("ZSG_ADAM_OVERLAP", "0") == "1"
+
+
 def bn_consumer_fuse() -> bool:
     """ZSG_BN_CONSUMER_FUSE=1 (read when a plan is lowered; default OFF).  Built and measured in round 3 (profiles/
     r03_prefuse_ab.txt): the fused loaders cost the consumer convolution 3-6 us (Winograd: the transform is redone by up to four
@@ -355,10 +363,20 @@ class ZSGNet(nn.Module):
             self.store.view("att_box.5.bias").fill_(-4.0)
             self.store.view("reg_box.5.bias").zero_()
 
+    def join_grads(self):
+        """After a backward with FusedAdam attached the main stream has not yet joined the side stream's last weight gradients
+        (FusedAdam.step does, after updating everything else under them): anything ELSE that reads or writes gradients on the
+        current stream joins here."""
+        ov = getattr(self, "_adam_overlap", None)
+        if ov is not None:
+            torch.cuda.current_stream().wait_stream(ov[1])
+            self._adam_overlap = None
+
     def join_weight_readers(self):
         """Called before anything WRITES the flat weight buffer on the current stream (optimizer step, load_state_dict):
         a training forward that was never back-propagated (metrics-only forward, discarded loss) leaves its backward weight
         preparation running on the side stream, reading the weights — make the current stream wait for it."""
+        self.join_grads()
         for plan in self._plans.values():
             if plan._prep_pending:
                 torch.cuda.current_stream().wait_event(plan._prep_ev)
@@ -465,6 +483,7 @@ class _Plan:
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
         self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
+        self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
@@ -480,16 +499,26 @@ class _Plan:
         self.fold_jobs, self.fold_used, self.fold_rows = [], 0, 0          # eval: BatchNorm folded into the convolutions
         self.fold_arena = self._buf(net.store.total + 8 * len(net.convs)) if (not training and net.bns) else None
         self.wino_jobs = {"fwd": WinoJobs(), "bwd": WinoJobs()}     # filter transforms of the Winograd convolutions (one launch each)
+        # work that depends on the weights only / touches buffers nobody reads yet: runs on the side stream at the start of a training
+        # forward (Winograd filter transforms, zero-fills of split-K outputs); the main stream waits for it right before the first
+        # launch that needs any of it (_wait_idx): an event WAIT, no marker of its own
+        self.prep_u, self._u_ev, self._wait_idx = Program("fwd-prep"), None, 1 << 30
+        self._side_prep = training and os.environ.get("ZSG_U_ON_SIDE", "1") != "0"
+        self._zero_calls = []
         self._lower()
+        for i, c in enumerate(self.fwd.calls):          # (positions after the hoisting of the language maps)
+            if any(c is z for z in self._zero_calls):
+                self._wait_idx = min(self._wait_idx, i)
+                break
         wj = self.wino_jobs["fwd"]
-        self.prep_u, self._u_ev, self._first_wino = Program("fwd-prep"), None, 0
-        if wj.jobs and training and os.environ.get("ZSG_U_ON_SIDE", "1") != "0":
+        if wj.jobs and self._side_prep:
             # U = G g G^T of every Winograd forward convolution depends on the weights only: in training it runs on the side stream
-            # while the main stream converts the image and runs the stem (it was 47 us at the head of the forward's dependent
-            # chain); the main stream waits for it (an event wait, no marker of its own) right before its first Winograd launch
+            # while the main stream converts the image and runs the stem (it was 47 us at the head of the forward's dependent chain)
             self.prep_u.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
+            self.prep_u.calls.insert(0, self.prep_u.calls.pop())          # (needed first)
+            self.prep_u.lanes.insert(0, self.prep_u.lanes.pop())
             wfns = (lib.zsg_conv_wino, lib.zsg_conv_wino_pre)
-            self._first_wino = next(i for i, c in enumerate(self.fwd.calls) if c[0] in wfns)
+            self._wait_idx = min(self._wait_idx, next(i for i, c in enumerate(self.fwd.calls) if c[0] in wfns))
         elif wj.jobs:        # eval (after the BatchNorm fold): first launch after the image conversion
             self.fwd.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
             self.fwd.calls.insert(1, self.fwd.calls.pop())
@@ -639,7 +668,17 @@ class _Plan:
                 chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
                 partials, out.bn_chunks = self._ws_now(), chunks
-        self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, None, None, partials, *tail, what=L.name + ("+pre" if pre else ""), lane=self._lane)
+        pre_zero = None
+        if self._side_prep and ((d.tile_hint >> 16) & 0xff) > 1 and len(out.levels) == 1:
+            # split-K: the K slices are added with atomics to a ZEROED output.  The zero-fill (a dependent ~6 us launch in front of the
+            # convolution when the library issues it) goes to the side-stream preparation instead — nobody reads this buffer between
+            # the previous step's backward and this launch — and the convolution is told to accumulate onto its own output.
+            lv0 = out.levels[0]
+            self.prep_u.add(lib.zsg_memset_f32, out.buf[lv0.off:], out.B * lv0.bstride, 0.0, what="zero:" + L.name)
+            pre_zero = out.buf
+        self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, pre_zero, None, partials, *tail, what=L.name + ("+pre" if pre else ""), lane=self._lane)
+        if pre_zero is not None:
+            self._zero_calls.append(self.fwd.calls[-1])
         out.bn_inline = out.bn_affine = None
         if partials is not None and bn_defer and bn_consumer_fuse():
             # finalize at once into mean / invstd AND the (scale | shift) pair the consumer convolution's loader applies
@@ -807,7 +846,10 @@ class _Plan:
         d = dgrad_desc(dy, dx, cred, n, L.k, L.stride, L.pad, L.dil)
         wt_off = row0 * L.k * L.k * cred
         if d.zero_fill and not dx.gfilled:      # stride-parity classes without taps get no launch: clear them
-            self.bwd.add(lib.zsg_memset_f32, self.base(dx), sum(dx.B * l.H * l.W * dx.ld for l in dx.levels), 0.0, what="zero:" + L.name)
+            # (a gradient buffer is idle from the previous step's optimizer update until this backward: with the side-stream
+            # preparation on, the fill runs there during the forward instead of on the backward's dependent chain)
+            (self.prep if self._side_prep else self.bwd).add(lib.zsg_memset_f32, self.base(dx), sum(dx.B * l.H * l.W * dx.ld for l in dx.levels), 0.0,
+                                                             what="zero:" + L.name)
             dx.gfilled = True
         mask = None
         if src.needs_mask:
@@ -825,6 +867,13 @@ class _Plan:
         # a split-K choice would cost the BatchNorm below its fused backward sums: a pass over dout and x plus a launch
         pen = (0.006 + 2 * dx.rows() * n * 4 / 4e9) if (completes_bn and BNB_FUSE and not d.zero_fill and mask is None) else 0.0
         autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), split_penalty_ms=pen, wino_args=wargs)
+        if self._side_prep and ((d.tile_hint >> 16) & 0xff) > 1 and args[4] is None and len(dx.levels) == 1:
+            # split-K into a gradient buffer nothing has written yet: its zero-fill moves to the side-stream preparation (see conv())
+            lv0 = dx.levels[0]
+            self.prep.add(lib.zsg_memset_f32, dx.buf[lv0.off:], dx.B * lv0.bstride, 0.0, what="zero:dgrad:" + L.name)
+            args = args[:4] + (dx.buf,) + args[5:]
+            if wargs is not None:
+                wargs = wargs[:4] + (dx.buf,) + wargs[5:]
         if d.use_wino:
             self.wino_jobs["bwd"].add(*job)
             self.bwd.add(lib.zsg_conv_wino, d, *wargs, what="dgrad:" + L.name)
@@ -1501,6 +1550,7 @@ class _Plan:
     def run_forward(self, img, qvec, qlens, h0, c0) -> torch.Tensor:
         net = self.net
         B = self.B
+        net.join_grads()
         img = img.contiguous()
         u8 = img.dtype == torch.uint8
         if not u8 and img.dtype != torch.float32:
@@ -1548,9 +1598,9 @@ class _Plan:
                 self._prep_ev.record(self._prep_stream)
                 self._prep_fwd, self._prep_pending = self.fwd_id, True
         if len(self.prep_u):
-            self.fwd.run(stream_ptr(), 1, self._first_wino, join=False)
+            self.fwd.run(stream_ptr(), 1, self._wait_idx, join=False)
             torch.cuda.current_stream().wait_event(self._u_ev)
-            self.fwd.run(stream_ptr(), self._first_wino)
+            self.fwd.run(stream_ptr(), self._wait_idx)
         else:
             self.fwd.run(stream_ptr(), 1)
         return self.out5.buf.view(B, self.A, 5).clone()
@@ -1596,7 +1646,48 @@ class _Plan:
             self.reducer.run(nb, lambda i, j: self.bwd.run(st, i, j, join=(j == nb)), side_stream=lambda: self.bwd._side)
             self.reducer.wait()
         else:
-            self.bwd.run(st)
+            cut = self._adam_cut() if (getattr(net, "_fused_opt", None) is not None and adam_overlap()) else None
+            if cut is None:
+                self.bwd.run(st)
+            else:
+                # FusedAdam is attached: the range up to i_cut completes every gradient behind flat offset `off` (all but the stem /
+                # first block, whose weight gradients are the tail of the side stream with nothing left to overlap them); the main
+                # stream does NOT join the side stream here — FusedAdam.step updates [off, end) behind an event recorded now, and
+                # [0, off) after the join (ZSGNet.join_grads is the join for anyone else)
+                i_cut, off = cut
+                self.bwd.run(st, 0, i_cut, graph=False, join=False)
+                if self.bwd._side is None:
+                    self.bwd.run(st, i_cut, len(self.bwd.calls), graph=False)
+                else:
+                    if self._adam_ev is None:
+                        self._adam_ev = torch.cuda.Event()
+                    self._adam_ev.record(self.bwd._side)
+                    self.bwd.run(st, i_cut, len(self.bwd.calls), graph=False, join=False)
+                    net._adam_overlap = (self._adam_ev, self.bwd._side, off)
+
+    def _adam_cut(self):
+        """(launch index, flat offset): the backward launches [0, index) complete the gradient of every parameter stored at or behind
+        `offset`; the parameters in front of it (the stem and the first block: first in the flat buffer, last in the backward) are what
+        the final ~dozen launches write.  None when the split is not worth it."""
+        if self._adam_cut_v is not False:
+            return self._adam_cut_v
+        from . import ops as _ops
+        self._adam_cut_v = None
+        ents, n = self.net.store.entries, len(self.bwd.calls)
+        if not _ops.SIDE_STREAM or _ops.HIP_GRAPH or n < 40:
+            return None
+        tail = [nm for nm in self.net._param_names if self.grad_ready.get(nm, -1) >= n - 12]
+        if not tail:
+            return None
+        off = max(ents[nm].offset + (ents[nm].size + 3) // 4 * 4 for nm in tail)
+        rest = [nm for nm in self.net._param_names if ents[nm].offset >= off]
+        if off > self.net.store.total // 4 or not rest:
+            return None
+        i_cut = max(self.grad_ready.get(nm, -1) for nm in rest) + 1
+        if i_cut > n - 4:
+            return None
+        self._adam_cut_v = (i_cut, off)
+        return self._adam_cut_v
 
 
 def map_pretrained_keys(net: "ZSGNet", sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

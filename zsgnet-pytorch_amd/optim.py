@@ -17,6 +17,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(flat)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=flat.device)
         self.grad_scale = grad_scale
+        # attached: a backward may leave its last weight gradients (the stem's) running on the side stream; step() updates everything
+        # else under them (mdl._Plan.run_backward / ZSGNet.join_grads)
+        net._fused_opt = self
 
     def zero_grad(self, set_to_none: bool = False):
         """One memset of the flat gradient buffer; the p.grad views stay (backward accumulates into them).  With
@@ -26,6 +29,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = None
             return
         st = self.net.store
+        self.net.join_grads()
         self.net._grad_reduced = False          # (DDP: one reduced backward per zero_grad, see _Plan.run_backward)
         if st.grad is not None and st.grad.is_cuda:
             check(lib.zsg_memset_f32(st.grad.data_ptr(), st.grad.numel(), 0.0, stream_ptr()), "zero_grad")
@@ -34,11 +38,24 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         g = self.param_groups[0]
         st = self.net.store
+        ov = getattr(self.net, "_adam_overlap", None)
+        self.net._adam_overlap = None
         self.net.join_weight_readers()          # (a forward without backward may still be reading the weights on the side stream)
-        check(lib.zsg_adam_step(st.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), st.flat.numel(),
-                                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                float(g["weight_decay"]), float(self.grad_scale), self.step_count.data_ptr(), stream_ptr()),
-              "zsg_adam_step")
+        hp = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(self.grad_scale))
+        if ov is not None:
+            # [off, end): gradients complete behind the event; [0, off) (stem / first block) after the side stream's last weight gradients
+            ev, side, off = ov
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            n = st.flat.numel()
+            check(lib.zsg_adam_step_range(st.flat.data_ptr() + 4 * off, st.grad.data_ptr() + 4 * off, self.m.data_ptr() + 4 * off,
+                                          self.v.data_ptr() + 4 * off, n - off, *hp, self.step_count.data_ptr(), 0, stream_ptr()), "zsg_adam_step_range")
+            cur.wait_stream(side)
+            check(lib.zsg_adam_step_range(st.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), off, *hp,
+                                          self.step_count.data_ptr(), 1, stream_ptr()), "zsg_adam_step_range")
+            return
+        check(lib.zsg_adam_step(st.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), st.flat.numel(), *hp,
+                                self.step_count.data_ptr(), stream_ptr()), "zsg_adam_step")
 
     def state_dict(self):
         d = super().state_dict()
