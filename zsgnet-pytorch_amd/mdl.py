@@ -583,7 +583,9 @@ class _Plan:
     def _wino_u(self, src_ptr: int, N: int, Cred: int, row_ld: int, tap_ld: int, flip: int):
         """Transformed filter image of one 3x3 convolution (+ a one-off transform so that the tuner times real data);
         the job joins the program's batched transform only if the Winograd kernel wins the tuning."""
-        U = self._buf(lib.zsg_wino_u_elems(Cred, N))
+        # (not a plan buffer: when the direct kernel wins the tuning nobody keeps a reference and the image is freed; a Winograd
+        # launch keeps it alive through its program's argument list.  The transform writes every element, padding included.)
+        U = torch.empty(int(lib.zsg_wino_u_elems(Cred, N)), dtype=torch.float32, device=self.dev)
         job = (src_ptr, U.data_ptr(), N, Cred, row_ld, tap_ld, flip)
         one = WinoJobs()
         one.add(*job)
@@ -755,6 +757,10 @@ class _Plan:
             self.wt[L.name] = self.wt_arena[off:off + n]
             e = self.net.store.entries[L.name + ".weight"]
             self.wt_jobs.append((e.offset, off, L.cout, L.k * L.k, L.cpad, cred))
+            # fill the image once now: the autotuner that follows times the data gradient (and the Winograd filter transform) on real
+            # weights, not on the arena's zeros (zero operands clock ~20 % higher: MI355X_MICROARCH.md, DVFS)
+            check(lib.zsg_transpose_w(self.net.store.flat.data_ptr() + 4 * e.offset, self.wt[L.name].data_ptr(), L.cout, L.k * L.k, L.cpad, cred,
+                                      stream_ptr()), "transpose_w")
         return self.wt[L.name]
 
     def _finish_prep(self):
