@@ -47,6 +47,7 @@ struct IgParams {
     int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
     int bk64;         // tile_hint bit 27: 64-deep K tiles
+    int pp;           // tile_hint bit 28: staggered K groups (64x64 8-wave tile)
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     IgSegDev seg[ZSG_MAX_SEG];
@@ -75,9 +76,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BK: K-tile depth.  32 = one barrier per 32 reduction elements; 64 halves the number of K steps — each step carries ~0.3-0.4 us
 // that no MFMA overlaps (address arithmetic, load issue, fragment-read latency, the barrier: tools/igemm_model.py, profiles/
 // r03_igemm_model_*.txt), which at one or two resident blocks per CU is 25-45 % of a step — at twice the LDS per block.
-template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK>
+//
+// PP ("staggered K groups", KS = 2 only): the two K groups of the 8-wave block run half a K tile out of phase.  While group 0 issues
+// its MFMAs on tile t, group 1 parks its share of tile t+1 in LDS, re-issues its global loads and reads its fragments of tile t;
+// after a barrier the roles swap.  A block that has the CU to itself serialises operand delivery (0.45 us per 64x64x32 tile at the
+// per-CU fetch cap) with MFMA issue (0.43 us) when all its waves walk the same phases (0.69 us per tile measured); staggered, each
+// SIMD always has one wave in the matrix pipe and one in the memory path.  Two barriers per K tile instead of one.
+template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams p) {
     static_assert(BK == 32 || (BK == 64 && !BX && !MERGE_X), "K tile depth");
+    static_assert(!PP || (KS == 2 && !BX && !PRE && !MERGE_X), "staggered K groups: the 8-wave two-group tile only");
     constexpr int LDR = BX ? 52 : BK + 4;     // floats per LDS tile row (an odd number of 16-byte units: conflict-free b128 fragment reads)
     constexpr int NT = 64 * WM * WN * KS;     // threads
     constexpr int KG = BK / 4;           // threads (16-byte groups) per tile row
@@ -356,6 +364,48 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         if (!(IG_ABL & 16)) __syncthreads();
     };
     in_loop = true;
+    if constexpr (PP) {
+        const int kgu = __builtin_amdgcn_readfirstlane(kg);       // (wave-uniform: the two groups take different paths through the step)
+        auto frag_mfma_read = [&](int it, f32x4 (&fa)[BK / 16], f32x4 (&fb)[BK / 16]) {
+            const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
+            const float* b = Bs + (it & 1) * BN * LDR + b_row * LDR + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int kq = kgu * (BK / 16) + kk;
+                fa[kk] = *(const f32x4*)(a + kq * 8);
+                fb[kk] = *(const f32x4*)(b + kq * 8);
+            }
+        };
+        auto mfmas = [&](const f32x4 (&fa)[BK / 16], const f32x4 (&fb)[BK / 16]) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][e], fb[kk][e], acc[0][0], 0, 0, 0);
+        };
+        static_assert(!PP || (TM == 1 && TN == 1), "staggered K groups: one 32x32 sub-tile per wave");
+        auto step_pp = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p) {
+            f32x4 fa[BK / 16], fb[BK / 16];
+            if (kgu == 0) {
+                frag_mfma_read(it, fa, fb);
+                mfmas(fa, fb);
+                __syncthreads();                                     // group 1 has parked its share of tile it+1 and holds its fragments
+                load_tile(nxt_a, nxt_b, nxt_p, it + NS < n_it);
+                store_tile((it + 1) & 1, cur_a, cur_b, cur_p);
+                __syncthreads();                                     // tile it+1 complete in LDS
+            } else {
+                load_tile(nxt_a, nxt_b, nxt_p, it + NS < n_it);
+                store_tile((it + 1) & 1, cur_a, cur_b, cur_p);
+                frag_mfma_read(it, fa, fb);
+                __syncthreads();
+                mfmas(fa, fb);
+                __syncthreads();
+            }
+        };
+        for (int it = 0; it < n_it; it += 2) {
+            step_pp(it, ra[0], rb[0], ps[0], ra[1], rb[1], ps[1]);
+            if (it + 1 < n_it) step_pp(it + 1, ra[1], rb[1], ps[1], ra[0], rb[0], ps[0]);
+        }
+    } else
     for (int it = 0; it < n_it; it += NS) {
 #pragma unroll
         for (int st = 0; st < NS; ++st)
@@ -611,17 +661,17 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE, int BK>
+template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE, int BK, bool PP = false>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     const size_t lds = (size_t)2 * (BM + BN) * (BX ? 52 : BK + 4) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;      // idempotent; a benign race sets it twice
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, PP>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
@@ -633,6 +683,13 @@ static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const cha
             static char nm[96];
             snprintf(nm, sizeof(nm), "%s+pre", kname);
             return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, true, IG_BK>(p, st, flops, nm);
+        }
+        if constexpr (!BX && KS == 2 && BM == 64 && BN == 64) {
+            if (p.pp && !p.bk64) {
+                static char nm[96];
+                snprintf(nm, sizeof(nm), "%s+pp", kname);
+                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK, true>(p, st, flops, nm);
+            }
         }
         if constexpr (!BX) {
             if (p.bk64) {
@@ -700,6 +757,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
         p.pre = src_affine;
     }
     p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x && !bx && !src_affine;
+    p.pp = ((d->tile_hint >> 28) & 1) && !d->merge_x && !bx && !src_affine && w8 && BM == 64 && BN == 64;
 
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
