@@ -112,6 +112,13 @@ CONV_CASES = [
     (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (1, 1024, 256, 19, 19, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (3, 160, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
+    # three-buffer ring (tile_hint bit 29): K of one / two / three / many tiles, every tile shape it exists for
+    (2, 32, 64, 16, 16, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 29)),
+    (2, 64, 256, 16, 16, 1, 1, 0, 1, True, True, False, 64 | (64 << 8) | (1 << 24) | (1 << 29)),
+    (2, 96, 128, 17, 15, 3, 1, 1, 1, True, True, False, 128 | (64 << 8) | (1 << 29)),
+    (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 128 | (64 << 8) | (1 << 24) | (1 << 29)),
+    (1, 1024, 256, 19, 19, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 29)),
+    (3, 160, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 29)),
 ]
 
 
@@ -145,8 +152,8 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
     assert_close(out.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, "conv fwd")
     if not bias and not relu:
         # fused BatchNorm statistics: per-tile (sum, sum^2) partials from the epilogue -> mean / invstd
-        for bm, bn_, w8, k64 in ((64, 64, 0, 0), (128, 64, 0, 0), (128, 128, 1, 0), (64, 64, 1, 1), (128, 64, 1, 1), (128, 128, 1, 1), (64, 64, 1, 2)):
-            if (bn_ == 128 and (Co <= 64 or mx)) or (k64 == 1 and (mx or cp % 64)) or (k64 == 2 and mx):
+        for bm, bn_, w8, k64 in ((64, 64, 0, 0), (128, 64, 0, 0), (128, 128, 1, 0), (64, 64, 1, 1), (128, 64, 1, 1), (128, 128, 1, 1), (64, 64, 1, 2), (64, 64, 0, 4), (128, 64, 1, 4)):
+            if (bn_ == 128 and (Co <= 64 or mx)) or (k64 == 1 and (mx or cp % 64)) or (k64 in (2, 4) and mx):
                 continue
             d4 = ops.fwd_desc(src, ov, cp, Co, k, s, p, d, wC=cp, merge_x=mx, tile_hint=ops.tile_hint(bm, bn_, 1, w8) | (k64 << 27))
             chunks = (B * Ho * Wo + bm - 1) // bm

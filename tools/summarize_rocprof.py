@@ -19,7 +19,7 @@ if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 
-DEFAULTS = {"igemm_kernel": [None] * 5 + ["1", "false", "false", "32"], "wino_kernel": [None] * 3 + ["false"],
+DEFAULTS = {"igemm_kernel": [None] * 5 + ["1", "false", "false", "32", "0"], "wino_kernel": [None] * 3 + ["false"],
             "wgrad_kernel": [None] * 5 + ["true"]}
 
 
@@ -37,6 +37,9 @@ def klass(name):
         if base == "igemm_kernel" and len(args) >= 9:
             suffix = ("+pre" if args[7] == "true" else "") + ("+k64" if args[8] == "64" else "")
             args[7], args[8] = "false", "32"
+            if len(args) >= 10:
+                suffix += {"1": "+pp", "2": "+r3"}.get(args[9], "")
+                args[9] = "0"
         if base == "wino_kernel" and len(args) >= 4:
             suffix = "+pre" if args[3] == "true" else ""
             args[3] = "false"

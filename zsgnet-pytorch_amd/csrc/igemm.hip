@@ -48,6 +48,7 @@ struct IgParams {
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
     int bk64;         // tile_hint bit 27: 64-deep K tiles
     int pp;           // tile_hint bit 28: staggered K groups (64x64 8-wave tile)
+    int r3;           // tile_hint bit 29: three-buffer LDS ring, fragments read one step ahead
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     IgSegDev seg[ZSG_MAX_SEG];
@@ -82,10 +83,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // after a barrier the roles swap.  A block that has the CU to itself serialises operand delivery (0.45 us per 64x64x32 tile at the
 // per-CU fetch cap) with MFMA issue (0.43 us) when all its waves walk the same phases (0.69 us per tile measured); staggered, each
 // SIMD always has one wave in the matrix pipe and one in the memory path.  Two barriers per K tile instead of one.
-template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK, bool PP = false>
+//
+// SCH = 2 ("ring"): THREE LDS tile buffers and double-buffered fragment registers.  In the lock-step schedule a K step is
+// barrier -> fragment ds_reads -> (LDS latency) -> MFMAs -> wait for the loads -> ds_write -> barrier: everything between the barrier
+// and the first MFMA (~0.35 us per step whatever the tile: profiles/r03_igemm_ablation.txt) is exposed when the block has the CU
+// to itself.  With tile t+1 already complete in the ring, the fragments of step t+1 are read WHILE step t's MFMAs issue, so after the
+// barrier the next MFMA chain starts from registers.
+template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK, int SCH = 0>
 __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams p) {
+    constexpr bool PP = SCH == 1;
+    constexpr bool R3 = SCH == 2;
+    constexpr int NB = R3 ? 3 : 2;           // LDS tile buffers
     static_assert(BK == 32 || (BK == 64 && !BX && !MERGE_X), "K tile depth");
     static_assert(!PP || (KS == 2 && !BX && !PRE && !MERGE_X), "staggered K groups: the 8-wave two-group tile only");
+    static_assert(!R3 || (!BX && !PRE && !MERGE_X && BK == 32), "ring schedule: fp32, 32-deep tiles");
     constexpr int LDR = BX ? 52 : BK + 4;     // floats per LDS tile row (an odd number of 16-byte units: conflict-free b128 fragment reads)
     constexpr int NT = 64 * WM * WN * KS;     // threads
     constexpr int KG = BK / 4;           // threads (16-byte groups) per tile row
@@ -96,9 +107,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     constexpr int TN = BN / WN / 32;
     static_assert(RA >= 1 && RB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                  // [2][BM][LDR]
-    float* Bs = smem + 2 * BM * LDR;                   // [2][BN][LDR]
-    int* rowout = (int*)(smem + 2 * (BM + BN) * LDR);  // [BM]
+    float* As = smem;                                  // [NB][BM][LDR]
+    float* Bs = smem + NB * BM * LDR;                  // [NB][BN][LDR]
+    int* rowout = (int*)(smem + NB * (BM + BN) * LDR); // [BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -364,7 +375,51 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
         if (!(IG_ABL & 16)) __syncthreads();
     };
     in_loop = true;
-    if constexpr (PP) {
+    if constexpr (R3) {
+        // ring schedule.  Invariant at the top of step t: tiles t and t+1 are complete in LDS[t % 3], LDS[(t+1) % 3]; register stage
+        // t & 1 holds tile t+2 (in flight); F[t & 1] holds this wave's fragments of tile t.
+        constexpr int NQ = BK / 8 / KS;
+        f32x4 Fa[2][NQ][TM], Fb[2][NQ][TN];
+        auto read_frags = [&](int t, f32x4 (&fa)[NQ][TM], f32x4 (&fb)[NQ][TN]) {
+            const int buf = t % 3;
+            const float* a = As + buf * BM * LDR + a_row * LDR + 4 * lh;
+            const float* b = Bs + buf * BN * LDR + b_row * LDR + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) {
+                const int kq = kg * NQ + kk;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[kk][j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
+            }
+        };
+        auto step_r3 = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p,
+                           f32x4 (&fa)[NQ][TM], f32x4 (&fb)[NQ][TN], f32x4 (&fa_n)[NQ][TM], f32x4 (&fb_n)[NQ][TN]) {
+            load_tile(nxt_a, nxt_b, nxt_p, it + 3 < n_it);              // tile it+3 -> the stage tile it+1 left last step
+            read_frags(it + 1, fa_n, fb_n);                             // in flight under this step's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
+            store_tile((it + 2) % 3, cur_a, cur_b, cur_p);               // tile it+2 (requested two steps ago)
+            __syncthreads();
+        };
+        // (the common prologue left tile 0 in LDS[0] and tile 1 in flight in stage 0, behind a barrier)
+        if (n_it > 0) {
+            store_tile(1, ra[0], rb[0], ps[0]);                          // tile 1 -> LDS[1]
+            load_tile(ra[0], rb[0], ps[0], n_it > 2);                    // tile 2 -> stage 0
+            __syncthreads();
+            read_frags(0, Fa[0], Fb[0]);
+        }
+        for (int it = 0; it < n_it; it += 2) {
+            step_r3(it, ra[0], rb[0], ps[0], ra[1], rb[1], ps[1], Fa[0], Fb[0], Fa[1], Fb[1]);
+            if (it + 1 < n_it) step_r3(it + 1, ra[1], rb[1], ps[1], ra[0], rb[0], ps[0], Fa[1], Fb[1], Fa[0], Fb[0]);
+        }
+    } else if constexpr (PP) {
         const int kgu = __builtin_amdgcn_readfirstlane(kg);       // (wave-uniform: the two groups take different paths through the step)
         auto frag_mfma_read = [&](int it, f32x4 (&fa)[BK / 16], f32x4 (&fb)[BK / 16]) {
             const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
@@ -661,17 +716,17 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE, int BK, bool PP = false>
+template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE, int BK, int SCH = 0>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
-    const size_t lds = (size_t)2 * (BM + BN) * (BX ? 52 : BK + 4) * sizeof(float) + BM * sizeof(int);
+    const size_t lds = (size_t)(SCH == 2 ? 3 : 2) * (BM + BN) * (BX ? 52 : BK + 4) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;      // idempotent; a benign race sets it twice
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, PP>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, SCH>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
@@ -688,7 +743,14 @@ static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const cha
             if (p.pp && !p.bk64) {
                 static char nm[96];
                 snprintf(nm, sizeof(nm), "%s+pp", kname);
-                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK, true>(p, st, flops, nm);
+                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK, 1>(p, st, flops, nm);
+            }
+        }
+        if constexpr (!BX && BM * BN <= 128 * 64) {
+            if (p.r3 && !p.bk64) {
+                static char nm[96];
+                snprintf(nm, sizeof(nm), "%s+r3", kname);
+                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK, 2>(p, st, flops, nm);
             }
         }
         if constexpr (!BX) {
@@ -758,6 +820,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     }
     p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x && !bx && !src_affine;
     p.pp = ((d->tile_hint >> 28) & 1) && !d->merge_x && !bx && !src_affine && w8 && BM == 64 && BN == 64;
+    p.r3 = ((d->tile_hint >> 29) & 1) && !d->merge_x && !bx && !src_affine && !p.pp && BM * BN <= 128 * 64;
 
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;

@@ -446,6 +446,7 @@ def wino_mode() -> str:
 BX_FLAG = 1 << 26            # tile_hint bit: the bf16x6 matrix path of the kernel
 K64_FLAG = 1 << 27           # tile_hint bit (igemm): 64-deep K tiles — half the K steps (barriers) at twice the LDS per block
 PP_FLAG = 1 << 28            # tile_hint bit (igemm, 64x64 8-wave tile): the two K groups run half a K tile out of phase
+R3_FLAG = 1 << 29            # tile_hint bit (igemm, tiles up to 128x64): three LDS tile buffers, fragments read one K step ahead
 
 
 def matrix_mode() -> str:
@@ -520,6 +521,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands.append(tile_hint(bm, bn, 1))
             if not d.merge_x and (bm == 128 or bn == 64):
                 cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup (64x64: two K groups)
+        if not d.merge_x and os.environ.get("ZSG_R3", "0") == "1":        # (measured round 3: 2-8 % slower than the two-buffer schedule)
+            cands += [tile_hint(bm, bn, 1, w8) | R3_FLAG for bm, bn in ((64, 64), (128, 64)) for w8 in (0, 1)]
         if not d.merge_x and os.environ.get("ZSG_PP", "0") == "1":        # (measured round 3: never faster than the lock-step variant)
             cands.append(tile_hint(64, 64, 1, 1) | PP_FLAG)
         if not d.merge_x and d.C % 64 == 0 and os.environ.get("ZSG_K64", "1") != "0":
