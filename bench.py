@@ -203,11 +203,18 @@ def main():
     fence()
     t0 = time.perf_counter()
     marks[0].record()
+    host_t = [t0]
     for i in range(a.steps):
         ls, em = step()
         marks[i + 1].record()               # (an event record is ~1 us of host time and no synchronisation)
+        host_t.append(time.perf_counter())
+    t_host = host_t[-1] - t0                # when the host had enqueued everything
     fence()
     dt = time.perf_counter() - t0
+    host = {"enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3), "lead_ms_at_end": round(1e3 * (dt - t_host), 3),
+            "first_steps_ms": [round(1e3 * (host_t[i + 1] - host_t[i]), 3) for i in range(min(4, a.steps))],
+            "what": "host time to enqueue one step (mean; the first steps after the fence, before the launch queues fill and throttle "
+                    "the host); how far ahead of the GPU the host was when it had enqueued the last timed step"}
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     median_ms = per_step[len(per_step) // 2]
     if world > 1:
@@ -377,7 +384,7 @@ def main():
         step_frac = (ips / world) * (3 * fwd_gf) * 1e9 / (PEAK_TF * 1e12) if fwd_gf else None
         out = {
             "metric": "train images/sec", "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 3), "median_ms_per_step": round(median_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "median_ms_per_step": round(median_ms, 3), "host": host, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (img~U[0,1), qvec~N(0,.35), random boxes; random-init weights)",
             "config": {"workload": f"ZSGNet train step, {a.arch + '+FPN' if a.backbone == 'retina' else 'SSD-VGG16'}, {a.img}x{a.img}, per-GPU bs={a.bs}, {a.tokens}-token queries "
                                    f"({config_label(a.arch, a.backbone, a.img, a.bs, world)})", "global_batch": a.bs * world,

@@ -1,5 +1,6 @@
 """Developer tool: overlap analysis of a rocprofv3 --kernel-trace CSV (one training step of the steady state).
-usage: python tools/trace_overlap.py <kernel_trace.csv> [step_index_from_end]
+usage: python tools/trace_overlap.py <kernel_trace.csv> [step_index_from_end] [--list]
+--list also prints every launch of the step in start order: queue, start offset, duration, idle time of its queue before it.
 Prints, for the chosen step: wall, GPU-busy union, time with >= 2 kernels in flight, time per kernel class while it runs ALONE."""
 import csv
 import re
@@ -25,11 +26,18 @@ def main():
     rows.sort()
     # steps are delimited by the adam kernel
     adam = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel")]
-    k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    k = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 2
     lo, hi = adam[-k - 1] + 1, adam[-k] + 1
     step = rows[lo:hi]
     t0, t1 = step[0][0], max(r[1] for r in step)
     print(f"step: {len(step)} launches, wall {(t1 - t0) / 1e3:.1f} us, queues {sorted(set(r[3] for r in step))}")
+    if "--list" in sys.argv:
+        qend, qs = {}, sorted(set(r[3] for r in step))
+        for s, e, n, q in step:
+            gap = (s - qend[q]) / 1e3 if q in qend else 0.0
+            qend[q] = e
+            short = re.sub(r"\(.*", "", n).replace("void ", "")[:70]
+            print(f"  q{qs.index(q)} +{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:7.1f} us  gap {gap:6.1f}  {short}")
     split = next(r[0] for r in step if "loss" in r[2])
     for name, a, b in (("forward", t0, split), ("backward+update", split, t1)):
         analyse(name, [r for r in step if a <= r[0] < b], a, b)

@@ -84,30 +84,74 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// Finalize: ONE WAVE per 4 channels — lane k sums partial rows k, k+64, ... with 16-byte loads (independent loads in flight,
-// fp64 accumulation), then a wave-level fp64 butterfly: no LDS, no barriers (the previous 8-channel x 32-lane block with an
-// LDS tree took 5.7 us per launch, most of it its five barriers; 106 such launches sit on the step's critical path).
+// Finalize: ONE BLOCK (BN_FW waves) per 4 channels.  Every lane issues all its row loads (BN_FU rows x 2 x 16 bytes) before it adds
+// anything — one memory round trip for up to 64 * BN_FW * BN_FU = 768 partial rows, i.e. every BatchNorm of the 300^2 network —
+// accumulates in fp64, then a transpose-reduce over the wave (xor 1 / 2 / 4 halve the value set: 8 + 4 + 2 + 1 + 3 exchanges
+// instead of 8 x 6) and ONE barrier for the BN_FW partial sums.  History (tools/ubench/bn_finalize.hip, launch after a producer
+// that rewrites the rows, 704 rows x 64 channels): 8-channel x 32-lane block with an LDS tree 5.7 us (five barriers); one wave per
+// 4 channels with `unroll 4` loads and full butterflies 6.2 us; this 3.2 us, against 2.4 us for an empty launch.  88 such
+// launches sit on the step's dependent chain.
 #define BN_FW 4                       // waves per block
-__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int chunks, int C, int c, double (&s)[4], double (&ss)[4]) {
-    const int lane = threadIdx.x & 63;
+#define BN_FU 3                       // rows in flight per lane
+__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int chunks, int C, int c, double& se, double& sse) {
+    __shared__ double red[BN_FW][8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = t; k0 < chunks; k0 += 64 * BN_FW * BN_FU) {
+        f32x4 a[BN_FU], b[BN_FU];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] = ss[e] = 0;
-    if (c < C) {
-#pragma unroll 4
-        for (int k = lane; k < chunks; k += 64) {
-            const f32x4 a = *(const f32x4*)(part + (size_t)k * 2 * C + c);
-            const f32x4 b = *(const f32x4*)(part + (size_t)k * 2 * C + C + c);
+        for (int u = 0; u < BN_FU; ++u) {
+            const int k = k0 + u * 64 * BN_FW;
+            const int kk = k < chunks ? k : chunks - 1;
+            a[u] = *(const f32x4*)(part + (size_t)kk * 2 * C + c);
+            b[u] = *(const f32x4*)(part + (size_t)kk * 2 * C + C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_FU; ++u) {
+            const bool ok = k0 + u * 64 * BN_FW < chunks;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s[e] += (double)a[e];
-                ss[e] += (double)b[e];
+                v[e] += ok ? (double)a[u][e] : 0.0;
+                v[4 + e] += ok ? (double)b[u][e] : 0.0;
             }
         }
     }
+    // after the exchange with lane ^ 1 / ^ 2 / ^ 4 a lane keeps half of its values, each summed with the partner's copy
+    double w4[4], w2[2], w1;
+    {
+        const bool hi = lane & 1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        s[e] = wave_sum_d(s[e]);
-        ss[e] = wave_sum_d(ss[e]);
+        for (int e = 0; e < 4; ++e) {
+            const double keep = hi ? v[4 + e] : v[e], give = hi ? v[e] : v[4 + e];
+            w4[e] = keep + __shfl_xor(give, 1, 64);
+        }
+    }
+    {
+        const bool hi = lane & 2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const double keep = hi ? w4[2 + e] : w4[e], give = hi ? w4[e] : w4[2 + e];
+            w2[e] = keep + __shfl_xor(give, 2, 64);
+        }
+    }
+    {
+        const bool hi = lane & 4;
+        const double keep = hi ? w2[1] : w2[0], give = hi ? w2[0] : w2[1];
+        w1 = keep + __shfl_xor(give, 4, 64);
+    }
+    // lane l holds value (l&1)*4 + ((l>>1)&1)*2 + ((l>>2)&1) of its 8-lane group: add the 8 groups, then the waves
+    w1 += __shfl_xor(w1, 8, 64);
+    w1 += __shfl_xor(w1, 16, 64);
+    w1 += __shfl_xor(w1, 32, 64);
+    if (lane < 8) red[wave][(lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1)] = w1;
+    __syncthreads();
+    se = sse = 0;
+    if (t < 4) {
+#pragma unroll
+        for (int w = 0; w < BN_FW; ++w) {
+            se += red[w][t];
+            sse += red[w][4 + t];
+        }
     }
 }
 
@@ -115,13 +159,11 @@ __global__ __launch_bounds__(64 * BN_FW) void bn_stats_finalize_kernel(const flo
                                                                        float* mean, float* invstd, float* rmean, float* rvar,
                                                                        float momentum, float eps, const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta, float* affine) {
-    const int c = (blockIdx.x * BN_FW + (threadIdx.x >> 6)) * 4;
-    double s[4], ss[4];
-    bn_reduce_partials(part, chunks, C, c, s, ss);
-    const int e = threadIdx.x & 63;
-    if (e >= 4 || c + e >= C) return;              // lanes 0..3 write one channel each
-    const double se = (e == 0) ? s[0] : ((e == 1) ? s[1] : ((e == 2) ? s[2] : s[3]));
-    const double sse = (e == 0) ? ss[0] : ((e == 1) ? ss[1] : ((e == 2) ? ss[2] : ss[3]));
+    const int c = blockIdx.x * 4;
+    double se, sse;
+    bn_reduce_partials(part, chunks, C, c, se, sse);
+    const int e = threadIdx.x;
+    if (e >= 4) return;                            // threads 0..3 write one channel each
     const double n = (double)rows;
     const double m = se / n;
     double var = sse / n - m * m;
@@ -201,13 +243,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // coef[0][c] = sum g / n ; coef[1][c] = sum g*xhat / n ; dgamma/dbeta written or accumulated.
 __global__ __launch_bounds__(64 * BN_FW) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
                                                                      float* coef, float* dgamma, float* dbeta, int accumulate) {
-    const int c = (blockIdx.x * BN_FW + (threadIdx.x >> 6)) * 4;
-    double s[4], ss[4];
-    bn_reduce_partials(part, chunks, C, c, s, ss);
-    const int e = threadIdx.x & 63;
-    if (e >= 4 || c + e >= C) return;
-    const double se = (e == 0) ? s[0] : ((e == 1) ? s[1] : ((e == 2) ? s[2] : s[3]));
-    const double sse = (e == 0) ? ss[0] : ((e == 1) ? ss[1] : ((e == 2) ? ss[2] : ss[3]));
+    const int c = blockIdx.x * 4;
+    double se, sse;
+    bn_reduce_partials(part, chunks, C, c, se, sse);
+    const int e = threadIdx.x;
+    if (e >= 4) return;
     coef[c + e] = (float)(se / (double)rows);
     coef[C + c + e] = (float)(sse / (double)rows);
     if (dbeta) dbeta[c + e] = (accumulate ? dbeta[c + e] : 0.f) + (float)se;
@@ -375,7 +415,7 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     float* part = (float*)ws;
     hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     ZSG_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -384,10 +424,10 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
 // Finalize only: the (sum, sum^2) partials were produced by the convolution's epilogue (zsg_conv_igemm bn_partials).
 extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
                                           float* running_mean, float* running_var, float momentum, float eps, void* stream) {
-    ZSG_REQUIRE(partials && mean && invstd && chunks > 0 && rows > 0 && C > 0, "bn_stats_from_partials: bad argument");
+    ZSG_REQUIRE(partials && mean && invstd && chunks > 0 && rows > 0 && C > 0 && (C % 4) == 0, "bn_stats_from_partials: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     ZSG_CHECK_LAUNCH("bn_stats_from_partials");
     return 0;
@@ -549,7 +589,7 @@ extern "C" int zsg_bn_affine_from_partials(const float* partials, int32_t chunks
                 "bn_affine_from_partials: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps, gamma, beta, affine);
     ZSG_CHECK_LAUNCH("bn_affine_from_partials");
     return 0;
@@ -598,7 +638,7 @@ extern "C" int zsg_bn_relu_maxpool_bwd(const float* dout, const uint8_t* idx, co
     float* coef = part + (size_t)gp.chunks * 2 * C;
     hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(gp.chunks, gp.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd,
                        gamma, beta, prow, gp.lanes, gp.rpb, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, part, gp.chunks, C, rows, coef, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, gp.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd, gamma,
                        beta, coef, rows, dx, g.lanes, g.rpb);
@@ -675,7 +715,7 @@ extern "C" int zsg_bn_backward_from_partials(const float* dout, const uint8_t* r
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * (2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.25 : 0)));
     float* coef = (float*)ws;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, coef, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, (const float*)nullptr, relu_mask, x, rows, C, mean,
                        invstd, gamma, coef, dx, g_out, g.lanes, g.rpb);
@@ -695,7 +735,7 @@ extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const u
     float* coef = part + (size_t)g.chunks * 2 * C;
     hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4 * BN_FW)), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
                        gamma, coef, dx, g_out, g.lanes, g.rpb);

@@ -82,6 +82,20 @@ def wg_batch() -> bool:
     return os.environ.get("ZSG_WG_BATCH", "0") == "1"
 
 
+def prep_late() -> bool:
+    """ZSG_PREP_LATE=1: the backward's weight images are enqueued on the side stream behind the forward's first side-stream launches
+    (query encoder, language maps, layer1's downsample branch) instead of in front of them."""
+    return os.environ.get("ZSG_PREP_LATE", "0") == "1"
+
+
+def side_after_stem() -> bool:
+    return os.environ.get("ZSG_SIDE_AFTER_STEM", "0") == "1"
+
+
+def prep_release_top() -> bool:
+    return os.environ.get("ZSG_PREP_RELEASE_TOP", "1") == "1"
+
+
 def adam_overlap() -> bool:
     """ZSG_ADAM_OVERLAP=1 (default OFF): with FusedAdam attached the backward does not join the side stream at its end; FusedAdam.step
     updates every parameter behind the stem / first block under the side stream's last weight gradients and the rest after the join
@@ -483,6 +497,7 @@ class _Plan:
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
         self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
+        self._rel_ev = torch.cuda.Event()
         self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
         self.bwd = Program("bwd")
@@ -1054,6 +1069,18 @@ class _Plan:
             del self.fwd.calls[i0:i1], self.fwd.lanes[i0:i1]
         self.fwd.calls[hoist_to:hoist_to] = moved_c      # ... and re-insert in their original order
         self.fwd.lanes[hoist_to:hoist_to] = moved_l
+        if self.training and side_after_stem():
+            # the head-of-program side-stream block (query encoder, language maps) goes BEHIND the stem's main-stream launches: its
+            # release is an event record on the main stream, and the stem convolution should not queue behind that marker
+            ln = self.fwd.lanes
+            j = next((i for i in range(1, len(ln)) if ln[i] == 0), None)
+            if j is not None and j > 1 and all(l == 1 for l in ln[1:j]):
+                k = j
+                while k < len(ln) and ln[k] == 0:
+                    k += 1
+                blk_c, blk_l = self.fwd.calls[1:j], ln[1:j]
+                self.fwd.calls[1:k] = self.fwd.calls[j:k] + blk_c
+                self.fwd.lanes[1:k] = ln[j:k] + blk_l
 
         # ---- backward program: replay the tape in reverse ----------------------------------------------------------
         if self.training:
@@ -1253,9 +1280,16 @@ class _Plan:
         p41 = self._upsample_add(t4, p51, "p41")
         with self.on_side_stream():
             p4 = self.conv(C[f + "P4_2"], p41, out=o4)
-        t3 = self.conv(C[f + "P3_1"], c3, name="t3")
-        p31 = self._upsample_add(t3, p41, "p31")
-        p3 = self.conv(C[f + "P3_2"], p31, out=o3, name="p3")
+        # (P3_1 / top-down add / the large P3_2 are lowered BEHIND the P6 -> P7 -> P8 chain: a side-stream launch waits for the main-stream
+        # work enqueued before it, so in program order behind P3_2 the chain only started when P3_2 had finished and the head's first
+        # convolution waited ~90 us for it; here it runs under P3_1 / P3_2)
+        def lower_p3():
+            t3 = self.conv(C[f + "P3_1"], c3, name="t3")
+            p31 = self._upsample_add(t3, p41, "p31")
+            return self.conv(C[f + "P3_2"], p31, out=o3, name="p3")
+        p6_first = os.environ.get("ZSG_FPN_P6_FIRST", "1") != "0"
+        if not p6_first:
+            p3 = lower_p3()
         side = self.on_side_stream()
         side.__enter__()
         p6 = self.conv(C[f + "P6"], c5, out=o6)
@@ -1273,13 +1307,14 @@ class _Plan:
         p7 = self.conv(C[f + "P7_2"], r6, out=o7)
         if net.six_hundred:
             side.__exit__(None, None, None)
+            if p6_first:
+                p3 = lower_p3()
             self._join_side()
             return [p4, p5, p6, p7]           # p3 is computed and dropped, as the reference does (fpn_resnet.py:173-174)
         l7 = p7.levels[0]
         p8 = o8
         self.fwd.add(lib.zsg_avgpool_fwd, self.base(p7), B, l7.H * l7.W, 256, self.base(p8), what="avgpool", lane=self._lane)
         side.__exit__(None, None, None)
-        self._join_side()
 
         def avg_back():
             if p8.grad is None:
@@ -1288,6 +1323,9 @@ class _Plan:
             self.bwd.add(lib.zsg_avgpool_bwd, self.base(p8.grad), B, l7.H * l7.W, 256, self.base(g), int(g.gfilled), what="avgpool_bwd")
             g.gfilled = True
         self.tape.append(avg_back)
+        if p6_first:
+            p3 = lower_p3()
+        self._join_side()
         return [p3, p4, p5, p6, p7, p8]
 
     def _upsample_add(self, a: Act, p: Act, name: str) -> Act:
@@ -1557,6 +1595,11 @@ class _Plan:
         net = self.net
         B = self.B
         net.join_grads()
+        rel = None
+        if prep_release_top() and self._prep_stream is not None:
+            # the side stream's weight preparation may start now (behind the optimizer step), not behind the input copies below
+            rel = self._rel_ev
+            rel.record(torch.cuda.current_stream())
         img = img.contiguous()
         u8 = img.dtype == torch.uint8
         if not u8 and img.dtype != torch.float32:
@@ -1595,16 +1638,26 @@ class _Plan:
             # their Winograd transforms) depend on the weights only: produced here on the side stream, under the forward
             if self._prep_stream is None:
                 self._prep_stream, self._prep_ev, self._u_ev = shared_side_stream(), torch.cuda.Event(), torch.cuda.Event()
-            self._prep_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step that wrote the weights
+            if rel is None:
+                self._prep_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step that wrote the weights
+            else:
+                self._prep_stream.wait_event(rel)
             if len(self.prep_u):
                 self.prep_u.run(self._prep_stream.cuda_stream)
                 self._u_ev.record(self._prep_stream)
+
+        def run_prep():
             if do_prep:
                 self.prep.run(self._prep_stream.cuda_stream)
                 self._prep_ev.record(self._prep_stream)
                 self._prep_fwd, self._prep_pending = self.fwd_id, True
+        late = prep_late() and len(self.prep_u) > 0
+        if not late:
+            run_prep()
         if len(self.prep_u):
             self.fwd.run(stream_ptr(), 1, self._wait_idx, join=False)
+            if late:
+                run_prep()         # (behind the forward's own side-stream launches of the first segment: needed in the backward only)
             torch.cuda.current_stream().wait_event(self._u_ev)
             self.fwd.run(stream_ptr(), self._wait_idx)
         else:
