@@ -366,6 +366,23 @@ int zsg_adam_step_range(float* p, const float* g, float* m, float* v, int64_t n,
 int zsg_memset_f32(float* p, int64_t n, float value, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Cross-stream ordering without marker packets (SURVEY 8b "Threading / streams": asynchronous launches on the passed stream, a
+ * dedicated side stream + hipEvents; the reference gets its concurrency from PyTorch's autograd / DDP reducer streams,
+ * main_dist.py:37-40, utils.py:407-414).  The weight gradients of the backward (and some leaves of the forward) run on a side
+ * stream; releasing them used to cost the main stream one hipEventRecord (a marker packet: ~4.3 us of main-stream time each, ~35
+ * per step).  Instead the caller arms an event for its thread, makes ONE libzsg call — every kernel that call launches carries the
+ * event as its dispatch packet's completion signal, the last launch wins — disarms it (NULL) and lets the other stream wait:
+ *     zsg_set_completion_event(ev); zsg_conv_igemm(..., main); zsg_set_completion_event(NULL); zsg_stream_wait_event(side, ev);
+ * Events are plain hipEvent_t (timing disabled) owned by the caller between create and destroy; zsg_event_record is the marker
+ * fallback for a release point that no libzsg launch precedes, or when the armed call launched nothing (zsg_set_completion_event
+ * returned 0 on disarming).  Thread-local arming: re-entrant across threads. */
+void* zsg_event_create(void);
+int zsg_event_destroy(void* ev);
+int zsg_set_completion_event(void* ev);     /* returns how many launches carried the event armed before this call (0: none did) */
+int zsg_event_record(void* ev, void* stream);
+int zsg_stream_wait_event(void* stream, void* ev);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Gradient exchange over RCCL (xGMI) — the NCCL collectives torch DistributedDataParallel issues for the reference
  * (main_dist.py:36-40, utils.py:395-414): C1 bucketed gradient all-reduce during backward, C2 BatchNorm-buffer
  * broadcast per training forward, C3 parameter broadcast at wrap time.  One process per GPU, one communicator per

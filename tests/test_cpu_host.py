@@ -326,3 +326,63 @@ def test_bench_self_launches_n_ranks_gloo():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out == {"launch_check": True, "n_gpus": 2, "backend": "gloo"}
+
+
+@pytest.mark.parametrize("name,defer", [("fwd", 0), ("bwd", 1)])
+def test_lane_schedule_orders_every_cross_stream_edge(name, defer, monkeypatch):
+    """ops.Program._schedule (the dry run behind the completion-event launcher): on random lane patterns every side-stream launch is
+    ordered behind the latest main-stream launch in front of it, every join behind every side-stream launch in front of it, and an
+    event is attached to a launch only if that launch is the latest of its stream (else a marker records it)."""
+    from zsgnet_pytorch_amd import ops
+    monkeypatch.setattr(ops, "SIDE_DEFER", defer)
+    rng = np.random.default_rng(7)
+    conv = ops._MAIN_CONVS[0]
+    for trial in range(60):
+        n = int(rng.integers(3, 60))
+        prog = ops.Program(name)
+        prog.side_batch = int(rng.integers(1, 4))
+        lanes = [int(v) for v in rng.choice([0, 0, 0, 1, 1, 2], size=n)]
+        prog.calls = [((conv if rng.random() < 0.5 else (lambda *a: 0)), (), f"c{i}") for i in range(n)]
+        prog.lanes = lanes
+        for join in (True, False):
+            for busy in (False, True):
+                sched, nev, busy_out = prog._schedule(0, n, join, busy)
+                # simulate two in-order streams
+                main_pos, side_pos = -1, -1          # program index of the latest launch issued on each stream (op order)
+                ev_main, ev_side = {}, {}            # event -> what it covers
+                side_sees_main, main_sees_side = -1, -1
+                issued = []
+                pre_side = busy                      # side-stream work of an earlier range is outstanding
+                for t, *rest in sched:
+                    if t == "m":
+                        i, k = rest
+                        assert lanes[i] != 1
+                        if lanes[i] == 2:            # a join launch: everything issued on the side stream so far is visible
+                            assert main_sees_side == side_pos and not pre_side, (trial, i)
+                        main_pos = i
+                        issued.append(i)
+                        if k >= 0:
+                            ev_main[k] = i
+                    elif t == "s":
+                        i, k = rest
+                        assert lanes[i] == 1
+                        assert side_sees_main == main_pos, (trial, i, side_sees_main, main_pos)
+                        side_pos = i
+                        issued.append(i)
+                        if k >= 0:
+                            ev_side[k] = i
+                    elif t == "rm":
+                        ev_main[rest[0]] = main_pos
+                    elif t == "rs":
+                        ev_side[rest[0]] = side_pos
+                        pre_side = False             # (a marker on the side stream also covers the earlier range's work)
+                    elif t == "ws":
+                        side_sees_main = max(side_sees_main, ev_main[rest[0]])
+                    elif t == "wm":
+                        main_sees_side = max(main_sees_side, ev_side[rest[0]])
+                        if ev_side[rest[0]] == side_pos and side_pos >= 0:
+                            pre_side = False         # in-order stream: its latest launch finishing implies everything before it
+                assert sorted(issued) == list(range(n))
+                if join:
+                    assert not busy_out and (side_pos < 0 or main_sees_side == side_pos) and not pre_side
+                assert nev == len(set(ev_main) | set(ev_side)) or nev >= len(ev_main) + len(ev_side)

@@ -31,6 +31,41 @@ for _ in range(12):
 torch.cuda.synchronize()
 plan = next(iter(net._plans.values()))
 for spec in sys.argv[1:]:
+    if spec == "tail":
+        # from the end of the backward's last main-stream launch to the point where the main stream has joined the side stream
+        # (the weight-gradient tail) and the optimizer's launch may start
+        prog = plan.bwd
+        last = max(i for i, l in enumerate(prog.lanes) if l != 1)
+        saved, marks, armed = prog.calls[last], [], [False]
+        fn0 = prog.calls[last][0]
+
+        def f(*args):
+            rc = fn0(*args)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append([e, None])
+            armed[0] = True
+            return rc
+        f.__name__ = fn0.__name__
+        prog.calls[last] = (f,) + prog.calls[last][1:]
+        jg = net.join_grads
+
+        def jg2():
+            jg()
+            if armed[0]:
+                armed[0] = False
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks[-1][1] = e
+        net.join_grads = jg2
+        for _ in range(40):
+            step()
+        torch.cuda.synchronize()
+        ts = sorted(x.elapsed_time(y) * 1e3 for x, y in marks[5:])
+        print(f"tail           [after {prog.calls[last][2]} .. side stream joined]  median {ts[len(ts) // 2]:8.1f} us   min {ts[0]:8.1f}   max {ts[-1]:8.1f}")
+        prog.calls[last] = saved
+        net.join_grads = jg
+        continue
     which, a, b = spec.split(":")
     a, b = int(a), int(b)
     prog = getattr(plan, which)

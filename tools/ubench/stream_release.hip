@@ -3,6 +3,7 @@
 // the 100 MHz constant clock, so the timeline is the GPU's, not the host's.
 // build: hipcc -O3 --offload-arch=gfx950 stream_release.hip -o stream_release
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -53,6 +54,40 @@ static void run_writer_case(const char* title, unsigned flags, int wgrid) {
     for (int i = 0; i < 4; ++i) printf("   %-24s start %8.1f us  end %8.1f us\n", nm[i], ((long long)h[2 * i] - (long long)t0) / 100.0, ((long long)h[2 * i + 1] - (long long)t0) / 100.0);
     printf("   => B starts %.1f us after A ends\n", ((long long)h[6] - (long long)h[1]) / 100.0);
     hipFree(big); hipFree(stamp); hipEventDestroy(ev);
+}
+
+// release WITHOUT a marker packet: A carries the event as its own completion signal (hipExtLaunchKernelGGL stopEvent), the side
+// stream waits for that; mode 0 = event record (marker), 1 = stop event on A, 2 = no release at all (reference)
+static void run_stopevent_case(const char* title, int mode, int n_pairs) {
+    unsigned long long* stamp;
+    hipMalloc(&stamp, 64 * 16);
+    hipEvent_t ev[16];
+    for (auto& e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    std::vector<unsigned long long> h(128);
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int i = 0; i < 64; ++i) { h[2 * i] = ~0ull; h[2 * i + 1] = 0; }
+        hipMemcpy(stamp, h.data(), 64 * 16, hipMemcpyHostToDevice);
+        hipDeviceSynchronize();
+        for (int i = 0; i < n_pairs; ++i) {          // main: A_i (30 us) [release] ; side: S_i (10 us, one block)
+            if (mode == 1)
+                hipExtLaunchKernelGGL(spin, dim3(256), dim3(256), 0, st[0], nullptr, ev[i], 0, stamp, 2 * i, 30L * 100);
+            else
+                hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, st[0], stamp, 2 * i, 30L * 100);
+            if (mode == 0) hipEventRecord(ev[i], st[0]);
+            if (mode != 2) hipStreamWaitEvent(st[1], ev[i], 0);
+            hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, st[1], stamp, 2 * i + 1, 10L * 100);
+        }
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(h.data(), stamp, 64 * 16, hipMemcpyDeviceToHost);
+    printf("%s\n", title);
+    double gap = 0, lat = 0;
+    for (int i = 1; i < n_pairs; ++i) gap += ((long long)h[2 * (2 * i)] - (long long)h[2 * (2 * i - 2) + 1]) / 100.0;
+    for (int i = 0; i < n_pairs; ++i) lat += ((long long)h[2 * (2 * i + 1)] - (long long)h[2 * (2 * i) + 1]) / 100.0;
+    printf("   main stream: A_i end -> A_i+1 start %.2f us (mean of %d);  side stream: S_i starts %.2f us after A_i ends;  whole chain %.1f us\n",
+           gap / (n_pairs - 1), n_pairs - 1, lat / n_pairs, ((long long)h[2 * (2 * n_pairs - 2) + 1] - (long long)h[0]) / 100.0);
+    hipFree(stamp);
+    for (auto& e : ev) hipEventDestroy(e);
 }
 
 struct K { const char* name; int stream; int grid, block; long us; bool memset_before; };
@@ -112,6 +147,9 @@ int main() {
              {{"A main", 0, 256, 256, 100, false}, {"S side", 1, 1, 64, 200, false}, {"B main", 0, 256, 256, 50, false}}, 0, false);
     run_case("7. B is a 1024-thread kernel, side: 512 blocks x 256 threads for 200 us",
              {{"A main", 0, 256, 256, 100, false}, {"S side", 1, 512, 256, 200, false}, {"B main", 0, 256, 1024, 50, false}}, 0, true);
+    run_stopevent_case("13. 12 x (main A 30 us -> release -> side S 10 us): release = hipEventRecord + hipStreamWaitEvent", 0, 12);
+    run_stopevent_case("14. same, release = A's own completion (hipExtLaunchKernelGGL stopEvent) + hipStreamWaitEvent", 1, 12);
+    run_stopevent_case("15. same, no release (independent streams)", 2, 12);
     run_writer_case("8. side stream is WRITING (2 GB in flight) while main records the event; event flags: DisableTiming", hipEventDisableTiming, 2048);
     run_writer_case("9. same, event flags: DisableTiming | ReleaseToDevice", hipEventDisableTiming | hipEventReleaseToDevice, 2048);
     run_writer_case("10. same, event flags: DisableTiming | DisableSystemFence", hipEventDisableTiming | hipEventDisableSystemFence, 2048);

@@ -116,6 +116,11 @@ SIGNATURES = {
     "zsg_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "zsg_adam_step_range": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, I32, P]),
     "zsg_memset_f32": (I32, [P, I64, F32, P]),
+    "zsg_event_create": (P, []),
+    "zsg_event_destroy": (I32, [P]),
+    "zsg_set_completion_event": (I32, [P]),
+    "zsg_event_record": (I32, [P, P]),
+    "zsg_stream_wait_event": (I32, [P, P]),
     "zsg_prof_enable": (I32, [I32]),
     "zsg_prof_collect": (I32, [C.POINTER(ProfEntry), I32]),
 }

@@ -56,7 +56,7 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > ZSG_NUM_CU * 8) blocks = ZSG_NUM_CU * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, st, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, grad_scale,
+    ZSG_LAUNCH(adam_kernel, dim3((int)blocks), dim3(256), 0, st, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, grad_scale,
                        step_count, tick);
     ZSG_CHECK_LAUNCH("adam_step");
     return 0;

@@ -25,6 +25,41 @@ extern "C" int zsg_set_deterministic(int32_t on) {
 extern "C" int zsg_version(void) { return ZSG_VERSION; }
 extern "C" const char* zsg_last_error(void) { return g_err; }
 
+// ---- cross-stream ordering without marker packets ----------------------------------------------------------------------
+thread_local hipEvent_t zsg_tls_completion_event = nullptr;
+thread_local int zsg_tls_completion_uses = 0;
+
+extern "C" void* zsg_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        zsg_set_error("event_create: %s", hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    return (void*)e;
+}
+extern "C" int zsg_event_destroy(void* ev) {
+    if (ev && hipEventDestroy((hipEvent_t)ev) != hipSuccess) ZSG_FAIL(-3, "event_destroy: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+extern "C" int zsg_set_completion_event(void* ev) {
+    const int used = zsg_tls_completion_uses;        // launches that carried the previously armed event
+    zsg_tls_completion_event = (hipEvent_t)ev;
+    zsg_tls_completion_uses = 0;
+    return used;
+}
+extern "C" int zsg_event_record(void* ev, void* stream) {
+    ZSG_REQUIRE(ev, "event_record: null event");
+    hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    if (e != hipSuccess) ZSG_FAIL(-3, "event_record: %s", hipGetErrorString(e));
+    return 0;
+}
+extern "C" int zsg_stream_wait_event(void* stream, void* ev) {
+    ZSG_REQUIRE(ev, "stream_wait_event: null event");
+    hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
+    if (e != hipSuccess) ZSG_FAIL(-3, "stream_wait_event: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // ---- profiler ----------------------------------------------------------------------------------------------------
 int g_zsg_prof_on = 0;
 struct ProfRec {

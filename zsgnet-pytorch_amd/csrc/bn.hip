@@ -399,7 +399,7 @@ extern "C" int zsg_bn_apply_from_partials(const float* x, int64_t rows, int32_t 
     BnGeom g = bn_geom(rows, C);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_apply", st, 0, (double)rows * C * (4 * (residual ? 3 : 2) + (relu_mask && relu ? 0.25 : 0)));
-    hipLaunchKernelGGL(bn_apply_inl_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, partials, chunks, gamma, beta, residual, relu,
+    ZSG_LAUNCH(bn_apply_inl_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, partials, chunks, gamma, beta, residual, relu,
                        out, relu_mask, mean, invstd, running_mean, running_var, momentum, eps, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_apply_from_partials");
     return 0;
@@ -413,9 +413,9 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)rows * C * 4);
     float* part = (float*)ws;
-    hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+    ZSG_LAUNCH((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
+    ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     ZSG_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -427,7 +427,7 @@ extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks,
     ZSG_REQUIRE(partials && mean && invstd && chunks > 0 && rows > 0 && C > 0 && (C % 4) == 0, "bn_stats_from_partials: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
+    ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     ZSG_CHECK_LAUNCH("bn_stats_from_partials");
     return 0;
@@ -589,7 +589,7 @@ extern "C" int zsg_bn_affine_from_partials(const float* partials, int32_t chunks
                 "bn_affine_from_partials: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
+    ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
                        running_mean, running_var, momentum, eps, gamma, beta, affine);
     ZSG_CHECK_LAUNCH("bn_affine_from_partials");
     return 0;
@@ -601,7 +601,7 @@ extern "C" int zsg_bn_apply_affine(const float* x, int64_t rows, int32_t C, cons
     BnGeom g = bn_geom(rows, C);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_apply", st, 0, (double)rows * C * (8 + (relu_mask && relu ? 0.25 : 0)));
-    hipLaunchKernelGGL(bn_apply_affine_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, affine, relu, out, relu_mask, g.lanes, g.rpb);
+    ZSG_LAUNCH(bn_apply_affine_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, affine, relu, out, relu_mask, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_apply_affine");
     return 0;
 }
@@ -616,7 +616,7 @@ extern "C" int zsg_bn_relu_maxpool_fwd(const float* x, int32_t B, int32_t H, int
     ZSG_PROF("bn_relu_maxpool_fwd", st, 0, ((double)B * H * W + (double)B * Ho * Wo * 1.25) * C * 4);
     int64_t blocks = (n + 255) / 256;
     if (blocks > ZSG_NUM_CU * 16) blocks = ZSG_NUM_CU * 16;
-    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((int)blocks), dim3(256), 0, st, x, B, H, W, C / 4, mean, invstd, gamma, beta, k, s, p, Ho, Wo,
+    ZSG_LAUNCH(bn_relu_maxpool_fwd_kernel, dim3((int)blocks), dim3(256), 0, st, x, B, H, W, C / 4, mean, invstd, gamma, beta, k, s, p, Ho, Wo,
                        out, idx);
     ZSG_CHECK_LAUNCH("bn_relu_maxpool_fwd");
     return 0;
@@ -636,11 +636,11 @@ extern "C" int zsg_bn_relu_maxpool_bwd(const float* dout, const uint8_t* idx, co
     ZSG_PROF("bn_backward", st, 0, ((double)prow * 2.25 + (double)rows * 2) * C * 4);
     float* part = (float*)ws;
     float* coef = part + (size_t)gp.chunks * 2 * C;
-    hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(gp.chunks, gp.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd,
+    ZSG_LAUNCH(bn_pool_bwd_partial_kernel, dim3(gp.chunks, gp.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd,
                        gamma, beta, prow, gp.lanes, gp.rpb, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, gp.chunks, C, rows, coef, dgamma, dbeta,
+    ZSG_LAUNCH(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, gp.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
-    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd, gamma,
+    ZSG_LAUNCH(bn_pool_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, idx, x, H, W, C, k, s, p, Ho, Wo, mean, invstd, gamma,
                        beta, coef, rows, dx, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_relu_maxpool_bwd");
     return 0;
@@ -675,7 +675,7 @@ extern "C" int zsg_bn_fold(const float* flat, const float* running_mean, const f
     ZSG_REQUIRE(flat && running_mean && running_var && jobs && arena && njobs > 0 && total_rows > 0, "bn_fold: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_fold", st, 0, 0);
-    hipLaunchKernelGGL(bn_fold_kernel, dim3(total_rows), dim3(256), 0, st, flat, running_mean, running_var, eps, (const ZsgFoldJob*)jobs, njobs,
+    ZSG_LAUNCH(bn_fold_kernel, dim3(total_rows), dim3(256), 0, st, flat, running_mean, running_var, eps, (const ZsgFoldJob*)jobs, njobs,
                        arena);
     ZSG_CHECK_LAUNCH("bn_fold");
     return 0;
@@ -684,7 +684,7 @@ extern "C" int zsg_bn_fold(const float* flat, const float* running_mean, const f
 extern "C" int zsg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                                  float* invstd, void* stream) {
     ZSG_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "bn_eval_stats: bad argument");
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean, running_var, C, eps,
+    ZSG_LAUNCH(bn_eval_stats_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean, running_var, C, eps,
                        mean, invstd);
     ZSG_CHECK_LAUNCH("bn_eval_stats");
     return 0;
@@ -696,7 +696,7 @@ extern "C" int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float
     BnGeom g = bn_geom(rows, C);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_apply", st, 0, (double)rows * C * (4 * (residual ? 3 : 2) + (relu_mask && relu ? 0.25 : 0)));
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, mean, invstd, gamma, beta, residual,
+    ZSG_LAUNCH(bn_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, mean, invstd, gamma, beta, residual,
                        relu, out, relu_mask, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_apply");
     return 0;
@@ -715,9 +715,9 @@ extern "C" int zsg_bn_backward_from_partials(const float* dout, const uint8_t* r
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * (2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.25 : 0)));
     float* coef = (float*)ws;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, coef, dgamma, dbeta,
+    ZSG_LAUNCH(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, (const float*)nullptr, relu_mask, x, rows, C, mean,
+    ZSG_LAUNCH(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, (const float*)nullptr, relu_mask, x, rows, C, mean,
                        invstd, gamma, coef, dx, g_out, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_backward_from_partials");
     return 0;
@@ -733,11 +733,11 @@ extern "C" int zsg_bn_backward(const float* dout, const float* relu_out, const u
     ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * ((relu_out && !relu_mask ? 3 : 2) * 2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.5 : 0)));
     float* part = (float*)ws;
     float* coef = part + (size_t)g.chunks * 2 * C;
-    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
+    ZSG_LAUNCH((bn_partial_kernel<1>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, dout, relu_out, relu_mask, mean, invstd,
                        rows, C, g.lanes, g.rpb, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
+    ZSG_LAUNCH(bn_bwd_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, coef, dgamma, dbeta,
                        accumulate);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
+    ZSG_LAUNCH(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, relu_out, relu_mask, x, rows, C, mean, invstd,
                        gamma, coef, dx, g_out, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_backward");
     return 0;

@@ -1,6 +1,7 @@
 // common.h — shared host/device helpers for libzsg (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -40,6 +41,23 @@ void zsg_set_error(const char* fmt, ...);
     do {                                                                                  \
         hipError_t e__ = hipGetLastError();                                               \
         if (e__ != hipSuccess) ZSG_FAIL(-3, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- kernel launches ------------------------------------------------------------------------------------------
+// Every kernel launch of libzsg goes through ZSG_LAUNCH.  When the calling thread has armed a completion event
+// (zsg_set_completion_event), the launch carries it as the dispatch packet's own completion signal (hipExtLaunchKernelGGL's stop
+// event): another stream can then wait for this launch with zsg_stream_wait_event WITHOUT an event-record marker packet in this
+// stream's queue (measured, tools/ubench/stream_release.hip: the next kernel of the releasing stream starts 3.4 us after this one
+// ends instead of 7.7 us behind a marker).  A call that launches several kernels re-arms the same event on each: the last wins.
+extern thread_local hipEvent_t zsg_tls_completion_event;
+extern thread_local int zsg_tls_completion_uses;
+#define ZSG_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                   \
+    do {                                                                                                                      \
+        if (zsg_tls_completion_event) {                                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, zsg_tls_completion_event, 0, __VA_ARGS__);      \
+            ++zsg_tls_completion_uses;                                                                                        \
+        } else                                                                                                                  \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                              \
     } while (0)
 
 // ---- per-launch profiling (prof.cpp) --------------------------------------------------------------------------

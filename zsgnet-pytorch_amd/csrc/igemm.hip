@@ -726,7 +726,7 @@ static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const ch
         attr_done = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, SCH>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    ZSG_LAUNCH((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, SCH>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }

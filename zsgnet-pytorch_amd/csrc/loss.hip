@@ -316,14 +316,14 @@ extern "C" int zsg_loss_fwd_bwd(const float* out5, const float* annot, const flo
     ArgMax* amax = (ArgMax*)(parts + (size_t)B * LS_CHUNKS);
     const bool chunked = !(flags & 4) && A >= 4 * LS_CHUNKS;      // softmax needs row-wide max / sum passes: one block per sample
     if (chunked) {
-        hipLaunchKernelGGL(loss_argmax_kernel, dim3(LS_CHUNKS, B), dim3(256), 0, st, annot, anchors, A, amax);
-        hipLaunchKernelGGL(loss_part_kernel, dim3(LS_CHUNKS, B), dim3(256), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags,
+        ZSG_LAUNCH(loss_argmax_kernel, dim3(LS_CHUNKS, B), dim3(256), 0, st, annot, anchors, A, amax);
+        ZSG_LAUNCH(loss_part_kernel, dim3(LS_CHUNKS, B), dim3(256), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags,
                            (const ArgMax*)amax, parts);
     } else {
-        hipLaunchKernelGGL(loss_stats_kernel, dim3(B), dim3(LS_THREADS), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags, rec);
+        ZSG_LAUNCH(loss_stats_kernel, dim3(B), dim3(LS_THREADS), 0, st, out5, annot, anchors, A, alpha, gamma, match_thr, flags, rec);
     }
     const int chunks = min(32, cdiv(A, 256));
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(chunks, B), dim3(256), 0, st, out5, annot, anchors, B, A, alpha, gamma, lamb_reg, match_thr,
+    ZSG_LAUNCH(loss_grad_kernel, dim3(chunks, B), dim3(256), 0, st, out5, annot, anchors, B, A, alpha, gamma, lamb_reg, match_thr,
                        flags, grad_scale, (const LossWs*)rec, chunked ? (const LossPart*)parts : (const LossPart*)nullptr, losses, grad5,
                        match_idx, npos);
     ZSG_CHECK_LAUNCH("loss_fwd_bwd");
@@ -415,8 +415,8 @@ extern "C" int zsg_eval(const float* out5, const float* annot, const float* anch
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("eval", st, 0, (double)B * A * 5 * 4);
     ArgMax* rec = (ArgMax*)ws_ok;                    // [B][EV_CHUNKS][2]
-    hipLaunchKernelGGL(eval_chunk_kernel, dim3(EV_CHUNKS, B), dim3(256), 0, st, out5, annot, anchors, A, rec);
-    hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(256), 0, st, out5, annot, anchors, img_size, B, A, acc_thr, (const ArgMax*)rec, metrics,
+    ZSG_LAUNCH(eval_chunk_kernel, dim3(EV_CHUNKS, B), dim3(256), 0, st, out5, annot, anchors, A, rec);
+    ZSG_LAUNCH(eval_finish_kernel, dim3(1), dim3(256), 0, st, out5, annot, anchors, img_size, B, A, acc_thr, (const ArgMax*)rec, metrics,
                        pred_boxes, pred_scores, pred_idx, best_idx);
     ZSG_CHECK_LAUNCH("eval");
     return 0;
@@ -430,7 +430,7 @@ __global__ void iou_kernel(const float* __restrict__ boxes, const float* __restr
 }
 extern "C" int zsg_iou(const float* boxes, const float* anchors, int32_t B, int32_t A, float* iou, void* stream) {
     ZSG_REQUIRE(boxes && anchors && iou && B > 0 && A > 0, "iou: bad argument");
-    hipLaunchKernelGGL(iou_kernel, dim3(cdiv((int64_t)B * A, 256)), dim3(256), 0, (hipStream_t)stream, boxes, anchors, B, A, iou);
+    ZSG_LAUNCH(iou_kernel, dim3(cdiv((int64_t)B * A, 256)), dim3(256), 0, (hipStream_t)stream, boxes, anchors, B, A, iou);
     ZSG_CHECK_LAUNCH("iou");
     return 0;
 }

@@ -136,7 +136,7 @@ __global__ void lstm_gather_last_kernel(const float* __restrict__ qvec, const fl
 
 extern "C" int zsg_lstm_gather_last(const float* qvec, const float* qlens, int32_t B, int32_t T, int32_t E, float* out, void* stream) {
     ZSG_REQUIRE(qvec && qlens && out && B > 0 && T > 0 && E > 0, "lstm_gather_last: bad argument");
-    hipLaunchKernelGGL(lstm_gather_last_kernel, dim3(cdiv((int64_t)B * E, 256)), dim3(256), 0, (hipStream_t)stream, qvec, qlens, B, T, E, out);
+    ZSG_LAUNCH(lstm_gather_last_kernel, dim3(cdiv((int64_t)B * E, 256)), dim3(256), 0, (hipStream_t)stream, qvec, qlens, B, T, E, out);
     ZSG_CHECK_LAUNCH("lstm_gather_last");
     return 0;
 }
@@ -148,7 +148,7 @@ extern "C" int zsg_lstm_fwd(const float* gin, const float* w_hh, const float* b_
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("lstm_fwd", st, 2.0 * B * T * 4 * H * H, 0);
 #define ZSG_LSTM_FWD(HH, REG)                                                                                                   \
-    hipLaunchKernelGGL((lstm_fwd_kernel<HH, REG>), dim3(B), dim3(4 * HH), 0, st, gin, w_hh, b_hh, h0, c0, qlens_rank, lens, B, T, \
+    ZSG_LAUNCH((lstm_fwd_kernel<HH, REG>), dim3(B), dim3(4 * HH), 0, st, gin, w_hh, b_hh, h0, c0, qlens_rank, lens, B, T, \
                        gates, cst, hprev, we, we_ld, we_off)
     if (H == 128) ZSG_LSTM_FWD(128, true);
     else if (H == 64) ZSG_LSTM_FWD(64, true);
@@ -167,7 +167,7 @@ extern "C" int zsg_lstm_bwd(const float* dwe, int32_t we_ld, int32_t we_off, con
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("lstm_bwd", st, 2.0 * B * T * 4 * H * H, 0);
 #define ZSG_LSTM_BWD(HH) \
-    hipLaunchKernelGGL((lstm_bwd_kernel<HH>), dim3(B), dim3(4 * HH), 0, st, dwe, we_ld, we_off, w_hh, gates, cst, c0, qlens_rank, lens, B, T, dgates)
+    ZSG_LAUNCH((lstm_bwd_kernel<HH>), dim3(B), dim3(4 * HH), 0, st, dwe, we_ld, we_off, w_hh, gates, cst, c0, qlens_rank, lens, B, T, dgates)
     if (H == 128) ZSG_LSTM_BWD(128);
     else if (H == 64) ZSG_LSTM_BWD(64);
     else if (H == 256) ZSG_LSTM_BWD(256);

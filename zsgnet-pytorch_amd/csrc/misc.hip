@@ -87,7 +87,7 @@ extern "C" int zsg_maxpool_fwd(const float* x, int32_t B, int32_t H, int32_t W, 
     const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("maxpool_fwd", st, 0, ((double)B * H * W + (double)B * Ho * Wo * 1.25) * C * 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, B, H, W, C / 4, k, s, p, Ho, Wo, out, idx);
+    ZSG_LAUNCH(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, B, H, W, C / 4, k, s, p, Ho, Wo, out, idx);
     ZSG_CHECK_LAUNCH("maxpool_fwd");
     return 0;
 }
@@ -98,7 +98,7 @@ extern "C" int zsg_maxpool_bwd(const float* dout, const uint8_t* idx, int32_t B,
     const int64_t n = (int64_t)B * H * W * (C / 4);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("maxpool_bwd", st, 0, ((double)B * H * W + (double)B * Ho * Wo * 1.25) * C * 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dout, idx, B, H, W, C / 4, k, s, p, Ho, Wo, dx);
+    ZSG_LAUNCH(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dout, idx, B, H, W, C / 4, k, s, p, Ho, Wo, dx);
     ZSG_CHECK_LAUNCH("maxpool_bwd");
     return 0;
 }
@@ -157,7 +157,7 @@ extern "C" int zsg_upsample_add_fwd(const float* a, const float* p, int32_t B, i
     const int64_t n = (int64_t)B * Hd * Wd * (C / 4);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("upsample_add_fwd", st, 0, (double)n * 16 * 2.25);
-    hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, p, B, Hs, Ws, Hd, Wd, C / 4,
+    ZSG_LAUNCH(upsample_add_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, p, B, Hs, Ws, Hd, Wd, C / 4,
                        (float)Hs / (float)Hd, (float)Ws / (float)Wd, out);
     ZSG_CHECK_LAUNCH("upsample_add_fwd");
     return 0;
@@ -169,7 +169,7 @@ extern "C" int zsg_upsample_add_bwd(const float* dout, int32_t B, int32_t Hs, in
     const int64_t n = (int64_t)B * Hs * Ws * (C / 4);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("upsample_add_bwd", st, 0, (double)B * Hd * Wd * C * 4 * 1.25);
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dout, B, Hs, Ws, Hd, Wd, C / 4,
+    ZSG_LAUNCH(upsample_add_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dout, B, Hs, Ws, Hd, Wd, C / 4,
                        (float)Hs / (float)Hd, (float)Ws / (float)Wd, dp, accumulate);
     ZSG_CHECK_LAUNCH("upsample_add_bwd");
     return 0;
@@ -196,13 +196,13 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dout, const float* __r
 }
 extern "C" int zsg_relu_fwd(const float* x, int64_t n, float* out, void* stream) {
     ZSG_REQUIRE(x && out && (n % 4) == 0, "relu_fwd: bad argument");
-    hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, out);
+    ZSG_LAUNCH(relu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, out);
     ZSG_CHECK_LAUNCH("relu_fwd");
     return 0;
 }
 extern "C" int zsg_relu_bwd(const float* dout, const float* x, int64_t n, float* dx, int32_t accumulate, void* stream) {
     ZSG_REQUIRE(dout && x && dx && (n % 4) == 0, "relu_bwd: bad argument");
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, x, n / 4, dx, accumulate);
+    ZSG_LAUNCH(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, x, n / 4, dx, accumulate);
     ZSG_CHECK_LAUNCH("relu_bwd");
     return 0;
 }
@@ -225,13 +225,13 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dout, int B, int HW
 }
 extern "C" int zsg_avgpool_fwd(const float* x, int32_t B, int32_t HW, int32_t C, float* out, void* stream) {
     ZSG_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "avgpool_fwd: bad argument");
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv((int64_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, B, HW, C, out);
+    ZSG_LAUNCH(avgpool_fwd_kernel, dim3(cdiv((int64_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, B, HW, C, out);
     ZSG_CHECK_LAUNCH("avgpool_fwd");
     return 0;
 }
 extern "C" int zsg_avgpool_bwd(const float* dout, int32_t B, int32_t HW, int32_t C, float* dx, int32_t accumulate, void* stream) {
     ZSG_REQUIRE(dout && dx && B > 0 && HW > 0 && C > 0, "avgpool_bwd: bad argument");
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cdiv((int64_t)B * HW * C, 256)), dim3(256), 0, (hipStream_t)stream, dout, B, HW, C, dx,
+    ZSG_LAUNCH(avgpool_bwd_kernel, dim3(cdiv((int64_t)B * HW * C, 256)), dim3(256), 0, (hipStream_t)stream, dout, B, HW, C, dx,
                        accumulate);
     ZSG_CHECK_LAUNCH("avgpool_bwd");
     return 0;
@@ -265,13 +265,13 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ dout, const float* _
 }
 extern "C" int zsg_l2norm_fwd(const float* x, int64_t rows, int32_t C, float* out, float* norm, void* stream) {
     ZSG_REQUIRE(x && out && norm && rows > 0 && C > 0, "l2norm_fwd: bad argument");
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, out, norm);
+    ZSG_LAUNCH(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, out, norm);
     ZSG_CHECK_LAUNCH("l2norm_fwd");
     return 0;
 }
 extern "C" int zsg_l2norm_bwd(const float* dout, const float* out, const float* norm, int64_t rows, int32_t C, float* dx, void* stream) {
     ZSG_REQUIRE(dout && out && norm && dx && rows > 0 && C > 0, "l2norm_bwd: bad argument");
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dout, out, norm, rows, C, dx);
+    ZSG_LAUNCH(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dout, out, norm, rows, C, dx);
     ZSG_CHECK_LAUNCH("l2norm_bwd");
     return 0;
 }
@@ -289,7 +289,7 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ img, int B, int C
 extern "C" int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t W, float* out, void* stream) {
     ZSG_REQUIRE(img && out && C >= 1 && C <= 4, "nchw_to_nhwc4: bad argument (C=%d)", C);
     const int64_t n = (int64_t)B * H * W;
-    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, img, B, C, H * W, out);
+    ZSG_LAUNCH(nchw_to_nhwc4_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, img, B, C, H * W, out);
     ZSG_CHECK_LAUNCH("nchw_to_nhwc4");
     return 0;
 }
@@ -307,7 +307,7 @@ extern "C" int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out
     ZSG_REQUIRE(img && out && pixels > 0, "u8hwc_to_nhwc4: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("u8hwc_to_nhwc4", st, 0, (double)pixels * 19);
-    hipLaunchKernelGGL(u8hwc_to_nhwc4_kernel, dim3(grid_for(pixels)), dim3(256), 0, st, img, pixels, out);
+    ZSG_LAUNCH(u8hwc_to_nhwc4_kernel, dim3(grid_for(pixels)), dim3(256), 0, st, img, pixels, out);
     ZSG_CHECK_LAUNCH("u8hwc_to_nhwc4");
     return 0;
 }
@@ -332,7 +332,7 @@ extern "C" int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t 
     ZSG_REQUIRE(src && dst && N > 0 && T > 0 && C > 0 && dst_ld >= N, "transpose_w: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("transpose_w", st, 0, (double)N * T * C * 8);
-    hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(C, 32), cdiv(dst_ld, 32), T), dim3(256), 0, st, src, dst, N, T, C, dst_ld);
+    ZSG_LAUNCH(transpose_w_kernel, dim3(cdiv(C, 32), cdiv(dst_ld, 32), T), dim3(256), 0, st, src, dst, N, T, C, dst_ld);
     ZSG_CHECK_LAUNCH("transpose_w");
     return 0;
 }
@@ -376,7 +376,7 @@ extern "C" int zsg_transpose_w_batched(const float* src_base, float* dst_base, c
     ZSG_REQUIRE(src_base && dst_base && jobs && njobs > 0 && total_tiles > 0, "transpose_w_batched: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("transpose_w", st, 0, 0);
-    hipLaunchKernelGGL(transpose_w_batched_kernel, dim3(total_tiles), dim3(256), 0, st, src_base, dst_base, (const ZsgTransposeJob*)jobs, njobs);
+    ZSG_LAUNCH(transpose_w_batched_kernel, dim3(total_tiles), dim3(256), 0, st, src_base, dst_base, (const ZsgTransposeJob*)jobs, njobs);
     ZSG_CHECK_LAUNCH("transpose_w_batched");
     return 0;
 }
@@ -434,19 +434,24 @@ __global__ void colsum4_kernel(const float* __restrict__ x, int64_t gstride, int
         for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, s[e]);
     }
 }
-__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    // 16-byte stores over the aligned body, scalar head / tail
+    const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)p & 15)) & 15) / 4);
+    const int64_t n4 = (n - head) / 4;
+    f32x4* q = (f32x4*)(p + head);
+    const f32x4 v4 = {v, v, v, v};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) q[i] = v4;
+    if (blockIdx.x == 0) {
+        for (int64_t i = threadIdx.x; i < head; i += blockDim.x) p[i] = v;
+        for (int64_t i = head + n4 * 4 + threadIdx.x; i < n; i += blockDim.x) p[i] = v;
+    }
 }
 extern "C" int zsg_memset_f32(float* p, int64_t n, float value, void* stream) {
     ZSG_REQUIRE(p || n == 0, "memset_f32: null");
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (value == 0.f) {
-        hipError_t e = hipMemsetAsync(p, 0, (size_t)n * 4, st);
-        if (e != hipSuccess) ZSG_FAIL(-3, "memset_f32: %s", hipGetErrorString(e));
-        return 0;
-    }
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, n, value);
+    // (a kernel, not hipMemsetAsync: the runtime's fill brings a ~6.5 us marker gap into the stream and cannot carry a completion event)
+    ZSG_LAUNCH(fill_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, p, n, value);
     ZSG_CHECK_LAUNCH("memset_f32");
     return 0;
 }
@@ -472,11 +477,11 @@ extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32
         }
         const int rpb4 = cdiv(rows, sp);
         if (g_zsg_deterministic) {
-            hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(c4, CLd), 1, groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CLd);
+            ZSG_LAUNCH(colsum4_kernel, dim3(cdiv(c4, CLd), 1, groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CLd);
             ZSG_CHECK_LAUNCH("colsum");
             return 0;
         }
-        hipLaunchKernelGGL(colsum4_kernel, dim3(cb4, cdiv(rows, rpb4), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CL);
+        ZSG_LAUNCH(colsum4_kernel, dim3(cb4, cdiv(rows, rpb4), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb4, CL);
         ZSG_CHECK_LAUNCH("colsum");
         return 0;
     }
@@ -485,7 +490,7 @@ extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32
     while (splits > 1 && (int64_t)splits * cb * groups > 2048) splits = (splits + 1) / 2;
     if (g_zsg_deterministic) splits = 1;
     const int rpb = cdiv(rows, splits);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cb, cdiv(rows, rpb), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb);
+    ZSG_LAUNCH(colsum_kernel, dim3(cb, cdiv(rows, rpb), groups), dim3(256), 0, st, x, gstride, rows, ld, c0, C, out, rpb);
     ZSG_CHECK_LAUNCH("colsum");
     return 0;
 }
@@ -501,7 +506,7 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, int64_t rows, int
 }
 extern "C" int zsg_pad_rows(const float* src, int64_t rows, int32_t C, int32_t src_ld, float* dst, int32_t dst_ld, void* stream) {
     ZSG_REQUIRE(src && dst && rows > 0 && C > 0 && dst_ld >= C && src_ld >= C, "pad_rows: bad argument");
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(rows * dst_ld)), dim3(256), 0, (hipStream_t)stream, src, rows, C, src_ld, dst, dst_ld);
+    ZSG_LAUNCH(pad_rows_kernel, dim3(grid_for(rows * dst_ld)), dim3(256), 0, (hipStream_t)stream, src, rows, C, src_ld, dst, dst_ld);
     ZSG_CHECK_LAUNCH("pad_rows");
     return 0;
 }
@@ -525,7 +530,7 @@ extern "C" int zsg_interleave(float* compact, int64_t rows, int32_t groups, int3
     ZSG_REQUIRE(compact && strided && rows > 0 && groups > 0 && k > 0 && offset >= 0 && offset + k <= group_stride, "interleave: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("interleave", st, 0, (double)rows * groups * k * 8);
-    hipLaunchKernelGGL(interleave_kernel, dim3(grid_for(rows * groups * k)), dim3(256), 0, st, compact, rows, groups, k, strided, group_stride,
+    ZSG_LAUNCH(interleave_kernel, dim3(grid_for(rows * groups * k)), dim3(256), 0, st, compact, rows, groups, k, strided, group_stride,
                        offset, dir);
     ZSG_CHECK_LAUNCH("interleave");
     return 0;
@@ -571,7 +576,7 @@ extern "C" int zsg_head_lang_map(const float* V, const float* G, int32_t B, int3
     const int64_t n = (int64_t)B * h * w * (N / 4);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("head_lang_map", st, 0, (double)B * h * w * N * 4);
-    hipLaunchKernelGGL(head_lang_map_kernel, dim3(grid_for(n)), dim3(256), 0, st, V, G, B, h, w, N, out);
+    ZSG_LAUNCH(head_lang_map_kernel, dim3(grid_for(n)), dim3(256), 0, st, V, G, B, h, w, N, out);
     ZSG_CHECK_LAUNCH("head_lang_map");
     return 0;
 }
@@ -647,8 +652,8 @@ extern "C" int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32
     if (sp > 32) sp = 32;
     if (g_zsg_deterministic) sp = 1;                          // one block per (image, column group): one add per element
     const int rpb = cdiv(rows, sp);
-    hipLaunchKernelGGL(head_image_sums_kernel, dim3(cdiv(c4, CL), cdiv(rows, rpb), B), dim3(256), 0, st, dy, rows, N, rpb, Q, CL);
-    hipLaunchKernelGGL(head_border_lines_kernel, dim3(B, 4), dim3(256), 0, st, dy, B, h, w, N, Q);
+    ZSG_LAUNCH(head_image_sums_kernel, dim3(cdiv(c4, CL), cdiv(rows, rpb), B), dim3(256), 0, st, dy, rows, N, rpb, Q, CL);
+    ZSG_LAUNCH(head_border_lines_kernel, dim3(B, 4), dim3(256), 0, st, dy, B, h, w, N, Q);
     ZSG_CHECK_LAUNCH("head_border_sums");
     return 0;
 }
@@ -682,7 +687,7 @@ __global__ void head_border_finalize_kernel(const float* __restrict__ Q, int B, 
 }
 extern "C" int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad, void* stream) {
     ZSG_REQUIRE(Q && S1 && S2 && B > 0 && N > 0, "head_border_finalize: bad argument");
-    hipLaunchKernelGGL(head_border_finalize_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, (hipStream_t)stream, Q, B, N, S1, S2, bias_grad);
+    ZSG_LAUNCH(head_border_finalize_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, (hipStream_t)stream, Q, B, N, S1, S2, bias_grad);
     ZSG_CHECK_LAUNCH("head_border_finalize");
     return 0;
 }
@@ -698,7 +703,7 @@ extern "C" int zsg_batch_sum(const float* x, int32_t B, int64_t stride, float* o
     ZSG_REQUIRE(x && out && B > 0 && stride > 0 && (stride % 4) == 0, "batch_sum: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("batch_sum", st, 0, (double)B * stride * 4);
-    hipLaunchKernelGGL(batch_sum_kernel, dim3(grid_for(stride / 4)), dim3(256), 0, st, x, B, stride / 4, out);
+    ZSG_LAUNCH(batch_sum_kernel, dim3(grid_for(stride / 4)), dim3(256), 0, st, x, B, stride / 4, out);
     ZSG_CHECK_LAUNCH("batch_sum");
     return 0;
 }

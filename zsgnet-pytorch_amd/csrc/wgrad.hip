@@ -87,7 +87,7 @@ void wg_reduce_job_fill(WgReduceJob& j, const zsg_conv_desc* d, const float* ws,
 
 int wg_reduce_launch(const WgReduceJob& j, hipStream_t st) {
     ZSG_PROF("wgrad_reduce_kernel", st, 0, (double)(j.splits + 1) * j.N * j.ncols * 4);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wg_reduce_blocks(j.N, j.ncols, j.kl)), dim3(256), 0, st, j);
+    ZSG_LAUNCH(wgrad_reduce_kernel, dim3(wg_reduce_blocks(j.N, j.ncols, j.kl)), dim3(256), 0, st, j);
     return 0;
 }
 
@@ -376,7 +376,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
             attr_done = true;                                                                                              \
         }                                                                                                                  \
         ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, 0);                        \
-        hipLaunchKernelGGL((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>), grid, dim3(64 * WM_ * WN_), lds, st, p);           \
+        ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>), grid, dim3(64 * WM_ * WN_), lds, st, p);           \
     } while (0)
     if (!avec) {                                      // dY rows not 16-byte addressable: the one scalar-load variant
         WG_LAUNCH_A(1, 1, 16, 2, 2, false);
@@ -441,7 +441,7 @@ extern "C" int zsg_wgrad_reduce_batched(const void* jobs_dev, int32_t njobs, int
     ZSG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "wgrad_reduce_batched: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("wgrad_reduce_kernel", st, 0, total_bytes);
-    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, st, (const WgReduceJob*)jobs_dev, njobs);
+    ZSG_LAUNCH(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, st, (const WgReduceJob*)jobs_dev, njobs);
     ZSG_CHECK_LAUNCH("wgrad_reduce_batched");
     return 0;
 }

@@ -521,7 +521,7 @@ extern "C" int zsg_wino_weights(const void* jobs_dev, int32_t njobs, int32_t tot
     ZSG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "wino_weights: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("wino_weight_kernel", st, 0, 0);
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(total_blocks), dim3(256), 0, st, (const WnWJob*)jobs_dev, njobs);
+    ZSG_LAUNCH(wino_weight_kernel, dim3(total_blocks), dim3(256), 0, st, (const WnWJob*)jobs_dev, njobs);
     ZSG_CHECK_LAUNCH("wino_weights");
     return 0;
 }
@@ -543,7 +543,7 @@ static int wino_launch1(const WnParams& p, hipStream_t st, double flops, const c
         attr_lds = lds;
     }
     ZSG_PROF(kname, st, flops, 0);
-    hipLaunchKernelGGL((wino_kernel<TM, TN, PS, PRE>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
+    ZSG_LAUNCH((wino_kernel<TM, TN, PS, PRE>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_wino");
     return 0;
 }

@@ -315,7 +315,7 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
     }
     {
         ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, 0);
-        hipLaunchKernelGGL(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
+        ZSG_LAUNCH(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
     }
     if (n_slabs) {
         *n_slabs = p.splits;       // the caller reduces (zsg_wgrad_reduce_batched)

@@ -82,14 +82,17 @@ def wg_batch() -> bool:
     return os.environ.get("ZSG_WG_BATCH", "0") == "1"
 
 
-def prep_late() -> bool:
-    """ZSG_PREP_LATE=1: the backward's weight images are enqueued on the side stream behind the forward's first side-stream launches
-    (query encoder, language maps, layer1's downsample branch) instead of in front of them."""
-    return os.environ.get("ZSG_PREP_LATE", "0") == "1"
+def prep_at() -> str:
+    """ZSG_PREP_AT: where the backward's weight images are enqueued on the side stream during the forward (see _Plan._prep_index)."""
+    return os.environ.get("ZSG_PREP_AT", "j2")
 
 
-def side_after_stem() -> bool:
-    return os.environ.get("ZSG_SIDE_AFTER_STEM", "0") == "1"
+def side_after_stem() -> int:
+    """ZSG_SIDE_AFTER_STEM: 0 = the query encoder / language maps head the forward program's side-stream work; 1 = they are released
+    behind the stem; 2 = behind the stem AND layer1.0's downsample branch (which the main stream joins ~0.3 ms later, while the head
+    reads the language maps ~4 ms later); 3 = behind the main stream's first join with the side stream (layer1.0's residual add: a join
+    waits for everything on the side stream, so in front of it the query encoder's ~0.25 ms delayed that join by ~50-190 us)."""
+    return int(os.environ.get("ZSG_SIDE_AFTER_STEM", "0"))
 
 
 def prep_release_top() -> bool:
@@ -498,6 +501,7 @@ class _Plan:
         self.prep = Program("bwd-prep")
         self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
         self._rel_ev = torch.cuda.Event()
+        self._prep_idx_v = False
         self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
         self.bwd = Program("bwd")
@@ -1078,6 +1082,11 @@ class _Plan:
                 k = j
                 while k < len(ln) and ln[k] == 0:
                     k += 1
+                if side_after_stem() == 2:       # ... and behind the first residual block's downsample branch (joined much sooner)
+                    while k < len(ln) and ln[k] == 1:
+                        k += 1
+                elif side_after_stem() == 3:     # ... behind the main stream's first join (a join waits for the WHOLE side stream)
+                    k = next((i + 1 for i in range(j, len(ln)) if ln[i] == 2), k)
                 blk_c, blk_l = self.fwd.calls[1:j], ln[1:j]
                 self.fwd.calls[1:k] = self.fwd.calls[j:k] + blk_c
                 self.fwd.lanes[1:k] = ln[j:k] + blk_l
@@ -1651,18 +1660,44 @@ class _Plan:
                 self.prep.run(self._prep_stream.cuda_stream)
                 self._prep_ev.record(self._prep_stream)
                 self._prep_fwd, self._prep_pending = self.fwd_id, True
-        late = prep_late() and len(self.prep_u) > 0
-        if not late:
-            run_prep()
+        # cut points of the forward program: (launch index, action enqueued in front of that launch)
+        cuts = []
         if len(self.prep_u):
-            self.fwd.run(stream_ptr(), 1, self._wait_idx, join=False)
-            if late:
-                run_prep()         # (behind the forward's own side-stream launches of the first segment: needed in the backward only)
-            torch.cuda.current_stream().wait_event(self._u_ev)
-            self.fwd.run(stream_ptr(), self._wait_idx)
-        else:
-            self.fwd.run(stream_ptr(), 1)
+            cuts.append((self._wait_idx, lambda: torch.cuda.current_stream().wait_event(self._u_ev)))
+        k_prep = self._prep_index() if do_prep else None
+        if do_prep and k_prep is None:
+            run_prep()             # at the head of the side stream's work
+        elif do_prep:
+            cuts.append((k_prep, run_prep))
+        cuts.sort(key=lambda c: c[0])
+        pos = 1
+        for idx, action in cuts:
+            if idx > pos:
+                self.fwd.run(stream_ptr(), pos, idx, join=False)
+                pos = idx
+            action()
+        self.fwd.run(stream_ptr(), pos)
         return self.out5.buf.view(B, self.A, 5).clone()
+
+    def _prep_index(self):
+        """Where in the forward program the backward's weight images (transposed / Winograd-transformed filters: ~0.2 ms of HBM-bound
+        launches the backward needs, nothing in the forward does) are enqueued on the side stream: None = in front of everything
+        (ZSG_PREP_AT=top), else the launch index they go in front of — `late` = the first launch that waits for the forward's own
+        preparation, `j<n>` = behind the n-th join of the main stream with the side stream (the residual blocks' downsample branches),
+        so that they do not sit in front of side-stream work the main stream waits for sooner."""
+        if self._prep_idx_v is not False:
+            return self._prep_idx_v
+        mode = prep_at()
+        v = None
+        joins = [i for i, l in enumerate(self.fwd.lanes) if l == 2]
+        if mode == "late" and len(self.prep_u):
+            v = self._wait_idx
+        elif mode.startswith("j") and mode[1:].isdigit() and len(joins) >= int(mode[1:]) >= 1:
+            v = joins[int(mode[1:]) - 1] + 1
+        elif mode.isdigit():
+            v = min(int(mode), len(self.fwd.calls))
+        self._prep_idx_v = v if (v is None or v > 1) else None
+        return self._prep_idx_v
 
     def run_backward(self, g5: torch.Tensor):
         net = self.net

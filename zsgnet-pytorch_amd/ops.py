@@ -214,6 +214,11 @@ SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
 SIDE_BATCH = int(os.environ.get("ZSG_SIDE_BATCH", "0"))
 
 
+# Cross-stream edges ride on the producing launch's own completion signal (zsg_set_completion_event / zsg_stream_wait_event, zsg.h)
+# instead of an event-record marker in the producing stream's queue; ZSG_COMPLETION_EVENTS=0 restores the marker path.
+COMPLETION_EVENTS = os.environ.get("ZSG_COMPLETION_EVENTS", "1") != "0"
+
+
 _MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb, lib.zsg_conv_igemm_pre, lib.zsg_conv_wino_pre)
 
 
@@ -248,6 +253,8 @@ class Program:
         self.side_batch = 1     # deferred side launches are released at every side_batch-th main-stream convolution
         self._side_busy = False
         self._graphs = {}       # (start, stop, side-stream mode) -> [eager replays so far, captured graph | None]
+        self._sched = {}        # (start, stop, join, side stream busy at entry, release policy) -> compiled lane schedule
+        self._ce_pool = []      # completion events (hipEvent_t behind the C ABI)
 
     def add(self, fn, *args, what: str = "", lane: int = 0):
         self.calls.append((fn, marshal(fn, args, self.keep), what or fn.__name__))
@@ -319,6 +326,120 @@ class Program:
             main.wait_stream(side)
             self._side_busy = False
 
+    def _schedule(self, start: int, stop: int, join: bool, side_busy: bool):
+        """The lane scheduler of _run_lanes as a dry run: a flat list of operations for [start, stop) —
+             ('m', i, k)  launch i on the main stream  (k >= 0: the launch carries completion event k)
+             ('s', i, k)  launch i on the side stream  (      "      )
+             ('ws', k) / ('wm', k)   the side / main stream waits for event k
+             ('rm', k) / ('rs', k)   event k recorded on the main / side stream (a marker: only where no launch of this range precedes
+                                     the edge)
+        Same release policy as _run_lanes (deferral, batching); a release is attached to the last main-stream launch in front of it, a
+        join to the last side-stream launch."""
+        ops, nev = [], 0
+        dirty, last_main, last_side = True, None, None
+        defer = SIDE_DEFER if self.name == "bwd" else 0
+        pending, nconv, batch = [], 0, max(1, SIDE_BATCH or self.side_batch)
+
+        def side_launch(i):
+            nonlocal dirty, nev, last_side, side_busy, last_main
+            if dirty:
+                k, nev = nev, nev + 1
+                if last_main is not None and ops[last_main][2] < 0:
+                    ops[last_main] = ("m", ops[last_main][1], k)
+                else:
+                    ops.append(("rm", k))
+                ops.append(("ws", k))
+                dirty = False
+            ops.append(("s", i, -1))
+            last_side, side_busy = len(ops) - 1, True
+
+        def join_side():
+            nonlocal nev, last_side, side_busy
+            k, nev = nev, nev + 1
+            if last_side is not None and ops[last_side][2] < 0:
+                ops[last_side] = ("s", ops[last_side][1], k)
+            else:
+                ops.append(("rs", k))
+            ops.append(("wm", k))
+            last_side, side_busy = None, False
+
+        for i in range(start, stop):
+            fn = self.calls[i][0]
+            if self.lanes[i] == 2 and (side_busy or pending):
+                for j, _ in pending:
+                    side_launch(j)
+                pending.clear()
+                join_side()
+            if self.lanes[i] == 1:
+                if defer:
+                    pending.append([i, defer])
+                else:
+                    side_launch(i)
+                continue
+            dirty = True
+            ops.append(("m", i, -1))
+            last_main = len(ops) - 1
+            if pending and fn in _MAIN_CONVS:
+                for e in pending:
+                    e[1] -= 1
+                nconv += 1
+                if nconv % batch == 0:
+                    while pending and pending[0][1] <= 0:
+                        side_launch(pending.pop(0)[0])
+        for j, _ in pending:
+            side_launch(j)
+        if join and side_busy:
+            join_side()
+        return ops, nev, side_busy
+
+    def _run_lanes_ce(self, stream: int, start: int, stop: int, join: bool = True):
+        """_run_lanes with the cross-stream edges on completion events of the producing launches (no marker packet in the producing
+        stream's queue: ~4.3 us of main-stream time per release, ~35 releases per step)."""
+        main = torch.cuda.current_stream()
+        assert main.cuda_stream == stream, "Program.run expects torch's current stream"
+        if self._side is None:
+            self._side = shared_side_stream()
+            self._ev_pool = []
+        key = (start, stop, join, self._side_busy, SIDE_DEFER, SIDE_BATCH or self.side_batch)
+        sched = self._sched.get(key)
+        if sched is None:
+            sched = self._sched[key] = self._schedule(start, stop, join, self._side_busy)
+        ops, nev, busy_out = sched
+        while len(self._ce_pool) < nev:
+            e = lib.zsg_event_create()
+            if not e:
+                raise ZsgError(f"event_create failed: {lib.zsg_last_error().decode()}")
+            self._ce_pool.append(C.c_void_p(e))
+        evs = self._ce_pool
+        st0, st1 = C.c_void_p(stream), C.c_void_p(self._side.cuda_stream)
+        arm, rec, wait = lib.zsg_set_completion_event, lib.zsg_event_record, lib.zsg_stream_wait_event
+        calls = self.calls
+        for op in ops:
+            t = op[0]
+            if t == "m" or t == "s":
+                fn, args, what = calls[op[1]]
+                st = st0 if t == "m" else st1
+                k = op[2]
+                if k < 0:
+                    rc = fn(*args, st)
+                else:
+                    arm(evs[k])
+                    rc = fn(*args, st)
+                    if arm(None) == 0:          # the call launched nothing that could carry the event: a marker instead
+                        rec(evs[k], st)
+                if rc:
+                    arm(None)
+                    raise ZsgError(f"{self.name}/{what} failed ({rc}): {lib.zsg_last_error().decode()}")
+            elif t == "ws":
+                wait(st1, evs[op[1]])
+            elif t == "wm":
+                wait(st0, evs[op[1]])
+            elif t == "rm":
+                rec(evs[op[1]], st0)
+            else:
+                rec(evs[op[1]], st1)
+        self._side_busy = busy_out
+
     def run(self, stream: int, start: int = 0, stop: Optional[int] = None, graph: bool = True, join: bool = True):
         """Replay calls[start:stop] on `stream` (torch's current stream), eagerly by default (3.4-3.9 us of host time per
         launch: the host stays ahead of the GPU).  With HIP_GRAPH on, a range that has been replayed GRAPH_WARMUP times is
@@ -353,6 +474,8 @@ class Program:
 
     def _run_eager(self, stream: int, start: int, stop: int, join: bool = True):
         if SIDE_STREAM and any(self.lanes[start:stop]):
+            if COMPLETION_EVENTS and not torch.cuda.is_current_stream_capturing():
+                return self._run_lanes_ce(stream, start, stop, join)
             return self._run_lanes(stream, start, stop, join)
         st = C.c_void_p(stream)
         for fn, args, what in self.calls[start:stop]:
