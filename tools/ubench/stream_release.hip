@@ -90,6 +90,58 @@ static void run_stopevent_case(const char* title, int mode, int n_pairs) {
     for (auto& e : ev) hipEventDestroy(e);
 }
 
+// release through MEMORY: the last block of A writes a flag (atomic ticket), the side stream waits with hipStreamWaitValue32 — no
+// packet of the main stream's queue takes part.  mode 0: flag in hipMallocSignalMemory, 1: flag in plain device memory
+__global__ void spin_release(unsigned long long* stamp, int slot, long ticks, unsigned* ticket, unsigned* flag, unsigned seq) {
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) atomicMin(&stamp[2 * slot], t0);
+    while ((long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) atomicMax(&stamp[2 * slot + 1], wall_clock64());
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0;
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+static void run_waitvalue_case(const char* title, int mode, int n_pairs) {
+    int can = 0;
+    hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0);
+    unsigned long long* stamp;
+    unsigned *ticket, *flag = nullptr;
+    hipMalloc(&stamp, 64 * 16);
+    hipMalloc(&ticket, 64);
+    hipMemset(ticket, 0, 64);
+    hipError_t e = mode == 0 ? hipExtMallocWithFlags((void**)&flag, 64, hipMallocSignalMemory) : hipMalloc(&flag, 64);
+    printf("%s\n   (hipDeviceAttributeCanUseStreamWaitValue = %d, flag allocation: %s)\n", title, can, hipGetErrorString(e));
+    if (e != hipSuccess || !can) return;
+    hipMemset(flag, 0, 8);
+    std::vector<unsigned long long> h(128);
+    unsigned seq = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int i = 0; i < 64; ++i) { h[2 * i] = ~0ull; h[2 * i + 1] = 0; }
+        hipMemcpy(stamp, h.data(), 64 * 16, hipMemcpyHostToDevice);
+        hipDeviceSynchronize();
+        for (int i = 0; i < n_pairs; ++i) {
+            ++seq;
+            hipLaunchKernelGGL(spin_release, dim3(256), dim3(256), 0, st[0], stamp, 2 * i, 30L * 100, ticket, flag, seq);
+            hipError_t w = hipStreamWaitValue32(st[1], flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+            if (w != hipSuccess) { printf("   hipStreamWaitValue32: %s\n", hipGetErrorString(w)); return; }
+            hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, st[1], stamp, 2 * i + 1, 10L * 100);
+        }
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(h.data(), stamp, 64 * 16, hipMemcpyDeviceToHost);
+    double gap = 0, lat = 0;
+    for (int i = 1; i < n_pairs; ++i) gap += ((long long)h[2 * (2 * i)] - (long long)h[2 * (2 * i - 2) + 1]) / 100.0;
+    for (int i = 0; i < n_pairs; ++i) lat += ((long long)h[2 * (2 * i + 1)] - (long long)h[2 * (2 * i) + 1]) / 100.0;
+    printf("   main stream: A_i end -> A_i+1 start %.2f us (mean of %d);  side stream: S_i starts %.2f us after A_i ends;  whole chain %.1f us\n",
+           gap / (n_pairs - 1), n_pairs - 1, lat / n_pairs, ((long long)h[2 * (2 * n_pairs - 2) + 1] - (long long)h[0]) / 100.0);
+}
+
 struct K { const char* name; int stream; int grid, block; long us; bool memset_before; };
 
 static void run_case(const char* title, const std::vector<K>& ks, int release_after, bool release_at_all) {
@@ -150,6 +202,8 @@ int main() {
     run_stopevent_case("13. 12 x (main A 30 us -> release -> side S 10 us): release = hipEventRecord + hipStreamWaitEvent", 0, 12);
     run_stopevent_case("14. same, release = A's own completion (hipExtLaunchKernelGGL stopEvent) + hipStreamWaitEvent", 1, 12);
     run_stopevent_case("15. same, no release (independent streams)", 2, 12);
+    run_waitvalue_case("16. release through memory: last block of A writes a flag in SIGNAL memory, side stream hipStreamWaitValue32", 0, 12);
+    run_waitvalue_case("17. same, flag in plain device memory", 1, 12);
     run_writer_case("8. side stream is WRITING (2 GB in flight) while main records the event; event flags: DisableTiming", hipEventDisableTiming, 2048);
     run_writer_case("9. same, event flags: DisableTiming | ReleaseToDevice", hipEventDisableTiming | hipEventReleaseToDevice, 2048);
     run_writer_case("10. same, event flags: DisableTiming | DisableSystemFence", hipEventDisableTiming | hipEventDisableSystemFence, 2048);

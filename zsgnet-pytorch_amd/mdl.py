@@ -87,12 +87,10 @@ def prep_at() -> str:
     return os.environ.get("ZSG_PREP_AT", "j2")
 
 
-def side_after_stem() -> int:
-    """ZSG_SIDE_AFTER_STEM: 0 = the query encoder / language maps head the forward program's side-stream work; 1 = they are released
-    behind the stem; 2 = behind the stem AND layer1.0's downsample branch (which the main stream joins ~0.3 ms later, while the head
-    reads the language maps ~4 ms later); 3 = behind the main stream's first join with the side stream (layer1.0's residual add: a join
-    waits for everything on the side stream, so in front of it the query encoder's ~0.25 ms delayed that join by ~50-190 us)."""
-    return int(os.environ.get("ZSG_SIDE_AFTER_STEM", "0"))
+def lang_at() -> str:
+    """ZSG_LANG_AT: where the forward program releases the query encoder + language maps on the side stream: "head" = first (they
+    co-run with the stem), "stem" = behind the stem, "j<n>" = behind the n-th join (see _Plan._lower)."""
+    return os.environ.get("ZSG_LANG_AT", "j3")
 
 
 def prep_release_top() -> bool:
@@ -1051,12 +1049,20 @@ class _Plan:
                     self.bwd.add(lib.zsg_maxpool_bwd, self.base(pool_out.grad), idx, B, H1, W1, 64, 3, 2, 1, H2, W2, dx.buf, what="maxpool_bwd")
                     dx.gfilled = True
                 self.tape.append(pool_back)
-            taps = {}
+            taps, lat = {}, {}
+            early = self.training and os.environ.get("ZSG_FPN_LATERAL_EARLY", "0") != "0"
             for blk in net.blocks:
                 x = self._lower_block(blk, x)
                 if blk["last"]:
                     taps[blk["layer"]] = x
-            feats = self._lower_fpn(taps[2], taps[3], taps[4])
+                    if early and blk["layer"] in (2, 3):
+                        # the pyramid's lateral 1x1 convolutions P3_1 / P4_1 only read C3 / C4: on the side stream as soon as their
+                        # input exists, under layer3 / layer4 (whose 19^2 / 10^2 launches leave a quarter of the CUs idle), instead
+                        # of in the main stream's chain between layer4 and the head
+                        with self.on_side_stream():
+                            nm = "P3_1" if blk["layer"] == 2 else "P4_1"
+                            lat[blk["layer"]] = self.conv(C["backbone.fpn." + nm], x, name="t3" if blk["layer"] == 2 else "t4")
+            feats = self._lower_fpn(taps[2], taps[3], taps[4], lat.get(2), lat.get(3))
         self.feat_sizes = [(f.levels[0].H, f.levels[0].W) for f in feats]
         self.feat_sizes_t = torch.tensor(self.feat_sizes, dtype=torch.long, device=self.dev)
         self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
@@ -1073,23 +1079,28 @@ class _Plan:
             del self.fwd.calls[i0:i1], self.fwd.lanes[i0:i1]
         self.fwd.calls[hoist_to:hoist_to] = moved_c      # ... and re-insert in their original order
         self.fwd.lanes[hoist_to:hoist_to] = moved_l
-        if self.training and side_after_stem():
-            # the head-of-program side-stream block (query encoder, language maps) goes BEHIND the stem's main-stream launches: its
-            # release is an event record on the main stream, and the stem convolution should not queue behind that marker
+        where = lang_at()
+        if self.training and where != "head":
+            # the head-of-program side-stream block (query encoder, language maps; ~0.25 ms, read by the head ~4 ms later) is released
+            # further into the program: behind the stem ("stem") or behind the n-th join of the main stream with the side stream
+            # ("j<n>": a join waits for the WHOLE side stream, so in front of the first one the block delays layer1.0's residual add)
             ln = self.fwd.lanes
             j = next((i for i in range(1, len(ln)) if ln[i] == 0), None)
             if j is not None and j > 1 and all(l == 1 for l in ln[1:j]):
-                k = j
-                while k < len(ln) and ln[k] == 0:
-                    k += 1
-                if side_after_stem() == 2:       # ... and behind the first residual block's downsample branch (joined much sooner)
-                    while k < len(ln) and ln[k] == 1:
+                k = None
+                if where == "stem":
+                    k = j
+                    while k < len(ln) and ln[k] == 0:
                         k += 1
-                elif side_after_stem() == 3:     # ... behind the main stream's first join (a join waits for the WHOLE side stream)
-                    k = next((i + 1 for i in range(j, len(ln)) if ln[i] == 2), k)
-                blk_c, blk_l = self.fwd.calls[1:j], ln[1:j]
-                self.fwd.calls[1:k] = self.fwd.calls[j:k] + blk_c
-                self.fwd.lanes[1:k] = ln[j:k] + blk_l
+                elif where.startswith("j") and where[1:].isdigit():
+                    joins = [i for i in range(j, len(ln)) if ln[i] == 2]
+                    n = int(where[1:])
+                    if 1 <= n <= len(joins) - 2:          # (never behind the joins in front of the head itself; a network without
+                        k = joins[n - 1] + 1              #  residual joins — SSD-VGG — keeps the block at the head of the program)
+                if k is not None:
+                    blk_c, blk_l = self.fwd.calls[1:j], ln[1:j]
+                    self.fwd.calls[1:k] = self.fwd.calls[j:k] + blk_c
+                    self.fwd.lanes[1:k] = ln[j:k] + blk_l
 
         # ---- backward program: replay the tape in reverse ----------------------------------------------------------
         if self.training:
@@ -1266,7 +1277,7 @@ class _Plan:
             a.name = f"feat{i}"
         return lv
 
-    def _lower_fpn(self, c3: Act, c4: Act, c5: Act) -> List[Act]:
+    def _lower_fpn(self, c3: Act, c4: Act, c5: Act, t3: Optional[Act] = None, t4: Optional[Act] = None) -> List[Act]:
         """fpn_resnet.py:154-178"""
         net, B = self.net, self.B
         C = net.convs
@@ -1282,18 +1293,25 @@ class _Plan:
             o3, o4, o5, o6, o7, o8 = fl
         # The pyramid's output convolutions P5_2 / P4_2 and the whole P6 -> P7 (-> P8) chain are leaves that only the head reads:
         # in training they run on the side stream, concurrently with the lateral / top-down path and the large P3_2.
+        if t3 is not None or t4 is not None:
+            # the laterals lowered early on the side stream (P3_1 under layer3, P4_1 under layer4) are joined HERE, in front of the pyramid's
+            # own side-stream launches: a join waits for the whole side stream
+            self._join_side()
         p51 = self.conv(C[f + "P5_1"], c5, name="p51")
         with self.on_side_stream():
             p5 = self.conv(C[f + "P5_2"], p51, out=o5)
-        t4 = self.conv(C[f + "P4_1"], c4, name="t4")
+        if t4 is None:
+            t4 = self.conv(C[f + "P4_1"], c4, name="t4")
         p41 = self._upsample_add(t4, p51, "p41")
         with self.on_side_stream():
             p4 = self.conv(C[f + "P4_2"], p41, out=o4)
         # (P3_1 / top-down add / the large P3_2 are lowered BEHIND the P6 -> P7 -> P8 chain: a side-stream launch waits for the main-stream
         # work enqueued before it, so in program order behind P3_2 the chain only started when P3_2 had finished and the head's first
         # convolution waited ~90 us for it; here it runs under P3_1 / P3_2)
+        t3_in = t3
+
         def lower_p3():
-            t3 = self.conv(C[f + "P3_1"], c3, name="t3")
+            t3 = t3_in if t3_in is not None else self.conv(C[f + "P3_1"], c3, name="t3")
             p31 = self._upsample_add(t3, p41, "p31")
             return self.conv(C[f + "P3_2"], p31, out=o3, name="p3")
         p6_first = os.environ.get("ZSG_FPN_P6_FIRST", "1") != "0"
@@ -1337,10 +1355,11 @@ class _Plan:
         self._join_side()
         return [p3, p4, p5, p6, p7, p8]
 
-    def _upsample_add(self, a: Act, p: Act, name: str) -> Act:
+    def _upsample_add(self, a: Act, p: Act, name: str, join: bool = False) -> Act:
         la, lp = a.levels[0], p.levels[0]
         out = self.act(name, a.B, la.H, la.W, a.C)
-        self.fwd.add(lib.zsg_upsample_add_fwd, a.buf, p.buf, a.B, lp.H, lp.W, la.H, la.W, a.C, out.buf, what=name)
+        self.fwd.add(lib.zsg_upsample_add_fwd, a.buf, p.buf, a.B, lp.H, lp.W, la.H, la.W, a.C, out.buf, what=name,
+                     lane=2 if (join and self.training) else 0)
 
         def back():
             if out.grad is None:
