@@ -15,7 +15,8 @@
 #include "common.h"
 
 #define IG_BK 32
-// IG_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong) — 1 no MFMAs, 2 no global loads
+// IG_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong; 32 = no output stores in the plain
+// vectorised epilogue) — 1 no MFMAs, 2 no global loads
 // in the K loop, 4 no LDS stores, 8 no fragment reads, 16 no barrier.  tools/igemm_ablation.sh builds one library per value.
 #ifndef IG_ABL
 #define IG_ABL 0
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                 }
+                if ((IG_ABL & 32) && v[0] != 12345.678f) continue;      // (ablation: no output stores)
                 *(f32x4*)(p.out + o) = v;
             }
         }

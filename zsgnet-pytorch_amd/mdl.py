@@ -1711,8 +1711,8 @@ class _Plan:
         joins = [i for i, l in enumerate(self.fwd.lanes) if l == 2]
         if mode == "late" and len(self.prep_u):
             v = self._wait_idx
-        elif mode.startswith("j") and mode[1:].isdigit() and len(joins) >= int(mode[1:]) >= 1:
-            v = joins[int(mode[1:]) - 1] + 1
+        elif mode.startswith("j") and mode[1:].isdigit() and len(joins) - 2 >= int(mode[1:]) >= 1:
+            v = joins[int(mode[1:]) - 1] + 1       # (never behind the joins in front of the head: SSD-VGG has no others -> top)
         elif mode.isdigit():
             v = min(int(mode), len(self.fwd.calls))
         self._prep_idx_v = v if (v is None or v > 1) else None
