@@ -718,3 +718,40 @@ def test_wgrad_256_column_tile(Z, case):
     dw = torch.zeros(Co, k, k, cp, device="cuda")
     L.check(L.lib.zsg_conv_wgrad(C.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad 64x256")
     assert_close(dw[..., :Ci].permute(0, 3, 1, 2), ref, 5e-4, 5e-4 * float(ref.abs().max()), "wgrad, 256-column tile")
+
+
+def test_completion_event_orders_another_stream(Z):
+    """zsg_set_completion_event / zsg_stream_wait_event (include/zsg.h): a launch on stream A carries the armed event as its completion
+    signal and stream B, made to wait for it, sees everything that launch wrote — without a marker in A's queue.  Also: the disarming
+    call reports how many launches carried the event (0 for a call that launches nothing: the caller then records a marker)."""
+    L, _ = Z
+    lib = L.lib
+    n = 64 << 20                                        # 256 MB: the fill takes ~50 us, a racing reader would see stale zeros
+    a = torch.zeros(n, device="cuda")
+    b = torch.full((n,), -1.0, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = lib.zsg_event_create()
+    assert ev
+    ev = C.c_void_p(ev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        val = float(rep + 1)
+        assert lib.zsg_set_completion_event(ev) >= 0
+        L.check(lib.zsg_memset_f32(a.data_ptr(), n, val, C.c_void_p(sa.cuda_stream)), "memset")
+        assert lib.zsg_set_completion_event(None) == 1  # one launch carried the event
+        L.check(lib.zsg_stream_wait_event(C.c_void_p(sb.cuda_stream), ev), "wait")
+        L.check(lib.zsg_relu_fwd(a.data_ptr(), n, b.data_ptr(), C.c_void_p(sb.cuda_stream)), "relu")     # b = max(a, 0) on stream B
+        sb.synchronize()
+        assert float(b.min()) == val and float(b.max()) == val, (rep, float(b.min()), float(b.max()))
+    # a call that launches nothing reports 0 uses; the marker fallback orders the streams just the same
+    lib.zsg_set_completion_event(ev)
+    L.check(lib.zsg_memset_f32(a.data_ptr(), 0, 0.0, C.c_void_p(sa.cuda_stream)), "empty memset")
+    assert lib.zsg_set_completion_event(None) == 0
+    L.check(lib.zsg_memset_f32(a.data_ptr(), n, 7.0, C.c_void_p(sa.cuda_stream)), "memset")
+    L.check(lib.zsg_event_record(ev, C.c_void_p(sa.cuda_stream)), "record")
+    L.check(lib.zsg_stream_wait_event(C.c_void_p(sb.cuda_stream), ev), "wait")
+    L.check(lib.zsg_relu_fwd(a.data_ptr(), n, b.data_ptr(), C.c_void_p(sb.cuda_stream)), "relu")
+    sb.synchronize()
+    assert float(b.min()) == 7.0 and float(b.max()) == 7.0
+    torch.cuda.synchronize()
+    L.check(lib.zsg_event_destroy(ev), "destroy")
