@@ -1,7 +1,7 @@
 """ZSG_DETERMINISTIC=1: two PROCESSES that share the tuner's tile choices (ZSG_TUNE_CACHE) produce bit-identical
 outputs, losses and gradients — no launch combines partial sums with fp32 atomics in this mode (split-K candidates are
 not offered, bias / border column sums use one block per element group, the weight gradient's slabs are summed in a
-fixed order)."""
+fixed order) — and so do the same step on one stream and under the other scheduling options (round 3)."""
 import os
 import subprocess
 import sys
@@ -50,14 +50,21 @@ def test_two_processes_bit_identical(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(SCRIPT.format(root=ROOT))
     env = dict(os.environ, ZSG_DETERMINISTIC="1", ZSG_TUNE_CACHE=str(tmp_path / "tune.json"))
+    # process 2: the optimizer update split around the backward's tail (ZSG_ADAM_OVERLAP=1); 3: every launch on ONE stream (no
+    # cross-stream edge can be missing there); 4: round-2 scheduling (event-record markers instead of completion signals, the
+    # backward's weight images / the query encoder released at the head of the forward, P3 before the P6 chain).  Scheduling decides
+    # WHEN a launch runs, never what it computes: all five must agree to the bit.
+    variants = [{}, {}, {"ZSG_ADAM_OVERLAP": "1"}, {"ZSG_SIDE_STREAM": "0"},
+                {"ZSG_COMPLETION_EVENTS": "0", "ZSG_PREP_AT": "top", "ZSG_LANG_AT": "head", "ZSG_FPN_P6_FIRST": "0", "ZSG_PREP_RELEASE_TOP": "0"}]
     outs = []
-    for i in range(3):            # the third process: the optimizer update split around the backward's tail (ZSG_ADAM_OVERLAP=1) — same bits
+    for i, extra in enumerate(variants):
         out = tmp_path / f"r{i}.pt"
-        subprocess.run([sys.executable, str(script), str(out)], check=True, env=dict(env, ZSG_ADAM_OVERLAP="1") if i == 2 else env, timeout=900)
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=dict(env, **extra), timeout=900)
         outs.append(torch.load(out))
     assert (tmp_path / "tune.json").exists(), "the first process must persist its tile choices"
-    a, b, c = outs
-    for k in a:
-        assert torch.equal(a[k], b[k]), f"{k} differs between two deterministic runs (max |d| {float((a[k] - b[k]).abs().max()):.3g})"
-        assert torch.equal(a[k], c[k]), f"{k}: overlapped optimizer update differs from the joined one (max |d| {float((a[k] - c[k]).abs().max()):.3g})"
+    a = outs[0]
+    what = ["a second deterministic run", "the overlapped optimizer update", "the single-stream run", "the round-2 scheduling"]
+    for o, w in zip(outs[1:], what):
+        for k in a:
+            assert torch.equal(a[k], o[k]), f"{k}: {w} differs (max |d| {float((a[k] - o[k]).abs().max()):.3g})"
     assert torch.isfinite(a["grad1"]).all() and float(a["grad1"].abs().sum()) > 0
