@@ -1560,7 +1560,12 @@ class _Plan:
                 dwf = fwd_desc(Fp, dy, Cf, 256, 3, 1, 1, 1, wC=cp, wc0=0)
                 self.wgrad(dwf, Fp, dy, W0n, "wgrad:" + L0.name)
                 self.dgrad(L0, dy, Fp, n=Cf, row0=0, dx=self.grad_of(Fp))
-            hws_bytes = 16 << 20           # the small wgrads below run on the main stream: keep them off the side stream's slabs
+            # The language / grid columns of dW0, the bias gradient and d(we) hang off dy only and feed nothing but the query encoder's
+            # backward (itself on the side stream): with features present they are leaves of the main chain and go to the side stream,
+            # so that the pyramid's backward starts right behind conv0's data gradient (ZSG_LANG_BWD_SIDE=0: on the main stream, as before).
+            # (not with do_norm: the language vector's normalisation has its backward on the main stream, right behind d(we))
+            ln = 1 if (Cf and not (net.do_norm and Cw) and os.environ.get("ZSG_LANG_BWD_SIDE", "1") != "0") else 0
+            hws_bytes = 16 << 20           # (a workspace of their own: on the main stream they ran concurrently with the side stream's slabs)
             hws = self._buf(hws_bytes // 4) if (Cw or Cg) else None
             if Cw:
                 # language columns of dW0 and d(we) from validity-masked sums of dy, themselves nine plain per-image sums
@@ -1568,24 +1573,24 @@ class _Plan:
                 Q = self._buf(9 * B * 256)
                 S1 = Act(S, B, 9 * 256, 9 * 256, [Level(0, 1, 1, 9 * 256)], "head.S1")
                 S2 = Act(S, 1, B, B, [Level(B * 9 * 256, 1, 9 * 256, 9 * 256 * B)], "head.S2")
-                self.bwd.add(lib.zsg_memset_f32, Q, Q.numel(), 0.0, what="zero:head.Q")
+                self.bwd.add(lib.zsg_memset_f32, Q, Q.numel(), 0.0, what="zero:head.Q", lane=ln)
                 for i, (h, w) in enumerate(sizes):
-                    self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, Q, what=f"bsum{i}")
-                self.bwd.add(lib.zsg_head_border_finalize, Q, B, 256, S, self.base(S2), self.G(L0.name + ".bias"), what="bsum.finalize")
+                    self.bwd.add(lib.zsg_head_border_sums, self.base(dy.lvl(i)), B, h, w, 256, Q, what=f"bsum{i}", lane=ln)
+                self.bwd.add(lib.zsg_head_border_finalize, Q, B, 256, S, self.base(S2), self.G(L0.name + ".bias"), what="bsum.finalize", lane=ln)
                 dwl = fwd_desc(we, S1, Cw, 9 * 256, 1, 1, 0, 1, wC=cp, wt_ld=cp, wc0=Cf)
-                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 1, hws, hws_bytes, what="wgrad:" + L0.name + ".lang")
+                self.bwd.add(lib.zsg_conv_wgrad, dwl, we.buf, S, gW0, 1, hws, hws_bytes, what="wgrad:" + L0.name + ".lang", lane=ln)
                 ent = net.store.entries[W0n]
                 Wrows = Act(net.store.flat, 1, Cw, cp, [Level(ent.offset + Cf, 1, 9 * 256, 9 * 256 * cp)], "head.W0rows")
                 gwe = self.grad_of(we)
                 dwe = fwd_desc(Wrows, S2, Cw, B, 1, 1, 0, 1, wC=Cw, wt_ld=Cw)
-                self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), int(gwe.gfilled), hws, hws_bytes, what="dwe:" + prefix)
+                self.bwd.add(lib.zsg_conv_wgrad, dwe, Wrows.buf, S, self.base(gwe), int(gwe.gfilled), hws, hws_bytes, what="dwe:" + prefix, lane=ln)
                 gwe.gfilled = True
             if Cg:
                 dys = self.packed(prefix + ".dysum", 1, sizes, 256)
                 for i, (h, w) in enumerate(sizes):
-                    self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}")
+                    self.bwd.add(lib.zsg_batch_sum, self.base(dy.lvl(i)), B, h * w * 256, self.base(dys.lvl(i)), what=f"dysum{i}", lane=ln)
                 dwg = fwd_desc(gridmap, dys, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
-                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 1, hws, hws_bytes, what="wgrad:" + L0.name + ".grid")
+                self.bwd.add(lib.zsg_conv_wgrad, dwg, gridmap.buf, dys.buf, gW0, 1, hws, hws_bytes, what="wgrad:" + L0.name + ".grid", lane=ln)
             self.grad_ready[W0n] = len(self.bwd.calls)
         self.tape.append(head0_back)
         hs = [h1]
