@@ -154,6 +154,13 @@ int zsg_conv_wino_pre(const zsg_conv_desc* d, const float* src, const float* U, 
 int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* add_src,
                        const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
                        float* partials, void* stream);
+/* tile_hint BM = 32 (BN field = unit width 32 / 64 / 128) selects the filter-resident streaming kernel for the 1x1 / stride-1
+ * convolutions whose filter fits a CU's LDS (fpn_resnet.py:66-72: the bottleneck conv1 / conv3 / projection shortcut of the
+ * first stage, forward and data gradient): one persistent workgroup per CU, every wave walks units of 32 pixels x BN channels
+ * on its own.  It writes ONE partial row per workgroup; every other tile writes one per BM rows per segment.
+ * zsg_conv_igemm_partial_rows: rows of bn_partials / partials a zsg_conv_igemm / zsg_conv_igemm_bnb launch with this
+ * descriptor (and its tile_hint) writes; -1 when the hint is 0 (heuristic) or the streaming kernel does not cover the geometry. */
+int32_t zsg_conv_igemm_partial_rows(const zsg_conv_desc* d);
 int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* add_src,
                       const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
                       float* partials, void* stream);

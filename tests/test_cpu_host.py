@@ -386,3 +386,40 @@ def test_lane_schedule_orders_every_cross_stream_edge(name, defer, monkeypatch):
                 if join:
                     assert not busy_out and (side_pos < 0 or main_sees_side == side_pos) and not pre_side
                 assert nev == len(set(ev_main) | set(ev_side)) or nev >= len(ev_main) + len(ev_side)
+
+
+def test_partial_row_counts_and_streaming_kernel_geometry():
+    """Host logic of zsg_conv_igemm_partial_rows / ops.pw_cands (no launch): regular tiles write one BatchNorm-partial row per BM
+    rows per segment; the filter-resident streaming kernel (tile_hint BM = 32) one per workgroup, and only for dense 1x1 /
+    stride-1 geometries whose filter fits the LDS next to the eight wave buffers."""
+    import ctypes as C
+
+    import torch
+    import zsgnet_pytorch_amd.ops as ops
+    from zsgnet_pytorch_amd._lib import lib
+
+    def view(B, H, W, Cc):
+        return ops.TView(torch.empty(1), B, Cc, Cc, [ops.Level(0, H, W, H * W * Cc)])
+
+    B, H, W = 16, 75, 75
+    rows = B * H * W
+    d = ops.fwd_desc(view(B, H, W, 64), view(B, H, W, 256), 64, 256, 1, 1, 0, 1, wC=64)
+    assert lib.zsg_conv_igemm_partial_rows(C.byref(d)) == -1                      # heuristic hint: unknown
+    for bm in (64, 128):
+        d.tile_hint = ops.tile_hint(bm, 64, 1)
+        assert lib.zsg_conv_igemm_partial_rows(C.byref(d)) == (rows + bm - 1) // bm
+    assert ops.pw_cands(d) == [ops.tile_hint(32, 32, 1), ops.tile_hint(32, 64, 1), ops.tile_hint(32, 128, 1)]
+    assert d.tile_hint == ops.tile_hint(128, 64, 1)                               # (left as it was)
+    d.tile_hint = ops.tile_hint(32, 128, 1)
+    assert ops.igemm_partial_rows(d) == 256                                       # one row per workgroup, one workgroup per CU
+    small = ops.fwd_desc(view(1, 5, 5, 64), view(1, 5, 5, 64), 64, 64, 1, 1, 0, 1, wC=64, tile_hint=ops.tile_hint(32, 64, 1))
+    assert ops.igemm_partial_rows(small) == 1
+    # 256 -> 64: units of 32 / 64 columns only; 3x3, strided, non-dense and too-large-filter geometries are refused
+    assert ops.pw_cands(ops.fwd_desc(view(B, H, W, 256), view(B, H, W, 64), 256, 64, 1, 1, 0, 1, wC=256)) == [ops.tile_hint(32, 32, 1), ops.tile_hint(32, 64, 1)]
+    assert ops.pw_cands(ops.fwd_desc(view(B, H, W, 64), view(B, H, W, 64), 64, 64, 3, 1, 1, 1, wC=64)) == []
+    assert ops.pw_cands(ops.fwd_desc(view(B, 76, 76, 64), view(B, 38, 38, 64), 64, 64, 1, 2, 0, 1, wC=64)) == []
+    assert ops.pw_cands(ops.fwd_desc(view(B, 38, 38, 512), view(B, 38, 38, 128), 512, 128, 1, 1, 0, 1, wC=512)) == []
+    strided_out = ops.TView(torch.empty(1), B, 64, 128, [ops.Level(0, H, W, H * W * 128)])      # pixel stride 128: still dense rows
+    assert ops.pw_cands(ops.fwd_desc(view(B, H, W, 64), strided_out, 64, 64, 1, 1, 0, 1, wC=64)) != []
+    dg = ops.dgrad_desc(view(B, H, W, 256), view(B, H, W, 64), 256, 64, 1, 1, 0, 1)
+    assert ops.pw_cands(dg) == [ops.tile_hint(32, 32, 1), ops.tile_hint(32, 64, 1)]

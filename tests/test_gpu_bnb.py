@@ -25,6 +25,13 @@ CASES = [
     (2, 64, 64, 19, 19, 3, 1, False, True, "wino", (64, 64, 0)),
     (2, 128, 96, 10, 7, 3, 1, True, True, "wino", (32, 64, 1)),
     (3, 64, 128, 5, 5, 3, 1, False, False, "wino", (32, 32, 1)),
+    # filter-resident streaming kernel (csrc/pw.hip, tile_hint BM = 32, BN = unit width): one partial row per workgroup
+    (2, 256, 64, 19, 19, 1, 1, False, True, "igemm", (32, 128, 0)),
+    (2, 256, 64, 19, 19, 1, 1, True, True, "igemm", (32, 64, 0)),
+    (3, 64, 256, 10, 13, 1, 1, True, False, "igemm", (32, 32, 0)),
+    (2, 64, 64, 21, 21, 1, 1, False, True, "igemm", (32, 64, 0)),
+    (16, 256, 64, 75, 75, 1, 1, True, True, "igemm", (32, 128, 0)),       # layer1 conv1's data gradient at the bench shape
+    (16, 64, 256, 75, 75, 1, 1, False, True, "igemm", (32, 32, 0)),       # layer1 conv3's
     # many partial rows (100 / 200)
     (4, 64, 64, 40, 40, 1, 1, False, True, "igemm", (64, 64, 0)),
     (4, 64, 32, 40, 40, 3, 1, True, True, "wino", (32, 64, 1)),
@@ -85,7 +92,11 @@ def test_dgrad_with_bn_backward_sums(Z, case):
     d0 = ops.dgrad_desc(dyv, view_of(ops, dx0, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)
     assert not d0.zero_fill
     if kern != "wino":
-        chunks = sum((B * d0.seg[i].rows_y * d0.seg[i].rows_x + bm - 1) // bm for i in range(d0.nseg))
+        chunks = int(L.lib.zsg_conv_igemm_partial_rows(C.byref(d0)))
+        if bm != 32:
+            assert chunks == sum((B * d0.seg[i].rows_y * d0.seg[i].rows_x + bm - 1) // bm for i in range(d0.nseg))
+        else:
+            assert 0 < chunks <= 256
     L.check(fn_plain(C.byref(d0), dyd.data_ptr(), wop.data_ptr(), dx0.data_ptr(), None, dx0.data_ptr() if acc else None, None, None, st), "plain dgrad")
     dx1 = fresh()
     d1 = ops.dgrad_desc(dyv, view_of(ops, dx1, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)

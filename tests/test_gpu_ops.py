@@ -242,6 +242,100 @@ def test_conv_fwd_dgrad_wgrad(Z, case):
     torch.cuda.synchronize()
 
 
+PW_CASES = [
+    # B, Ci, Co, H, W   (1x1 / stride 1; every unit width the geometry admits is run)
+    (2, 64, 256, 19, 19),        # 23 row tiles, the last with 18 live rows; fewer units than waves
+    (3, 256, 64, 10, 13),        # four K chunks per unit
+    (2, 64, 64, 21, 21),
+    (1, 128, 128, 37, 41),       # two K chunks, N = one 128-wide unit
+    (5, 64, 192, 30, 30),        # N = 192 = 3 or 6 units: not a geometry of the kernel — the hint must be refused
+    (16, 64, 256, 75, 75),       # layer1 conv3 at the bench shape: 2-3 units per wave, next-unit prefetch across units
+    (16, 256, 64, 75, 75),       # layer1 conv1
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[f"p{i}" for i in range(len(PW_CASES))])
+def test_conv_pw_streaming(Z, case):
+    """The filter-resident streaming kernel behind zsg_conv_igemm's tile_hint BM = 32 (csrc/pw.hip) against torch-CPU fp32
+    F.conv2d: forward with bias + ReLU, forward with the fused BatchNorm statistics (one partial row per workgroup,
+    zsg_conv_igemm_partial_rows), data gradient plain and with accumulate + mask; the plain launches must also equal the 64x64
+    tile's results to fp32 summation-order accuracy.  Tolerances as test_conv_fwd_dgrad_wgrad."""
+    L, ops = Z
+    B, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(7 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y_lin = F.conv2d(xr, wr)
+    gy = torch.randn(y_lin.shape, generator=g)
+    y_lin.backward(gy)
+    y_ref = F.relu(y_lin.detach() + b.view(1, -1, 1, 1))
+    st = L.stream_ptr()
+    xd, wd, bd = dev(nhwc(x)), dev(ohwi(w)), dev(b)
+    src = view_of(ops, xd, B, H, W, Ci)
+    rows = B * H * W
+    probe = ops.fwd_desc(src, view_of(ops, torch.empty(1), B, H, W, Co), Ci, Co, 1, 1, 0, 1, wC=Ci)
+    hints = ops.pw_cands(probe)
+    if Co == 192:
+        assert hints == [], "192 channels = 3 / 6 units: not a geometry of the streaming kernel"
+        probe.tile_hint = ops.tile_hint(32, 64, 1)
+        assert L.lib.zsg_conv_igemm_partial_rows(C.byref(probe)) == -1
+        out = torch.zeros(B, H, W, Co, device="cuda")
+        rc = L.lib.zsg_conv_igemm(C.byref(ops.fwd_desc(src, view_of(ops, out, B, H, W, Co), Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=probe.tile_hint)),
+                                  xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, None, st)
+        assert rc != 0, "an inapplicable streaming hint must fail loudly, not fall back"
+        return
+    assert hints, "the streaming kernel must cover this geometry"
+    yf = y_lin.detach().permute(0, 2, 3, 1).reshape(-1, Co).double()
+    for hint in hints:
+        out = torch.full((B, H, W, Co), float("nan"), device="cuda")
+        ov = view_of(ops, out, B, H, W, Co)
+        d1 = ops.fwd_desc(src, ov, Ci, Co, 1, 1, 0, 1, wC=Ci, relu=True, tile_hint=hint)
+        L.check(L.lib.zsg_conv_igemm(C.byref(d1), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr(), None, None, None, st), "pw fwd")
+        assert_close(out.permute(0, 3, 1, 2), y_ref, 2e-4, 2e-4, f"pw fwd bias+relu hint {hint:x}")
+        # fused BatchNorm statistics
+        d2 = ops.fwd_desc(src, ov, Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=hint)
+        chunks = ops.igemm_partial_rows(d2)
+        assert chunks == min(256, ((rows + 31) // 32 * (Co // ((hint >> 8) & 0xff)) + 7) // 8)
+        part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
+        out.fill_(float("nan"))
+        L.check(L.lib.zsg_conv_igemm(C.byref(d2), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "pw fwd+stats")
+        assert_close(out.permute(0, 3, 1, 2), y_lin.detach(), 2e-4, 2e-4, f"pw fwd hint {hint:x}")
+        assert not torch.isnan(part).any()
+        assert_close(part[:, 0].double().sum(0), yf.sum(0), 1e-4, 1e-4 * float(yf.abs().sum(0).max()), "pw bn partial sums")
+        assert_close(part[:, 1].double().sum(0), (yf * yf).sum(0), 1e-4, 1e-6, "pw bn partial sums of squares")
+        mean, invstd = torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+        L.check(L.lib.zsg_bn_stats_from_partials(part.data_ptr(), chunks, rows, Co, mean.data_ptr(), invstd.data_ptr(), None, None, 0.1, 1e-5, st), "finalize")
+        assert_close(mean, yf.mean(0), 1e-4, 1e-5, "pw fused bn mean")
+        assert_close(invstd, 1 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5), 2e-4, 0, "pw fused bn invstd")
+        # the same launch twice: bit-identical (no atomics, fixed reduction order)
+        part2, out2 = torch.full_like(part, float("nan")), torch.full_like(out, float("nan"))
+        L.check(L.lib.zsg_conv_igemm(C.byref(d2), xd.data_ptr(), wd.data_ptr(), out2.data_ptr(), None, None, None, part2.data_ptr(), st), "pw again")
+        assert torch.equal(out, out2) and torch.equal(part, part2)
+    # data gradient: rows = dx pixels, reduction = dy channels
+    dyd = dev(nhwc(gy))
+    dyv = view_of(ops, dyd, B, H, W, Co)
+    wt = torch.empty((Ci, 1, 1, Co), device="cuda")
+    L.check(L.lib.zsg_transpose_w(wd.data_ptr(), wt.data_ptr(), Co, 1, Ci, Co, st), "transpose_w")
+    probe = ops.dgrad_desc(dyv, view_of(ops, torch.empty(1), B, H, W, Ci), Co, Ci, 1, 1, 0, 1)
+    dhints = ops.pw_cands(probe)
+    assert dhints
+    prev = torch.randn(B, H, W, Ci, generator=g)
+    mask = torch.randn(B, H, W, Ci, generator=g)
+    for hint in dhints:
+        dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
+        dd = ops.dgrad_desc(dyv, view_of(ops, dx, B, H, W, Ci), Co, Ci, 1, 1, 0, 1, tile_hint=hint)
+        L.check(L.lib.zsg_conv_igemm(C.byref(dd), dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, None, st), "pw dgrad")
+        assert_close(dx.permute(0, 3, 1, 2), xr.grad, 5e-4, 5e-4 * float(xr.grad.abs().max()), f"pw dgrad hint {hint:x}")
+        dx2, maskd = dev(prev), dev(mask)
+        d2 = ops.dgrad_desc(dyv, view_of(ops, dx2, B, H, W, Ci), Co, Ci, 1, 1, 0, 1, tile_hint=hint)
+        L.check(L.lib.zsg_conv_igemm(C.byref(d2), dyd.data_ptr(), wt.data_ptr(), dx2.data_ptr(), None, dx2.data_ptr(), maskd.data_ptr(), None, st), "pw dgrad+")
+        ref2 = (prev + xr.grad.permute(0, 2, 3, 1)) * (mask > 0)
+        assert_close(dx2, ref2, 5e-4, 5e-4 * float(ref2.abs().max()), f"pw dgrad accumulate+mask hint {hint:x}")
+    torch.cuda.synchronize()
+
+
 def test_conv_multilevel_shared_weights(Z):
     """grouped launch over pyramid levels (shared head), output scattered into the [B, A, 5]-style buffer"""
     L, ops = Z

@@ -22,6 +22,10 @@ struct BnbDev {
     const unsigned char* mask;    // 4 ReLU bits per 16-byte group (bn_apply's relu_mask) or nullptr
 };
 
+// pw.hip: the filter-resident streaming kernel behind zsg_conv_igemm's tile_hint BM = 32 (uw = the hint's BN field)
+int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
+                       const float* mask_src, float* bn_partials, const BnbDev* bnb, hipStream_t st);
+
 #define ZSG_WAVE 64
 #define ZSG_NUM_CU 256
 #define ZSG_NUM_XCD 8

@@ -807,6 +807,10 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     pick_tile(d, &BM, &BN, &splits, &w8, &bx);
     if (d->merge_x && BN == 128) BN = 64;
     if (d->merge_x) w8 = 0;
+    if (BM == 32) {                               // the filter-resident streaming kernel of the 1x1 layers (pw.hip); BN = unit width
+        ZSG_REQUIRE(!src_affine && !bx && splits <= 1, "conv_igemm: the streaming 1x1 kernel has no split-K / bf16x6 / fused-loader variant");
+        return zsg_conv_pw_launch(d, BN, src, wt, out, bias, add_src, mask_src, bn_partials, bnb, (hipStream_t)stream);
+    }
     IgParams p;
     memset(&p, 0, sizeof(p));
     double flops = 0;

@@ -27,8 +27,8 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, marshal, shared_side_stream,
-                  wino_mode, wino_ok)
+from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
+                  shared_side_stream, wino_mode, wino_ok)
 from .params import ParamStore, pad4, register_named
 
 VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
@@ -683,8 +683,7 @@ class _Plan:
             if d.use_wino:
                 chunks = self._wino_chunks(d, src.B)
             else:
-                bm = d.tile_hint & 0xff
-                chunks = sum((src.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
+                chunks = igemm_partial_rows(d)
             if chunks * 2 * L.cout * 4 <= self.ws_bytes:
                 partials, out.bn_chunks = self._ws_now(), chunks
         pre_zero = None
@@ -964,8 +963,7 @@ class _Plan:
                 if d.use_wino:
                     chunks = self._wino_chunks(d, x.B)
                 else:
-                    bm = d.tile_hint & 0xff
-                    chunks = sum((x.B * d.seg[i].rows_y * d.seg[i].rows_x + bm - 1) // bm for i in range(d.nseg))
+                    chunks = igemm_partial_rows(d)
                 fuse = chunks * 2 * L.c * 4 + 2 * L.c * 4 <= self.ws_bytes
             if fuse:
                 part = self.ws[2 * L.c:]              # (the first 2C floats of the workspace: the finalize launch's coefficients)

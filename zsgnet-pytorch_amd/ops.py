@@ -607,6 +607,30 @@ def wino_default_hint(d: ConvDesc) -> int:
     return tile_hint(64, 64, 1) if blocks >= 384 else tile_hint(32, 64, 1)
 
 
+def pw_cands(d: ConvDesc) -> list:
+    """tile hints (BM = 32, BN = unit width) of the filter-resident streaming kernel (csrc/pw.hip) for a 1x1 / stride-1 convolution
+    whose filter fits a CU's LDS next to the eight wave buffers; the library checks the geometry again (zsg_conv_igemm_partial_rows
+    returns -1 where the kernel does not apply)."""
+    if d.nseg != 1 or d.merge_x or d.C % 64 or (d.N * (d.C + 4) + 8 * 32 * 68) * 4 > 160 * 1024:
+        return []
+    out = []
+    keep = d.tile_hint
+    for uw in (32, 64, 128):
+        if d.N % uw == 0 and d.N // uw in (1, 2, 4, 8):
+            d.tile_hint = tile_hint(32, uw, 1)
+            if lib.zsg_conv_igemm_partial_rows(C.byref(d)) > 0:
+                out.append(d.tile_hint)
+    d.tile_hint = keep
+    return out
+
+
+def igemm_partial_rows(d: ConvDesc) -> int:
+    """rows of BatchNorm partials the zsg_conv_igemm / zsg_conv_igemm_bnb launch of d (with its tile_hint) writes"""
+    n = int(lib.zsg_conv_igemm_partial_rows(C.byref(d)))
+    assert n > 0, "no partial-row count for this descriptor / tile hint"
+    return n
+
+
 def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0, split_penalty_ms: float = 0.0,
                   wino_args: Optional[Sequence] = None, wino_fn=None) -> int:
     """Pick d.tile_hint for `fn(d, *args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the real
@@ -628,7 +652,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         return 0
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
-                         mode if wino_args is not None else "", deterministic(), matrix_mode(), fn.__name__))
+                         mode if wino_args is not None else "", deterministic(), matrix_mode(), fn.__name__,
+                         os.environ.get("ZSG_PW", "1") != "0"))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -652,6 +677,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands += [tile_hint(bm, bn, 1, w8) | K64_FLAG for bm, bn in tiles for w8 in (0, 1) if not (bm == 128 and bn == 128 and not w8)]
         if matrix_mode() == "bf16x6" and not d.merge_x:
             cands += [tile_hint(bm, bn, 1, w8) | BX_FLAG for bm, bn in tiles for w8 in (0, 1)]
+        if fn is lib.zsg_conv_igemm and matrix_mode() == "fp32" and os.environ.get("ZSG_PW", "1") != "0":
+            cands += pw_cands(d)
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
         if dense and blocks64 < 1024 and not deterministic():
