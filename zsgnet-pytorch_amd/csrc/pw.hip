@@ -22,6 +22,11 @@
 // deterministic): zsg_conv_igemm_partial_rows() tells the caller how many rows a launch writes.
 #include "common.h"
 
+// PW_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong) — 1 no MFMAs, 2 no output stores,
+// 4 no fragment reads, 8 no source loads in the streaming loop, 16 no partial-row reduction at the end, 32 no per-row statistics.  tools/pw_ablation.sh builds one library per value.
+#ifndef PW_ABL
+#define PW_ABL 0
+#endif
 #define PW_TB 68          // floats per row of a wave's tile buffer: 64 + 4 = 17 x 16 B (odd: conflict-free b128 rows)
 #define PW_WAVES 8
 #define PW_LDS_MAX (160 * 1024)
@@ -52,6 +57,17 @@ __device__ __forceinline__ void pw_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+#if PW_ABL & 1
+#define PW_MFMA(c, a, b) (c)[0] += (a) * (b)
+#else
+#define PW_MFMA(c, a, b) (c) = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
+#if PW_ABL & 4
+#define PW_FRAG(ptr) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
+#else
+#define PW_FRAG(ptr) (*(const f32x4*)(ptr))
+#endif
 
 __device__ __forceinline__ void buf_store4(rsrc_t r, unsigned byte_off, f32x4 v) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + rr + 4 * i;
             const bool ok = live & (m < M);
-            r[i] = buf_load4(rs, ok ? 4u * (unsigned)(p.src_off + m * p.src_ld + rk * 64 + 4 * cg) : ZSG_OOB);
+            r[i] = buf_load4(rs, (ok && !((PW_ABL & 8) && ru >= 8)) ? 4u * (unsigned)(p.src_off + m * p.src_ld + rk * 64 + 4 * cg) : ZSG_OOB);
         }
     };
 #define PW_ADVANCE()           \
@@ -184,23 +200,23 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
             const float* b = Ws + (n0 + li) * LDW + kc * 64 + 4 * lh;
             if constexpr (NJ <= 2) {
                 // few MFMAs per fragment set: the reads of kq + 1 are issued ahead of kq's MFMAs
-                f32x4 fa = *(const f32x4*)a, fb[NJ];
+                f32x4 fa = PW_FRAG(a), fb[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDW);
+                for (int j = 0; j < NJ; ++j) fb[j] = PW_FRAG(b + j * 32 * LDW);
 #pragma unroll
                 for (int kq = 0; kq < 8; ++kq) {
                     f32x4 fan = fa, fbn[NJ];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) fbn[j] = fb[j];
                     if (kq < 7) {
-                        fan = *(const f32x4*)(a + (kq + 1) * 8);
+                        fan = PW_FRAG(a + (kq + 1) * 8);
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) fbn[j] = *(const f32x4*)(b + j * 32 * LDW + (kq + 1) * 8);
+                        for (int j = 0; j < NJ; ++j) fbn[j] = PW_FRAG(b + j * 32 * LDW + (kq + 1) * 8);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][e], fa[e], acc[j], 0, 0, 0);
+                        for (int j = 0; j < NJ; ++j) PW_MFMA(acc[j], fb[j][e], fa[e]);
                     fa = fan;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) fb[j] = fbn[j];
@@ -208,14 +224,14 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
             } else {
 #pragma unroll
                 for (int kq = 0; kq < 8; ++kq) {
-                    const f32x4 fa = *(const f32x4*)(a + kq * 8);
+                    const f32x4 fa = PW_FRAG(a + kq * 8);
                     f32x4 fb[NJ];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDW + kq * 8);
+                    for (int j = 0; j < NJ; ++j) fb[j] = PW_FRAG(b + j * 32 * LDW + kq * 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][e], fa[e], acc[j], 0, 0, 0);
+                        for (int j = 0; j < NJ; ++j) PW_MFMA(acc[j], fb[j][e], fa[e]);
                 }
             }
         }
@@ -296,19 +312,19 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
                         f32x4 g = v[i];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[e] = ((mb[i] >> e) & 1u) ? g[e] : 0.f;
-                        if (off[i] != ZSG_OOB) {         // (dead rows / columns: x and the bits are zeros, but keep them out explicitly)
-                            s1[jp] += g;
-                            s2[jp] += g * ((xb[i] - mu) * is);
-                        }
+                        // (no row test — measured: eight compare + branch pairs per pass cost 3-5 us per launch.  A dead row's
+                        // accumulator, add_src, x and ReLU bits are all exact zeros (out-of-range loads), so it adds 0 * finite;
+                        // a dead column's sums are never written out)
+                        s1[jp] += g;
+                        s2[jp] += g * ((xb[i] - mu) * is);
                     }
                 } else {
-                    if (MODE == 0 && p.stats) {          // (plain convolution: the host excludes bias / add / ReLU here)
+                    if (MODE == 0 && p.stats && !(PW_ABL & 32)) {          // (plain convolution: the host excludes bias / add / ReLU here)
 #pragma unroll
-                        for (int i = 0; i < RH; ++i)
-                            if (off[i] != ZSG_OOB) {
-                                s1[jp] += v[i];
-                                s2[jp] += v[i] * v[i];
-                            }
+                        for (int i = 0; i < RH; ++i) {    // (dead rows hold exact zeros, dead columns are never written out: no test)
+                            s1[jp] += v[i];
+                            s2[jp] += v[i] * v[i];
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < RH; ++i) {
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < RH; ++i) buf_store4(rs_out, off[i], v[i]);
+                for (int i = 0; i < RH; ++i) buf_store4(rs_out, ((PW_ABL & 2) && v[i][0] != 12345.678f) ? ZSG_OOB : off[i], v[i]);
             }
         }
         kc = 0;
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
 #undef PW_ADVANCE
 
     // ---- one partial row per workgroup: lanes of a column group, then the waves of a column split, in a fixed order ------------
-    if (p.stats) {
+    if (p.stats && !(PW_ABL & 16)) {
         __syncthreads();                    // every wave has left the streaming loop: the filter panel is no longer needed
         float* red = smem;                  // [PW_WAVES][2][UW]
 #pragma unroll
