@@ -418,7 +418,14 @@ def test_partial_row_counts_and_streaming_kernel_geometry():
     assert ops.pw_cands(ops.fwd_desc(view(B, H, W, 256), view(B, H, W, 64), 256, 64, 1, 1, 0, 1, wC=256)) == [ops.tile_hint(32, 32, 1), ops.tile_hint(32, 64, 1)]
     assert ops.pw_cands(ops.fwd_desc(view(B, H, W, 64), view(B, H, W, 64), 64, 64, 3, 1, 1, 1, wC=64)) == []
     assert ops.pw_cands(ops.fwd_desc(view(B, 76, 76, 64), view(B, 38, 38, 64), 64, 64, 1, 2, 0, 1, wC=64)) == []
-    assert ops.pw_cands(ops.fwd_desc(view(B, 38, 38, 512), view(B, 38, 38, 128), 512, 128, 1, 1, 0, 1, wC=512)) == []
+    # a filter that does not fit as a whole is cut into 2 / 4 / 8 panels (column blocks of the grid): 128 -> 512 in 4 panels of 128
+    # rows (64 row groups x 4), 512 -> 128 only in 4 panels of 32; 256 -> 1024 would need 16: refused
+    d512 = ops.fwd_desc(view(B, 38, 38, 128), view(B, 38, 38, 512), 128, 512, 1, 1, 0, 1, wC=128)
+    assert ops.pw_cands(d512) == [ops.tile_hint(32, 32, 1), ops.tile_hint(32, 64, 1), ops.tile_hint(32, 128, 1)]
+    d512.tile_hint = ops.tile_hint(32, 128, 1)
+    assert ops.igemm_partial_rows(d512) == 64
+    assert ops.pw_cands(ops.fwd_desc(view(B, 38, 38, 512), view(B, 38, 38, 128), 512, 128, 1, 1, 0, 1, wC=512)) == [ops.tile_hint(32, 32, 1)]
+    assert ops.pw_cands(ops.fwd_desc(view(B, 19, 19, 256), view(B, 19, 19, 1024), 256, 1024, 1, 1, 0, 1, wC=256)) == []
     strided_out = ops.TView(torch.empty(1), B, 64, 128, [ops.Level(0, H, W, H * W * 128)])      # pixel stride 128: still dense rows
     assert ops.pw_cands(ops.fwd_desc(view(B, H, W, 64), strided_out, 64, 64, 1, 1, 0, 1, wC=64)) != []
     dg = ops.dgrad_desc(view(B, H, W, 256), view(B, H, W, 64), 256, 64, 1, 1, 0, 1)

@@ -30,6 +30,8 @@ CASES = [
     (2, 256, 64, 19, 19, 1, 1, True, True, "igemm", (32, 64, 0)),
     (3, 64, 256, 10, 13, 1, 1, True, False, "igemm", (32, 32, 0)),
     (2, 64, 64, 21, 21, 1, 1, False, True, "igemm", (32, 64, 0)),
+    (2, 512, 128, 19, 19, 1, 1, True, True, "igemm", (32, 128, 0)),        # four filter panels (column blocks)
+    (16, 512, 128, 38, 38, 1, 1, False, True, "igemm", (32, 64, 0)),       # layer2 conv1's data gradient at the bench shape
     (16, 256, 64, 75, 75, 1, 1, True, True, "igemm", (32, 128, 0)),       # layer1 conv1's data gradient at the bench shape
     (16, 64, 256, 75, 75, 1, 1, False, True, "igemm", (32, 32, 0)),       # layer1 conv3's
     # many partial rows (100 / 200)
@@ -96,7 +98,7 @@ def test_dgrad_with_bn_backward_sums(Z, case):
         if bm != 32:
             assert chunks == sum((B * d0.seg[i].rows_y * d0.seg[i].rows_x + bm - 1) // bm for i in range(d0.nseg))
         else:
-            assert 0 < chunks <= 256
+            assert 0 < chunks <= 256 and (Ci < 512 or chunks <= 64)
     L.check(fn_plain(C.byref(d0), dyd.data_ptr(), wop.data_ptr(), dx0.data_ptr(), None, dx0.data_ptr() if acc else None, None, None, st), "plain dgrad")
     dx1 = fresh()
     d1 = ops.dgrad_desc(dyv, view_of(ops, dx1, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)

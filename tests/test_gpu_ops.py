@@ -249,6 +249,9 @@ PW_CASES = [
     (2, 64, 64, 21, 21),
     (1, 128, 128, 37, 41),       # two K chunks, N = one 128-wide unit
     (5, 64, 192, 30, 30),        # N = 192 = 3 or 6 units: not a geometry of the kernel — the hint must be refused
+    (2, 128, 512, 19, 19),       # filter cut into 4 panels of 128 rows (one per workgroup column block); dgrad: 512 -> 128 in panels of 32
+    (1, 256, 128, 20, 21),       # 2 panels of 64 rows
+    (16, 128, 512, 38, 38),      # layer2 conv3 at the bench shape: 64 row groups x 4 column blocks
     (16, 64, 256, 75, 75),       # layer1 conv3 at the bench shape: 2-3 units per wave, next-unit prefetch across units
     (16, 256, 64, 75, 75),       # layer1 conv1
 ]
@@ -297,7 +300,10 @@ def test_conv_pw_streaming(Z, case):
         # fused BatchNorm statistics
         d2 = ops.fwd_desc(src, ov, Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=hint)
         chunks = ops.igemm_partial_rows(d2)
-        assert chunks == min(256, ((rows + 31) // 32 * (Co // ((hint >> 8) & 0xff)) + 7) // 8)
+        uw = (hint >> 8) & 0xff
+        ncb = next(c for c in (1, 2, 4, 8) if Co % c == 0 and (Co // c) % uw == 0 and (Co // c) // uw in (1, 2, 4, 8)
+                   and ((Co // c) * (Ci + 4) + 8 * 32 * 68) * 4 <= 160 * 1024)          # filter panels (column blocks of the grid)
+        assert chunks == min(256 // ncb, ((rows + 31) // 32 * (Co // ncb // uw) + 7) // 8)
         part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
         out.fill_(float("nan"))
         L.check(L.lib.zsg_conv_igemm(C.byref(d2), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "pw fwd+stats")

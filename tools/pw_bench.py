@@ -16,7 +16,7 @@ from tools.igemm_model import t_single
 
 def main():
     st = stream_ptr()
-    shapes = ((90000, 64, 256), (90000, 256, 64), (90000, 64, 64), (23104, 128, 128), (23104, 64, 128))
+    shapes = ((90000, 64, 256), (90000, 256, 64), (90000, 64, 64), (23104, 128, 512), (23104, 512, 128), (90000, 256, 128), (5776, 256, 1024))
     if os.environ.get("SHAPES"):                     # e.g. SHAPES="90000x64x256"
         shapes = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(","))
     print("time of ONE launch in us (median of 15, device idle before each); '+st' = with fused BatchNorm statistics")

@@ -38,13 +38,14 @@ struct PwParams {
     const float* bias;
     const float* add_src;
     const float* mask_src;
-    float* stats;         // [gridDim.x][2][N] partial rows (BatchNorm statistics, or BatchNorm-backward sums when bnb.x)
+    float* stats;         // [row groups][2][N] partial rows (BatchNorm statistics, or BatchNorm-backward sums when bnb.x)
     BnbDev bnb;
     int M, K, N;
     int src_ld, out_ld, wt_ld, wc0;
     int src_off, out_off;
     int relu;
-    int NS;               // column splits: N = NS x 32 NJ
+    int NS;               // column splits of a workgroup's panel: NB = NS x 32 NJ
+    int NCB, NB;          // column blocks: the filter is cut into NCB panels of NB = N / NCB rows, one per workgroup
     int rt;               // row tiles: ceil(M / 32)
     int ns_shift;         // log2(NS)
 };
@@ -91,18 +92,32 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K, LDW = K + 4;         // filter row pitch: K/4 + 1 16-byte units (odd for K = 64, 128, 256 ...)
-    float* Ws = smem;                                        // [N][LDW]
-    float* Tb = smem + p.N * LDW + wave * (32 * PW_TB);      // this wave's [32][PW_TB]
+    float* Ws = smem;                                        // [NB][LDW]
+    float* Tb = smem + p.NB * LDW + wave * (32 * PW_TB);     // this wave's [32][PW_TB]
     const int li = lane & 31, lh = lane >> 5;                // MFMA fragment coordinates
     const int cg = lane & 15, rr = lane >> 4;                // staging / epilogue coordinates: 16-byte column group, row class
-    // Units: row tile rt = blockIdx.x + gridDim.x * j belongs to this workgroup (j = 0, 1, ..), its NS column splits are the
+    // Units: row tile rt = rgid + RG * j belongs to this workgroup's row group (j = 0, 1, ..), its NS column splits are the
     // workgroup's local units l = j * NS + ns, and wave w takes l = w, w + 8, ..: every workgroup gets the same number of row tiles
     // (+-1), a SIMD (waves s and s + 4) the same number of units (+-1), a wave keeps its column split (8 % NS == 0), and both
     // splits of a row tile read the source rows from the same CU's L1 / the same XCD's L2.
-    const int G = gridDim.x, RT = p.rt, nsh = p.ns_shift;
-    auto tile_of = [=](int l) { return (int)blockIdx.x + G * (l >> nsh); };
+    // Column blocks (NCB > 1: the filter does not fit as a whole): gridDim.x = RG x NCB, the NCB workgroups of a row group walk the
+    // same row tiles, each against its own panel of NB filter rows — on the same XCD where the grid allows (blockIdx % 8 picks the
+    // XCD), so that the source rows are fetched into one L2.
+    const int RT = p.rt, nsh = p.ns_shift, NCB = p.NCB, NB = p.NB;
+    const int RG = (int)gridDim.x / NCB;
+    int cb, rgid;
+    if ((int)gridDim.x % (ZSG_NUM_XCD * NCB) == 0) {
+        const int k = (int)blockIdx.x / ZSG_NUM_XCD;
+        cb = k % NCB;
+        rgid = (int)blockIdx.x % ZSG_NUM_XCD + ZSG_NUM_XCD * (k / NCB);
+    } else {
+        cb = (int)blockIdx.x % NCB;
+        rgid = (int)blockIdx.x / NCB;
+    }
+    auto tile_of = [=](int l) { return rgid + RG * (l >> nsh); };
     const int NS = p.NS;
-    const int n0 = (wave % NS) * UW;
+    const int n0l = (wave % NS) * UW;                        // this wave's columns: within the panel,
+    const int n0 = cb * NB + n0l;                            // and of the output
     const int nkc = K >> 6;
     const int M = p.M;
     const rsrc_t rs = make_rsrc(p.src);
@@ -146,14 +161,14 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
 
     {   // the filter panel, once per workgroup: eight 16-byte loads in flight per thread
         const rsrc_t rw = make_rsrc(p.wt);
-        const int kg = K >> 2, total = p.N * kg;
+        const int kg = K >> 2, total = NB * kg;
         for (int base = 0; base < total; base += 8 * 64 * PW_WAVES) {
             f32x4 t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int idx = base + tid + j * 64 * PW_WAVES;
                 const int n = idx / kg, g = idx - n * kg;
-                t[j] = buf_load4(rw, idx < total ? 4u * (unsigned)(n * p.wt_ld + p.wc0 + 4 * g) : ZSG_OOB);
+                t[j] = buf_load4(rw, idx < total ? 4u * (unsigned)((cb * NB + n) * p.wt_ld + p.wc0 + 4 * g) : ZSG_OOB);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
         pw_wave_sync();
         {
             const float* a = Tb + li * PW_TB + 4 * lh;
-            const float* b = Ws + (n0 + li) * LDW + kc * 64 + 4 * lh;
+            const float* b = Ws + (n0l + li) * LDW + kc * 64 + 4 * lh;
             if constexpr (NJ <= 2) {
                 // few MFMAs per fragment set: the reads of kq + 1 are issued ahead of kq's MFMAs
                 f32x4 fa = PW_FRAG(a), fb[NJ];
@@ -371,14 +386,14 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
             }
         }
         __syncthreads();
-        for (int n = tid; n < p.N; n += 64 * PW_WAVES) {
+        for (int n = tid; n < NB; n += 64 * PW_WAVES) {      // (n: column within the panel)
             const int ns = n / UW, cl = n - ns * UW;
             float a = 0.f, b = 0.f;
             for (int w = ns; w < PW_WAVES; w += NS) {
                 a += red[(w * 2 + 0) * UW + cl];
                 b += red[(w * 2 + 1) * UW + cl];
             }
-            float* o = p.stats + (size_t)blockIdx.x * 2 * p.N;
+            float* o = p.stats + (size_t)rgid * 2 * p.N + cb * NB;
             o[n] = a;
             o[p.N + n] = b;
         }
@@ -388,8 +403,9 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
 // ---- host side ------------------------------------------------------------------------------------------------------------
 
 // geometry the kernel covers: ONE dense 1x1 / stride-1 segment (row m of the GEMM = pixel m of both tensors), K a multiple of 64,
-// N = 1, 2, 4 or 8 units of `uw` columns, filter + eight tile buffers within the CU's LDS
-static bool pw_geometry_ok(const zsg_conv_desc* d, int uw, const char** why) {
+// the filter cut into ncb = 1, 2, 4 or 8 panels of nb = N / ncb rows such that a panel + the eight tile buffers fit the CU's LDS
+// and a panel is 1, 2, 4 or 8 units of `uw` columns (the smallest such ncb is used)
+static bool pw_geometry_ok(const zsg_conv_desc* d, int uw, const char** why, int* ncb_out = nullptr) {
     static const char* msg;
     const char*& w = why ? *why : msg;
     if (d->nseg != 1 || d->merge_x) { w = "one segment, no merge_x"; return false; }
@@ -405,30 +421,41 @@ static bool pw_geometry_ok(const zsg_conv_desc* d, int uw, const char** why) {
     }
     if (uw != 32 && uw != 64 && uw != 128) { w = "unit width 32 / 64 / 128"; return false; }
     if (d->C <= 0 || (d->C % 64) != 0 || d->N <= 0 || (d->N % uw) != 0) { w = "C % 64 == 0 and N % unit width == 0"; return false; }
-    const int ns = d->N / uw;
-    if (ns != 1 && ns != 2 && ns != 4 && ns != 8) { w = "N = 1, 2, 4 or 8 units"; return false; }
-    if (((size_t)d->N * (d->C + 4) + (size_t)PW_WAVES * 32 * PW_TB) * sizeof(float) > PW_LDS_MAX) { w = "filter does not fit the LDS"; return false; }
+    int ncb = 0;
+    for (int c = 1; c <= 8 && !ncb; c *= 2) {
+        if (d->N % c) break;
+        const int nb = d->N / c;
+        if (nb % uw) break;
+        const int ns = nb / uw;
+        if ((ns == 1 || ns == 2 || ns == 4 || ns == 8) && ((size_t)nb * (d->C + 4) + (size_t)PW_WAVES * 32 * PW_TB) * sizeof(float) <= PW_LDS_MAX) ncb = c;
+    }
+    if (!ncb) { w = "a filter panel of 1, 2, 4 or 8 units (N / 1, 2, 4 or 8 rows) that fits the LDS"; return false; }
     if ((d->src_ld % 4) || (d->out_ld % 4) || (s.src_off % 4) || (s.out_off % 4) || (d->wt_ld % 4) || (d->wc0 % 4)) { w = "16-byte aligned rows"; return false; }
     const int64_t rows = (int64_t)d->B * s.rows_y * s.rows_x;
     if (rows <= 0 || rows >= (1ll << 30) || s.src_off + rows * d->src_ld >= (1ll << 29) || s.out_off + rows * d->out_ld >= (1ll << 29)) {
         w = "tensor exceeds 2^29 elements";
         return false;
     }
+    if (ncb_out) *ncb_out = ncb;
     return true;
 }
 
-static int pw_grid(const zsg_conv_desc* d, int uw) {
+// row groups of a launch (= rows of BatchNorm partials it writes); the grid is row groups x column blocks, at most one workgroup per CU
+static int pw_row_groups(const zsg_conv_desc* d, int uw, int ncb) {
     const int64_t rows = (int64_t)d->B * d->seg[0].rows_y * d->seg[0].rows_x;
-    const int units = cdiv(rows, 32) * (d->N / uw);
-    const int g = cdiv(units, PW_WAVES);
-    return g < ZSG_NUM_CU ? g : ZSG_NUM_CU;
+    const int units = cdiv(rows, 32) * (d->N / ncb / uw);      // per column block
+    const int g = cdiv(units, PW_WAVES), gmax = ZSG_NUM_CU / ncb;
+    return g < gmax ? g : gmax;
 }
 
 // rows of BatchNorm partials a zsg_conv_igemm / zsg_conv_igemm_bnb launch with this descriptor (and its tile_hint) writes
 extern "C" int32_t zsg_conv_igemm_partial_rows(const zsg_conv_desc* d) {
     if (!d || !d->tile_hint) return -1;
     const int bm = d->tile_hint & 0xff, bn = (d->tile_hint >> 8) & 0xff;
-    if (bm == 32) return pw_geometry_ok(d, bn, nullptr) ? pw_grid(d, bn) : -1;
+    if (bm == 32) {
+        int ncb = 0;
+        return pw_geometry_ok(d, bn, nullptr, &ncb) ? pw_row_groups(d, bn, ncb) : -1;
+    }
     if (bm <= 0) return -1;
     int64_t t = 0;
     for (int s = 0; s < d->nseg; ++s) t += cdiv((int64_t)d->B * d->seg[s].rows_y * d->seg[s].rows_x, bm);
@@ -459,7 +486,8 @@ static int pw_launch1(const PwParams& p, int grid, size_t lds, hipStream_t st, d
 int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
                        const float* mask_src, float* bn_partials, const BnbDev* bnb, hipStream_t st) {
     const char* why = "";
-    ZSG_REQUIRE(pw_geometry_ok(d, uw, &why), "conv_igemm: the streaming 1x1 kernel (tile_hint BM = 32) needs %s", why);
+    int ncb = 0;
+    ZSG_REQUIRE(pw_geometry_ok(d, uw, &why, &ncb), "conv_igemm: the streaming 1x1 kernel (tile_hint BM = 32) needs %s", why);
     const uintptr_t al = (uintptr_t)src | (uintptr_t)wt | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)add_src | (uintptr_t)mask_src;
     ZSG_REQUIRE((al & 15) == 0, "conv_igemm: the streaming 1x1 kernel needs 16-byte aligned operands");
     PwParams p;
@@ -470,7 +498,9 @@ int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const f
     p.K = d->C; p.N = d->N; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.wt_ld = d->wt_ld;
     p.wc0 = d->wc0 + (s.ty.w0 * d->wS + s.tx.w0) * d->wC;          // (the one tap's position in a weight row)
     p.src_off = (int)s.src_off; p.out_off = (int)s.out_off; p.relu = d->relu;
-    p.NS = d->N / uw;
+    p.NCB = ncb;
+    p.NB = d->N / ncb;
+    p.NS = p.NB / uw;
     p.rt = cdiv(p.M, 32);
     p.ns_shift = p.NS == 8 ? 3 : p.NS == 4 ? 2 : p.NS == 2 ? 1 : 0;
     if (bnb) {
@@ -480,8 +510,8 @@ int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const f
     } else if (bn_partials) {
         ZSG_REQUIRE(!bias && !add_src && !d->relu && !mask_src, "conv_igemm: BN-statistics fusion needs a plain (bias-free) convolution");
     }
-    const int grid = pw_grid(d, uw);
-    const size_t lds = ((size_t)d->N * (d->C + 4) + (size_t)PW_WAVES * 32 * PW_TB) * sizeof(float);
+    const int grid = pw_row_groups(d, uw, ncb) * ncb;
+    const size_t lds = ((size_t)p.NB * (d->C + 4) + (size_t)PW_WAVES * 32 * PW_TB) * sizeof(float);
     const double flops = 2.0 * p.M * (double)d->N * d->C;
     if (uw == 128) return pw_launch1<4>(p, grid, lds, st, flops, "pw_kernel<4, 0>", "pw_kernel<4, 1>", "pw_kernel<4, 2>");
     if (uw == 64) return pw_launch1<2>(p, grid, lds, st, flops, "pw_kernel<2, 0>", "pw_kernel<2, 1>", "pw_kernel<2, 2>");

@@ -609,14 +609,14 @@ def wino_default_hint(d: ConvDesc) -> int:
 
 def pw_cands(d: ConvDesc) -> list:
     """tile hints (BM = 32, BN = unit width) of the filter-resident streaming kernel (csrc/pw.hip) for a 1x1 / stride-1 convolution
-    whose filter fits a CU's LDS next to the eight wave buffers; the library checks the geometry again (zsg_conv_igemm_partial_rows
-    returns -1 where the kernel does not apply)."""
-    if d.nseg != 1 or d.merge_x or d.C % 64 or (d.N * (d.C + 4) + 8 * 32 * 68) * 4 > 160 * 1024:
+    whose filter — whole, or cut into 2 / 4 / 8 panels of output channels — fits a CU's LDS next to the eight wave buffers; the
+    library decides (zsg_conv_igemm_partial_rows returns -1 where the kernel does not apply)."""
+    if d.nseg != 1 or d.merge_x or d.C % 64:
         return []
     out = []
     keep = d.tile_hint
     for uw in (32, 64, 128):
-        if d.N % uw == 0 and d.N // uw in (1, 2, 4, 8):
+        if d.N % uw == 0:
             d.tile_hint = tile_hint(32, uw, 1)
             if lib.zsg_conv_igemm_partial_rows(C.byref(d)) > 0:
                 out.append(d.tile_hint)
