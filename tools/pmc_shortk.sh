@@ -10,7 +10,9 @@ run() {
   rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC -d $OUT/${tag}_c --output-format csv -- python $R/tools/one_conv.py "$@" > /dev/null 2>&1
 }
 run l1conv3_128x128w $1 fwd 128 128 1 0 0
-run l1conv3_64x64 $1 fwd 64 64 0 0 0
+[ -z "$PW_ONLY" ] && run l1conv3_64x64 $1 fwd 64 64 0 0 0
+run l1conv3_pw64 $1 fwd 32 64 0 0 0        # the filter-resident streaming kernel (csrc/pw.hip): tile_hint BM = 32
+run l1conv3_pw128 $1 fwd 32 128 0 0 0
 cd $R && python - "$OUT" <<'PY' | tee $OUT/counters.txt
 import csv, glob, os, sys, collections
 out = sys.argv[1]
@@ -20,7 +22,7 @@ for d in sorted(glob.glob(out + "/*_[abc]")):
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
-            if "igemm_kernel" in r["Kernel_Name"]:
+            if "igemm_kernel" in r["Kernel_Name"] or "pw_kernel" in r["Kernel_Name"]:
                 a = agg[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
         for k, (n, v) in agg.items():
             res.setdefault(tag, {})[k] = v / n
