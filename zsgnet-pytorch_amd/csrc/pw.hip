@@ -1,36 +1,43 @@
-// pw.hip — filter-resident streaming kernel for the 1x1 / stride-1 convolutions whose whole filter fits a CU's LDS: the
-// bottleneck 1x1 layers of the trunk's first stage (fpn_resnet.py:66-72,86-100: conv1 64/256 -> 64, conv3 64 -> 256, the
-// projection shortcut 64 -> 256, at M = B x 75 x 75 pixels), forward and data gradient, fp32 MFMA, gfx950.
+// pw.hip — filter-resident streaming kernel for the 1x1 / stride-1 convolutions whose filter (whole, or cut into 2 / 4 / 8
+// panels of output channels) fits a CU's LDS: the bottleneck 1x1 layers of the trunk's first stages (fpn_resnet.py:66-72,86-100:
+// layer1's conv1 64/256 -> 64, conv3 64 -> 256 and projection shortcut 64 -> 256 at M = B x 75 x 75 pixels; layer2's conv3
+// 128 -> 512 at M = B x 38 x 38), forward and data gradient, fp32 MFMA, gfx950.  Reached through zsg_conv_igemm /
+// zsg_conv_igemm_bnb with tile_hint BM = 32 (BN = unit width); the host autotuner times it next to the implicit-GEMM tiles.
 //
 // Why a kernel of its own.  As tiles of the implicit GEMM (igemm.hip) these launches run at HALF their roofline (DESIGN 8,
 // profiles/r03_shortk_gemm.txt: 64 -> 256 takes 47-51 us for 18.7 us of MFMA work and ~21 us of HBM traffic): a block lives for
 // two K steps, so its prologue, two latency-exposed tile loads, three barriers and the LDS-transposed epilogue are paid per 64
 // MFMAs per wave and nothing overlaps them.  Here a workgroup is PERSISTENT (one per CU) and its eight waves are AUTONOMOUS:
-//   * the filter [N][K] (64 KB) is parked in LDS once per workgroup;
+//   * the filter panel [NB][K] (<= 67 KB) is parked in LDS once per workgroup;
 //   * a wave walks "units" of 32 pixel rows x (32 NJ) output channels.  It stages its own 32 x 64 slice of the source through a
 //     wave-private LDS buffer (coalesced 16-byte loads -> ds_write_b128 -> ds_read_b128 fragments: the LDS queue of a wave is
 //     in-order, so no barrier — not even a workgroup one — separates its writes from its reads), multiplies it against the
-//     resident filter, transposes the accumulators through the same buffer and stores whole 256-byte row runs;
-//   * the loads of the next slice are in flight during the MFMAs, and since no barrier ties the waves together they drift apart:
-//     the two waves of a SIMD interleave one's loads / stores with the other's MFMAs.
+//     resident panel, transposes the accumulators through the same buffer and stores whole 256-byte row runs;
+//   * the loads of the next slice(s) are in flight during the MFMAs, and no barrier ties the waves together.
 // The MFMA operands are swapped against igemm.hip (filter rows first): the 32x32 accumulator of lane (i, h) then holds, for
 // PIXEL i, the output channels 8 q + 4 h .. + 3 (q = 0..3) — four consecutive channels per register quad, i.e. the transposition
-// writes 16-byte units.
+// writes 16-byte units.  The K sum of an output runs in the same order as in the 64x64 tile: results are bit-identical to it.
 //
 // Epilogue terms, BatchNorm-statistics partials and BatchNorm-backward partials are those of igemm.hip's vectorised epilogue,
-// with ONE partial row per workgroup (a wave accumulates over all its units, the workgroup reduces its waves in a fixed order:
-// deterministic): zsg_conv_igemm_partial_rows() tells the caller how many rows a launch writes.
+// with ONE partial row per workgroup row group (a wave accumulates over all its units, the workgroup reduces its waves in a fixed
+// order: deterministic): zsg_conv_igemm_partial_rows() tells the caller how many rows a launch writes.
+//
+// Measured (profiles/r03_pw_microbench.txt, _ablation.txt, _pmc.txt, _ab.txt): 64 -> 256 @ M = 90000 51.6 -> 39.7 us per launch
+// (MFMA pipe busy 0.365 -> 0.445), 128 -> 512 @ M = 23104 39.5 -> 35.2; the input-dominated 256 -> 64 only ties (39.9 vs 39.8);
+// the training step 14.01 -> 13.91 ms.  What is left (ablation): ~14 us of launch latency + panel prologue + loop skeleton, and an
+// MFMA phase (19.3 us) that ADDS to the 7.6 us of loads + stores of the SIMD's other wave instead of hiding them.
 #include "common.h"
 
 // PW_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong) — 1 no MFMAs, 2 no output stores,
-// 4 no fragment reads, 8 no source loads in the streaming loop, 16 no partial-row reduction at the end, 32 no per-row statistics.  tools/pw_ablation.sh builds one library per value.
+// 4 no fragment reads, 8 no source loads in the streaming loop, 16 no partial-row reduction at the end, 32 no per-row statistics.
+// tools/pw_ablation.sh builds one library per value.
 #ifndef PW_ABL
 #define PW_ABL 0
 #endif
 #define PW_TB 68          // floats per row of a wave's tile buffer: 64 + 4 = 17 x 16 B (odd: conflict-free b128 rows)
 #define PW_WAVES 8
 #define PW_LDS_MAX (160 * 1024)
-#define PW_STAGGER_DEFAULT 0
+#define PW_STAGGER_DEFAULT 0     // (start offsets measured: no gain — see pw_kernel; the switch stays for experiments)
 #include <stdlib.h>
 
 struct PwParams {
