@@ -498,8 +498,9 @@ static int pw_launch1(const PwParams& p, int grid, size_t lds, hipStream_t st, d
 }
 
 // called by conv_igemm_impl (igemm.hip) for tile_hint BM == 32: uw = the hint's BN field
-int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
+int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw_hint, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
                        const float* mask_src, float* bn_partials, const BnbDev* bnb, hipStream_t st) {
+    int uw = uw_hint;
     const char* why = "";
     int ncb = 0;
     ZSG_REQUIRE(pw_geometry_ok(d, uw, &why, &ncb), "conv_igemm: the streaming 1x1 kernel (tile_hint BM = 32) needs %s", why);
@@ -539,7 +540,15 @@ int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const f
     } else if (bn_partials) {
         ZSG_REQUIRE(!bias && !add_src && !d->relu && !mask_src, "conv_igemm: BN-statistics fusion needs a plain (bias-free) convolution");
     }
-    const int grid = pw_row_groups(d, uw, ncb) * ncb;
+    const int grid = pw_row_groups(d, uw, ncb) * ncb;      // (from the hint's unit width: what zsg_conv_igemm_partial_rows promised)
+    // BatchNorm-backward partials with 128-channel units: x / add / bits of a pass + 64 accumulator registers do not fit next to
+    // each other (the half-batch form of MODE 2 measured 105 us where the 64-channel units take 51) — run the 64-channel units on
+    // the SAME grid (the unit dealing works for any grid; the row count of the partials is unchanged).
+    if (bnb && uw == 128 && p.NS * 2 <= 8) {
+        uw = 64;
+        p.NS *= 2;
+        p.ns_shift += 1;
+    }
     const size_t lds = ((size_t)p.NB * (d->C + 4) + (size_t)PW_WAVES * 32 * PW_TB) * sizeof(float);
     const double flops = 2.0 * p.M * (double)d->N * d->C;
     if (uw == 128) return pw_launch1<4>(p, grid, lds, st, flops, "pw_kernel<4, 0>", "pw_kernel<4, 1>", "pw_kernel<4, 2>");
