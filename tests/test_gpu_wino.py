@@ -40,6 +40,17 @@ WINO_CASES = [
     (1, 516, 256, 5, 5, True, True, 32, 32, 1 + 256),
     (2, 512, 96, 10, 10, True, False, 64, 64, 4 + 256),
     (16, 64, 64, 38, 38, False, False, 64, 64, 1 + 256),
+    # pipeline fill / drain and channel tails of the K loop: 1, 2, 3, 5 chunks of 8 channels, C % 8 == 4 (last chunk half dead)
+    (2, 8, 64, 9, 9, False, False, 32, 64, 1 + 256),
+    (2, 16, 64, 9, 9, True, True, 32, 64, 1 + 256),
+    (2, 24, 128, 7, 10, False, False, 64, 64, 1 + 256),
+    (3, 40, 64, 7, 10, True, False, 32, 64, 1),
+    (2, 12, 64, 9, 9, True, False, 32, 64, 1 + 256),
+    (2, 20, 64, 9, 9, False, False, 64, 64, 1 + 256),
+    (1, 516, 256, 5, 5, True, True, 32, 64, 1 + 256),
+    (2, 256, 45, 10, 10, True, False, 32, 64, 1 + 256),
+    (2, 512, 96, 10, 10, True, False, 32, 64, 4 + 256),
+    (4, 256, 256, 19, 19, False, False, 32, 64, 1 + 256),
 ]
 
 
@@ -47,7 +58,7 @@ WINO_CASES = [
 def test_wino_fwd_dgrad(Z, case):
     L, ops = Z
     B, Ci, Co, H, W, bias, relu, TB, BN, splits = case
-    ps4, splits = splits >> 8, splits & 0xff
+    ps4, splits = (splits >> 8) & 1, splits & 0xff
     g = torch.Generator().manual_seed(7 + Ci + Co + H)
     x = torch.randn(B, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5

@@ -29,6 +29,7 @@ int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const f
 #define ZSG_WAVE 64
 #define ZSG_NUM_CU 256
 #define ZSG_NUM_XCD 8
+#define ZSG_MAX_DEV 64      // per-device caches of kernel attributes (one process may drive several GPUs)
 
 // ---- error plumbing -------------------------------------------------------------------------------------------
 void zsg_set_error(const char* fmt, ...);

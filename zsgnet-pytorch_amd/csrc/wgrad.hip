@@ -165,11 +165,11 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
             const bool rok = live & (r < sg.rows);
             const int rr = rok ? r : 0;
             int b = fdiv(rr, per, sg.inv_per);
-            int rem = rr - b * per;
+            int rem = rr - mul24(b, per);
             int y = fdiv(rem, sg.rows_x, sg.inv_rx);
-            int x = rem - y * sg.rows_x;
-            const unsigned off = 4u * (unsigned)(sg.out_off + b * sg.out_bstride +
-                                                  ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld + na);
+            int x = rem - mul24(y, sg.rows_x);
+            const unsigned off = 4u * (unsigned)(sg.out_off + mul24(b, sg.out_bstride) +
+                                                  mul24(mul24(mul24(y, sg.osy) + sg.opy, sg.out_W) + (mul24(x, sg.osx) + sg.opx), p.out_ld) + na);
             if (AVEC) {
                 ra[j] = buf_load4(rs_a, (rok & a_colok) ? off : ZSG_OOB);
             } else {                                                  // rows not 16-byte addressable (out_ld % 4 != 0)
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
             const bool rok = live & (r < sg.rows);
             const int rr = rok ? r : 0;
             int b = fdiv(rr, per, sg.inv_per);
-            int rem = rr - b * per;
+            int rem = rr - mul24(b, per);
             int y = fdiv(rem, sg.rows_x, sg.inv_rx);
-            int x = rem - y * sg.rows_x;
-            const int yy = y * sg.sy + b_dy, xx = x * sg.sx + b_dx;
+            int x = rem - mul24(y, sg.rows_x);
+            const int yy = mul24(y, sg.sy) + b_dy, xx = mul24(x, sg.sx) + b_dx;
             const bool ok = rok & b_colok & ((unsigned)yy < (unsigned)sg.src_H) & ((unsigned)xx < (unsigned)sg.src_W);
-            const unsigned off = 4u * (unsigned)(sg.src_off + b * sg.src_bstride + (yy * sg.src_W + xx) * p.src_ld + b_c);
+            const unsigned off = 4u * (unsigned)(sg.src_off + mul24(b, sg.src_bstride) + mul24(mul24(yy, sg.src_W) + xx, p.src_ld) + b_c);
             rb[j] = buf_load4(rs_b, ok ? off : ZSG_OOB);
         }
         ++kt_next;
@@ -321,6 +321,10 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
         ZSG_REQUIRE(a.src_off + (int64_t)d->B * a.src_bstride < (1ll << 29) && a.out_off + (int64_t)d->B * a.out_bstride < (1ll << 29),
                     "conv_wgrad: tensor exceeds 2^29 elements (2 GB window)");
         ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0, "conv_wgrad: seg %d source not 16-byte aligned", s);
+        // the loader multiplies with 24-bit operands (mul24, wgrad_common.h)
+        ZSG_REQUIRE(a.src_bstride < (1 << 23) && a.out_bstride < (1 << 23) && d->src_ld < (1 << 23) && d->out_ld < (1 << 23) &&
+                        (int64_t)a.src_H * a.src_W < (1 << 23) && (int64_t)(a.rows_y * a.osy + a.opy + 1) * a.out_W < (1 << 23),
+                    "conv_wgrad: seg %d: an image stride / pixel count exceeds 2^23", s);
         WgSegDev& o = p.seg[s];
         o.rows_y = a.rows_y; o.rows_x = a.rows_x; o.rows = (int)rows; o.kt0 = kt;
         o.src_H = a.src_H; o.src_W = a.src_W; o.sy = a.sy; o.sx = a.sx;

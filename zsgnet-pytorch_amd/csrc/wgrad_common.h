@@ -26,9 +26,19 @@ struct WgParams {
     WgSegDev seg[ZSG_MAX_SEG];
 };
 
+// 24-bit integer multiply (v_mul_i32_i24 / v_mad_i32_i24: full rate; a 32-bit v_mul_lo_u32 is quarter rate, and next to fp32 MFMAs
+// every VALU cycle of the K loop is paid in full, tools/ubench/mfma_coissue.hip).  Both operands must fit 24 signed bits — row and
+// pixel counts, image strides and row pitches do (checked by the host); the 32-bit result is exact.
+// (inline asm: the compiler lowers __mul24 with a wave-uniform operand to s_bfe_i32 + the quarter-rate v_mul_lo_u32.)
+__device__ __forceinline__ int mul24(int a, int b_uniform) {     // a: per-lane, b_uniform: wave-uniform (kernel argument / segment field)
+    int r;
+    asm("v_mul_i32_i24 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+
 __device__ __forceinline__ int fdiv(int a, int d, float rcp) {   // a < 2^24, exact after one correction step
     int q = (int)((float)a * rcp);
-    int r = a - q * d;
+    int r = a - mul24(q, d);
     q += (r >= d) ? 1 : 0;
     q -= (r < 0) ? 1 : 0;
     return q;

@@ -24,6 +24,12 @@
 #include "common.h"
 
 #define WN_CK 8
+// WN_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong): 1 = every patch load of a lane hits
+// one cache line, 2 = the filter chunk is always chunk 0 (L2-resident), 4 = no MFMAs, 8 = no fragment reads, 16 = no patch loads /
+// transform, 32 = no filter DMA.  tools/wino_ablation.sh builds one library per value.
+#ifndef WN_ABL
+#define WN_ABL 0
+#endif
 
 struct WnSegDev {
     int tiles_y, tiles_x, tiles;   // tile grid per image; tiles = B * tiles_y * tiles_x
@@ -100,7 +106,13 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
 
     // ---- loader state (fixed over the K loop) ------------------------------------------------------------------------
     const int q = tid & 3, g = (tid >> 2) & 1;
-    int a_base[IA], a_mask[IA], a_lds[IA];
+    // Loop-invariant per-lane byte offsets (zero padding = out-of-range offset, baked in); the chunk's channel offset travels in an
+    // SGPR (the buffer instructions' soffset), so a load costs NO address arithmetic in the K loop.  On gfx950 nothing co-issues
+    // with a SIMD's fp32 MFMA stream (tools/ubench/mfma_coissue.hip: a partner wave retires ~0 instructions while its SIMD mate
+    // multiplies, a wave's own VALU costs ~6 cycles each on top of its MFMAs), so every instruction of this loop is paid in full.
+    unsigned a_voff[IA][4], a_voff_t[IA][4];       // a_voff_t: the last chunk of a C % 8 == 4 tensor (its upper channel quad is dead)
+    int a_lds[IA], a_mask[IA];
+    const bool c_tail = (p.C & 4) != 0;
 #pragma unroll
     for (int ia = 0; ia < IA; ++ia) {
         const int t = ((tid + NT * ia) >> 3) % TB;
@@ -114,11 +126,15 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
         const int tx = rem - ty * sg.tiles_x;
         const int y = 2 * ty - 1 + q, x0 = 2 * tx - 1;
         const bool rok = ok & ((unsigned)y < (unsigned)sg.H);
-        int mask = 0;
+        const int base = sg.src_off + b * sg.src_bstride + (y * sg.W + x0) * src_ld + 4 * g;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mask |= (rok & ((unsigned)(x0 + c) < (unsigned)sg.W)) ? (1 << c) : 0;
-        a_mask[ia] = mask;
-        a_base[ia] = sg.src_off + b * sg.src_bstride + (y * sg.W + x0) * src_ld + 4 * g;
+        for (int c = 0; c < 4; ++c) {
+            const bool pok = rok & ((unsigned)(x0 + c) < (unsigned)sg.W);
+            if (c == 0) a_mask[ia] = 0;
+            a_mask[ia] |= pok ? (1 << c) : 0;
+            a_voff[ia][c] = pok ? 4u * (unsigned)((WN_ABL & 1) ? 4 * (tid & 7) : base + c * src_ld) : ZSG_OOB;
+            a_voff_t[ia][c] = (pok && !(c_tail && g)) ? a_voff[ia][c] : ZSG_OOB;
+        }
         a_lds[ia] = q * SA + t * 8 + 4 * (g ^ ((t >> 3) & 1));
         if (q == 0 && g == 0 && a_thr) {
             rowinfo[2 * t] = ok ? sg.out_off + b * sg.out_bstride + ((2 * ty) * sg.W + 2 * tx) * p.out_ld : -1;
@@ -127,14 +143,18 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     }
     // B loader: LDS-DMA (buffer_load ... lds): one wave-instruction lands 1 KB = 32 rows of one position, lane-linear, so
     // the row swizzle is applied on the SOURCE side (lane l fills slot (row l>>1, half l&1) with half (l&1)^swz(row)).
-    int b_src[IB], b_dst[IB];
+    // The LDS destination is wave-uniform by construction: computed from a readfirstlane'd wave index so that it lives in SGPRs
+    // (M0 is then one s_add away, no v_readfirstlane per piece).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned b_voff[IB];
+    int b_dst[IB];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) {
-        const int kb = wave + (NT / 64) * ib;          // 1 KB piece index: pos * (BN/32) + row group
+        const int kb = wave_u + (NT / 64) * ib;        // 1 KB piece index: pos * (BN/32) + row group
         const int pos = kb / (BN / 32), rg = kb % (BN / 32);
         const int r = rg * 32 + (lane >> 1);
-        b_src[ib] = (pos * p.Npad + n0 + r) * 8 + 4 * ((lane & 1) ^ ((r >> 3) & 1));
-        b_dst[ib] = pos * SB + rg * 256;               // floats, wave-uniform
+        b_voff[ib] = 4u * (unsigned)((pos * p.Npad + n0 + r) * 8 + 4 * ((lane & 1) ^ ((r >> 3) & 1)));
+        b_dst[ib] = pos * SB + rg * 256;               // floats, wave-uniform (SGPR)
     }
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.U);
@@ -156,25 +176,32 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
         __syncthreads();
     }
     f32x4 ra[IA][4];
-    auto load_a = [&](int c, bool live) {
-        if (!a_thr) return;
-        const int koff = c * WN_CK + 4 * g;
-        const bool kok = live & (koff < p.C);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_a = [&](int c, bool live) {          // c, live: wave-uniform
+        if (!a_thr || !live || (WN_ABL & 16)) return;      // (a dead prefetch leaves ra as it is: it is stored into the idle buffer, never read)
+        const int so = (WN_ABL & 1) ? 0 : c * (WN_CK * 4); // bytes, SGPR
+        if (PRE || !(c_tail && c == p.chunks - 1)) {
 #pragma unroll
-        for (int ia = 0; ia < IA; ++ia)
+            for (int ia = 0; ia < IA; ++ia)
 #pragma unroll
-            for (int col = 0; col < 4; ++col) {
-                const bool ok = kok & ((a_mask[ia] >> col) & 1);
-                const unsigned off = 4u * (unsigned)(a_base[ia] + col * src_ld + c * WN_CK);
-                ra[ia][col] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
-            }
+                for (int col = 0; col < 4; ++col)
+                    ra[ia][col] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[ia][col], so, 0));
+        } else {
+#pragma unroll
+            for (int ia = 0; ia < IA; ++ia)
+#pragma unroll
+                for (int col = 0; col < 4; ++col)
+                    ra[ia][col] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff_t[ia][col], so, 0));
+        }
     };
     auto load_b = [&](int c, int buf) {              // straight into LDS, no registers
 #if __HIP_DEVICE_COMPILE__      // (the host pass of hipcc cannot type-check the LDS address-space cast; it never runs this body)
         lds_f32* b = (lds_f32*)(Bs + buf * 16 * SB);
+        const int so = (WN_ABL & 2) ? 0 : c * (ustep * 4);   // bytes, SGPR
+        if (WN_ABL & 32) return;
 #pragma unroll
         for (int ib = 0; ib < IB; ++ib)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, b + b_dst[ib], 16, 4 * (b_src[ib] + c * ustep), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, b + b_dst[ib], 16, (int)b_voff[ib], so, 0, 0);
 #endif
     };
     // Column transform B^T across the quad (lane q holds row q of d B): V[0] = t0 - t2, V[1] = t1 + t2, V[2] = t2 - t1 and
@@ -182,7 +209,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     // ONE cross-lane operand, i.e. one v_fmac_f32 with a DPP source per value.
     const float sgn = (q == 1) ? 1.f : -1.f;
     auto store_a = [&](int buf, int c) {           // c: the chunk held in ra (PRE: selects the channel group's scale / shift)
-        if (!a_thr) return;
+        if (!a_thr || (WN_ABL & 16)) return;
         float* a = As + buf * 16 * SA;
         if (PRE) {
             const int ko = min(c, p.chunks - 1) * WN_CK + 4 * g;
@@ -233,8 +260,15 @@ __global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams 
     const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + pbase * SB;
     auto mfma_pos = [&](const float* a, const float* b, int pl) {       // position p = j*4 + i: PS 2: pl = j*2 + il, i = 2ph + il; PS 4: pl = j, i = ph
         const int po = (PS == 2) ? (pl >> 1) * 4 + (pl & 1) : pl * 4;
-        const f32x4 fa = *(const f32x4*)(a + po * SA);
-        const f32x4 fb = *(const f32x4*)(b + po * SB);
+        f32x4 fa = {1.f, 1.f, 1.f, 1.f}, fb = {1.f, 1.f, 1.f, 1.f};
+        if (!(WN_ABL & 8)) {
+            fa = *(const f32x4*)(a + po * SA);
+            fb = *(const f32x4*)(b + po * SB);
+        }
+        if (WN_ABL & 4) {
+            acc[pl][0] += fa[0] + fb[1];
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
     };
@@ -533,14 +567,18 @@ static int wino_launch1(const WnParams& p, hipStream_t st, double flops, const c
     constexpr size_t stage = (size_t)2 * 16 * (SA + SB) * sizeof(float);
     constexpr size_t epi = ((size_t)TB * 4 * (BN + 4) + 2 * (NT / (BN / 4)) * BN) * sizeof(float);
     static_assert(epi <= stage, "the epilogue's transposed tile + statistics rows reuse the K-loop staging area (rowinfo sits behind it)");
+    static_assert(stage + TB * 2 * sizeof(int) <= 160 * 1024, "staging area exceeds a CU's LDS");
     // (PRE: the (scale | shift) table sits behind rowinfo; the epilogue no longer needs it)
     const size_t lds = stage + TB * 2 * sizeof(int) + (PRE ? (size_t)2 * p.chunks * WN_CK * sizeof(float) : 0);
     ZSG_REQUIRE(lds <= 160 * 1024, "conv_wino: %zu bytes of LDS (C = %d is too large for the source-transform variant)", lds, p.C);
-    static size_t attr_lds = 0;         // (PRE: grows with C; a benign race sets it twice)
-    if (lds > attr_lds) {
+    static size_t attr_lds[ZSG_MAX_DEV] = {};      // per device (PRE: grows with C; a benign race sets it twice)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_wino: device %d", dev);
+    if (lds > attr_lds[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_lds = lds;
+        attr_lds[dev] = lds;
     }
     ZSG_PROF(kname, st, flops, 0);
     ZSG_LAUNCH((wino_kernel<TM, TN, PS, PRE>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);

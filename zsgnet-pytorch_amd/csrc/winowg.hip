@@ -18,6 +18,7 @@
 
 #define WW_KT 8                       // tiles per stage
 #define WW_SP (WW_KT * 64 + 8)        // floats between positions (+8: conflict-free quad writes)
+#define WW_BIAS (1 << 24)             // bytes: > 4 * (W + 1) * src_ld for every supported geometry (checked by the host)
 
 struct WwSegDev {
     int tiles_y, tiles_x, tiles, st0;
@@ -62,57 +63,88 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     const int n_st = st_end - st_begin;
 
     // ---- loader: this wave stages tile `wave` of every stage; lane = (4-channel group g, patch row q) ----------------
+    // Nothing co-issues with a SIMD's fp32 MFMA stream on gfx950 and every VALU instruction costs ~6 cycles on top of it
+    // (tools/ubench/mfma_coissue.hip), so the loader keeps everything that is wave-uniform in SGPRs: the tile cursor (b, ty, tx)
+    // advances by 8 tiles per stage with scalar adds / wraps (no per-stage divisions), the tile's base offsets travel in the buffer
+    // instructions' soffset, and the per-lane parts of the addresses (pixel of the tile / patch, channel group; out of range where
+    // this lane's row of the transform does not need the pixel) are loop constants that change only with the pyramid level.
     const int q = lane & 3, g = lane >> 2;
     const int a_col = m0 + 4 * g, b_col = n0 + 4 * g;
     const bool a_colok = a_col < p.N, b_colok = b_col < p.C;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const rsrc_t rs_a = make_rsrc(p.dy);
-    const rsrc_t rs_b = make_rsrc(p.src);
+    // input patches reach one row and one column above / left of pixel (2ty, 2tx): the descriptor's base sits WW_BIAS bytes below the
+    // tensor so that neither the scalar nor the per-lane part of an offset is ever negative (the range check looks at the per-lane part)
+    const rsrc_t rs_b = make_rsrc((const char*)p.src - WW_BIAS);
     int si = 0;
 #pragma unroll
     for (int s = 1; s < ZSG_MAX_SEG; ++s)
         if (s < p.nseg && st_begin >= p.seg[s].st0) si = s;
     WwSegDev sg = p.seg[si];
     int st_next = st_begin;
-
-    f32x4 rd[4], rx[4];
-    auto load_stage = [&](bool live) {
-        if (si + 1 < p.nseg && st_next >= p.seg[si + 1].st0) {     // wave-uniform segment switch
-            ++si;
-            sg = p.seg[si];
-        }
-        const int t = (st_next - sg.st0) * WW_KT + wave;
-        const bool tok = live & (t < sg.tiles);
-        const int tt = tok ? t : 0;
+    int cur_t, cur_b, cur_ty, cur_tx;                 // this wave's tile of the next stage (SGPRs)
+    unsigned dyv[4], xv[4];                           // per-lane byte offsets inside the tile / patch (level constants)
+    auto seg_enter = [&](int t0) {                    // t0: wave-uniform tile index inside the level
         const int per = sg.tiles_y * sg.tiles_x;
-        const int b = fdiv(tt, per, sg.inv_per);
-        const int rem = tt - b * per;
-        const int ty = fdiv(rem, sg.tiles_x, sg.inv_tx);
-        const int tx = rem - ty * sg.tiles_x;
-        // dY tile: pixels (2ty + a, 2tx + bb)
+        const int b = t0 / per, rem = t0 - b * per, ty = rem / sg.tiles_x;
+        cur_t = t0;
+        cur_b = __builtin_amdgcn_readfirstlane(b);
+        cur_ty = __builtin_amdgcn_readfirstlane(ty);
+        cur_tx = __builtin_amdgcn_readfirstlane(rem - ty * sg.tiles_x);
+        // dY pixel (a, bb) of the 2x2 tile: row q of A dy needs dy row 0 for q < 3 and dy row 1 for q > 0
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const int y = 2 * ty + a, x = 2 * tx + bb;
-                const bool ok = tok & a_colok & (y < sg.H) & (x < sg.W);
-                const unsigned off = 4u * (unsigned)(sg.dy_off + b * sg.dy_bstride + (y * sg.W + x) * p.dy_ld + a_col);
-                rd[a * 2 + bb] = buf_load4(rs_a, ok ? off : ZSG_OOB);
+                const bool need = a_colok & (a == 0 ? q != 3 : q != 0);
+                dyv[a * 2 + bb] = need ? 4u * (unsigned)((a * sg.W + bb) * p.dy_ld + a_col) : ZSG_OOB;
             }
-        // input patch row q: pixels (2ty - 1 + q, 2tx - 1 + col)
-        const int y = 2 * ty - 1 + q;
-        const bool rok = tok & b_colok & ((unsigned)y < (unsigned)sg.H);
+        // input pixel (q, col) of the 4x4 patch, relative to pixel (2ty - 1, 2tx - 1) (the scalar part carries the - (W + 1) pixels)
+#pragma unroll
+        for (int col = 0; col < 4; ++col) xv[col] = b_colok ? 4u * (unsigned)((q * sg.W + col) * p.src_ld + b_col) : ZSG_OOB;
+    };
+    seg_enter((st_begin - sg.st0) * WW_KT + wave_u);
+
+    f32x4 rd[4], rx[4];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_stage = [&](bool live) {
+        if (si + 1 < p.nseg && st_next >= p.seg[si + 1].st0) {     // wave-uniform level switch
+            ++si;
+            sg = p.seg[si];
+            seg_enter(wave_u);
+        }
+        const bool tok = live & (cur_t < sg.tiles);
+        const int y0 = 2 * cur_ty, x0 = 2 * cur_tx;
+        const int so_d = 4 * (sg.dy_off + cur_b * sg.dy_bstride + (y0 * sg.W + x0) * p.dy_ld);
+        const int so_x = 4 * (sg.src_off + cur_b * sg.src_bstride + (y0 * sg.W + x0 - sg.W - 1) * p.src_ld) + WW_BIAS;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const bool ok = tok & (y0 + a < sg.H) & (x0 + bb < sg.W);          // wave-uniform
+                rd[a * 2 + bb] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)(ok ? dyv[a * 2 + bb] : ZSG_OOB), so_d, 0));
+            }
+        const bool rok = tok & ((unsigned)(y0 - 1 + q) < (unsigned)sg.H);
 #pragma unroll
         for (int col = 0; col < 4; ++col) {
-            const int x = 2 * tx - 1 + col;
-            const bool ok = rok & ((unsigned)x < (unsigned)sg.W);
-            const unsigned off = 4u * (unsigned)(sg.src_off + b * sg.src_bstride + (y * sg.W + x) * p.src_ld + b_col);
-            rx[col] = buf_load4(rs_b, ok ? off : ZSG_OOB);
+            const bool ok = rok & ((unsigned)(x0 - 1 + col) < (unsigned)sg.W);
+            rx[col] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(ok ? xv[col] : ZSG_OOB), so_x, 0));
         }
         ++st_next;
+        cur_t += WW_KT;
+        cur_tx += WW_KT;
+        while (cur_tx >= sg.tiles_x) {
+            cur_tx -= sg.tiles_x;
+            ++cur_ty;
+        }
+        while (cur_ty >= sg.tiles_y) {
+            cur_ty -= sg.tiles_y;
+            ++cur_b;
+        }
     };
-    // dY transform A dy A^T, row q in-lane: rows (dy0, dy0 + dy1, dy0 - dy1, +dy1 [negated]) = alpha*dy0 + beta*dy1
-    const float alpha = (q == 3) ? 0.f : 1.f;
-    const float beta = (q == 0) ? 0.f : ((q == 2) ? -1.f : 1.f);
+    // dY transform A dy A^T, row q in-lane: rows (dy0, dy0 + dy1, dy0 - dy1, +dy1 [negated]) = dy0 + beta*dy1 with the dy row a
+    // lane does not need loaded as zeros (seg_enter)
+    const float beta = (q == 2) ? -1.f : 1.f;
     const float sgn = (q == 1) ? 1.f : -1.f;     // input transform: V[q] = own + sgn * other (row 3 negated), see wino.hip
     const int lds_w = q * SP + wave * 64 + 4 * g;
     auto store_stage = [&](int buf) {
@@ -121,8 +153,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
         f32x4 r0, r1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            r0[e] = fmaf(beta, rd[2][e], alpha * rd[0][e]);
-            r1[e] = fmaf(beta, rd[3][e], alpha * rd[1][e]);
+            r0[e] = fmaf(beta, rd[2][e], rd[0][e]);
+            r1[e] = fmaf(beta, rd[3][e], rd[1][e]);
         }
         *(f32x4*)(ps) = r0;                      // j = 0
         *(f32x4*)(ps + 4 * SP) = r0 + r1;        // j = 1
@@ -284,6 +316,7 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
                     "conv_wgrad_wino: tensor exceeds 2^29 elements (2 GB window)");
         ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0 && (a.out_off % 4) == 0 && (a.out_bstride % 4) == 0,
                     "conv_wgrad_wino: seg %d operands not 16-byte aligned", s);
+        ZSG_REQUIRE(4ll * (a.src_W + 1) * d->src_ld < WW_BIAS, "conv_wgrad_wino: seg %d: row pitch too large", s);
         WwSegDev& o = p.seg[s];
         o.tiles_y = (a.src_H + 1) / 2; o.tiles_x = (a.src_W + 1) / 2; o.tiles = (int)tiles; o.st0 = st;
         o.H = a.src_H; o.W = a.src_W;
