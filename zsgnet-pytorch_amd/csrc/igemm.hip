@@ -190,6 +190,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
     int jx = (it0 / n_cc) % n_jx;
     int jy = it0 / (n_cc * n_jx);
 
+    unsigned a_vo[RA], b_vo[RB];       // per-lane byte offsets of the current tap's tile rows (see load_tile)
+    int so_a = 0, so_b = 0, skip = 0;  // the tile's channel offset in both operands (bytes, SGPRs); tiles until the offsets are recomputed
+    const bool c_tail = (Cdim % BK) != 0;
     bool in_loop = false;
     // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
     // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
@@ -211,28 +214,62 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams
             koff = cc * BK + 4 * g;
             kok = live & (koff < Cdim);
         }
-        const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
-        const int toff = (dyy * srcW + (MERGE_X ? 0 : dxx)) * src_ld + (MERGE_X ? 4 * g : koff);      // (scalar part + this lane's k group)
-        int okm = 0;
+        if constexpr (!MERGE_X && !PRE) {
+            // Nothing co-issues with a SIMD's fp32 MFMA stream on gfx950 and a VALU instruction costs ~6 cycles on top of it
+            // (tools/ubench/mfma_coissue.hip): the per-lane byte offsets of a tile (tap validity, channel group; out of range = zeros)
+            // are STATE that changes only when the filter tap changes (or in the channel tail); inside a tap the channel offset
+            // advances in an SGPR (the buffer instructions' soffset) and a K tile costs no address arithmetic at all.
+            if (skip == 0 || !live) {                      // wave-uniform: first tile of a tap, the channel tail, past the end
+                const bool tail = c_tail && cc == n_cc - 1;
+                const bool klane = live & (!tail || koff < Cdim);
+                const int tap = (dyy * srcW + dxx) * src_ld + 4 * g;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int yy = a_by[j] + dyy, xx = a_bx[j] + dxx;
-            // branch-free validity (bitwise &): out-of-image taps / dead rows / channel tail get an out-of-range
-            // buffer offset, for which the hardware returns zeros
-            const bool ok = kok & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
-            const unsigned off = 4u * (unsigned)(a_off[j] + toff);
-            ra[j] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
-            if (PRE) okm |= ok ? (1 << j) : 0;
-        }
-        if (PRE) {
-            ps.okm = okm;
-            ps.sc = buf_load4(rsrc_p, kok ? 4u * (unsigned)koff : ZSG_OOB);
-            ps.sh = buf_load4(rsrc_p, kok ? 4u * (unsigned)(Cdim + koff) : ZSG_OOB);
-        }
+                for (int j = 0; j < RA; ++j) {
+                    const int yy = a_by[j] + dyy, xx = a_bx[j] + dxx;
+                    const bool ok = klane & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
+                    a_vo[j] = ok ? 4u * (unsigned)(a_off[j] + tap) : ZSG_OOB;
+                }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const bool ok = kok & (b_off[j] >= 0);
-            rb[j] = buf_load4(rsrc_b, ok ? 4u * (unsigned)(b_off[j] + wtap) : ZSG_OOB);
+                for (int j = 0; j < RB; ++j) b_vo[j] = (klane & (b_off[j] >= 0)) ? 4u * (unsigned)(b_off[j] + 4 * g) : ZSG_OOB;
+                so_a = 4 * cc * BK;
+                so_b = 4 * ((wr * p.wS + ws_) * p.wC + cc * BK);
+                // tiles until the next recomputation: up to the tap's last chunk, which is recomputed when it is a channel tail
+                skip = tail ? 0 : n_cc - 1 - cc - (c_tail ? 1 : 0);
+                if (skip < 0) skip = 0;
+            } else {
+                --skip;
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < RA; ++j) ra[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_vo[j], so_a, 0));
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rb[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_vo[j], so_b, 0));
+            so_a += 4 * BK;
+            so_b += 4 * BK;
+        } else {
+            const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
+            const int toff = (dyy * srcW + (MERGE_X ? 0 : dxx)) * src_ld + (MERGE_X ? 4 * g : koff);      // (scalar part + this lane's k group)
+            int okm = 0;
+    #pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const int yy = a_by[j] + dyy, xx = a_bx[j] + dxx;
+                // branch-free validity (bitwise &): out-of-image taps / dead rows / channel tail get an out-of-range
+                // buffer offset, for which the hardware returns zeros
+                const bool ok = kok & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
+                const unsigned off = 4u * (unsigned)(a_off[j] + toff);
+                ra[j] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
+                if (PRE) okm |= ok ? (1 << j) : 0;
+            }
+            if (PRE) {
+                ps.okm = okm;
+                ps.sc = buf_load4(rsrc_p, kok ? 4u * (unsigned)koff : ZSG_OOB);
+                ps.sh = buf_load4(rsrc_p, kok ? 4u * (unsigned)(Cdim + koff) : ZSG_OOB);
+            }
+    #pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const bool ok = kok & (b_off[j] >= 0);
+                rb[j] = buf_load4(rsrc_b, ok ? 4u * (unsigned)(b_off[j] + wtap) : ZSG_OOB);
+            }
         }
         // advance counters
         if (++cc == n_cc) {
