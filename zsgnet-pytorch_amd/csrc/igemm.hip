@@ -90,8 +90,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // and the first MFMA (~0.35 us per step whatever the tile: profiles/r03_igemm_ablation.txt) is exposed when the block has the CU
 // to itself.  With tile t+1 already complete in the ring, the fragments of step t+1 are read WHILE step t's MFMAs issue, so after the
 // barrier the next MFMA chain starts from registers.
+// __launch_bounds__' second argument (two waves per SIMD = at most 256 registers per lane): without it hipcc parks the accumulators
+// of the 4-wave tiles in AGPRs and copies one tile in and out of them every K step (32 v_accvgpr moves per 16 MFMAs — VALU-class
+// instructions that are paid in full next to fp32 MFMAs).  The 64-deep 128x128 4-wave tile needs more than 256 registers.
 template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK, int SCH = 0>
-__global__ __launch_bounds__(64 * WM * WN * KS) void igemm_kernel(const IgParams p) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 128 && WM * WN * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
     constexpr bool PP = SCH == 1;
     constexpr bool R3 = SCH == 2;
     constexpr int NB = R3 ? 3 : 2;           // LDS tile buffers

@@ -94,7 +94,7 @@ int wg_reduce_launch(const WgReduceJob& j, hipStream_t st) {
 // Block tile (32*TM*WM) x (32*TN*WN) computed by WM x WN waves, each TM x TN MFMA tiles of 32x32.
 // AVEC: dY rows are 16-byte addressable (out_ld % 4 == 0; a ragged channel count just reads the row's own padding).
 template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true>
-__global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDA = BM + WG_PAD, LDB = BN + WG_PAD;

@@ -67,7 +67,7 @@ __device__ __forceinline__ float quad_other(float v) {
 // pair of zsg_bn_affine_from_partials, staged once per block into LDS) and the ReLU between the pixel loads and the row transform;
 // out-of-image pixels stay exact zeros (the padding is of the normalised activation, not of its input).
 template <int TM, int TN, int PS, bool PRE = false>
-__global__ __launch_bounds__(64 * PS * TM * TN) void wino_kernel(const WnParams p) {
+__global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnParams p) {
     constexpr int NT = 64 * PS * TM * TN;        // PS position groups x TM x TN waves
     constexpr int NP = 16 / PS;                  // positions (accumulator tiles) per wave
     constexpr int TB = 32 * TM, BN = 32 * TN;
