@@ -59,15 +59,9 @@ def exec_ratio(kernel: str) -> float:
 
 
 def source_stamp() -> str:
-    """sha256 over the kernel sources: ties a committed rocprof summary to the build it was measured on"""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "zsgnet-pytorch_amd", "csrc", "*"))):
-        if f.endswith((".hip", ".h", ".cpp")):
-            h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 over the kernel sources: ties a committed rocprof summary / the shipped tuning table to the build it was measured on"""
+    from zsgnet_pytorch_amd import ops as _o
+    return _o.source_stamp()
 
 
 def parse():
@@ -82,7 +76,7 @@ def parse():
     ap.add_argument("--tokens", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-bx", action="store_true", help="skip the second measurement with the bf16x6 matrix path enabled")
+    ap.add_argument("--no-bx", action="store_true", help="(accepted and ignored: the bf16x6 leg was removed in round 4)")
     ap.add_argument("--prof-out", default="")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in the RCCL data-parallel reducer even at world size 1 (smoke test)")
     ap.add_argument("--launch-check", action="store_true", help="only bring up the N-rank process group (backend ZSG_DIST_BACKEND, default "
@@ -224,7 +218,7 @@ def main():
     loss_val, acc = float(ls["loss"].detach()), float(em["Acc"])
     ips = a.bs * world * a.steps / dt
 
-    # (forward-only and bf16x6 legs run BEFORE the per-kernel profiled legs: bracketing every launch with timing events leaves the
+    # (the forward-only leg runs BEFORE the per-kernel profiled legs: bracketing every launch with timing events leaves the
     # process ~3 % slower afterwards)
     fwd = None
     if not a.no_roofline:          # every rank (the training forward of a DDP model broadcasts the BatchNorm buffers)
@@ -245,38 +239,6 @@ def main():
                "mfma_frac": round(a.bs * fgf * 1e9 / (fm * 1e-3) / (PEAK_TF * 1e12), 4) if fgf else None,
                "what": "train-mode ZSGNet.forward only, grad mode on (batch-statistics BatchNorm; the backward's weight preparation "
                        "co-runs on the side stream as in a step), algorithmic conv FLOPs / fp32-MFMA peak"}
-    bx = None
-    if not a.no_bx and os.environ.get("ZSG_MATRIX", "fp32") == "fp32":
-        # Second measurement, same step, same steps/warmup: the autotuner may also pick the kernels' bf16x6 variants (fp32
-        # operands split exactly into three bf16 terms, six bf16 MFMAs per product block, fp32 accumulation; dropped terms
-        # <= 2^-26 |ab|; error against fp64 equal to the fp32-MFMA path's: tests/test_gpu_bx.py).  Reported beside `value`, which
-        # stays the fp32-input-MFMA-only number.  (Run right after the timed region: behind the profiled legs below it measured 3 %
-        # low — 1128 vs 1165 img/s standalone.)
-        os.environ["ZSG_MATRIX"] = "bf16x6"
-        net._plans = {}                          # re-lower (and re-tune) under the new candidate set
-        for _ in range(a.warmup):
-            step()
-        fence()
-        tb = time.perf_counter()
-        for _ in range(a.steps):
-            ls_b, em_b = step()
-        fence()
-        dtb = time.perf_counter() - tb
-        if world > 1:
-            t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtb = float(t.item())
-        from zsgnet_pytorch_amd import ops as zops2
-        nbx = sum(1 for v in zops2._TUNE_CACHE.values() if v & zops2.BX_FLAG and not v & zops2.WINO_FLAG)
-        fgf = FWD_GF.get((a.arch, a.img))
-        bx = {"value": round(a.bs * world * a.steps / dtb, 2), "unit": "images/s", "ms_per_step": round(1e3 * dtb / a.steps, 3),
-              "step_mfma_frac": round((a.bs * a.steps / dtb) * 3 * fgf * 1e9 / (PEAK_TF * 1e12), 4) if fgf else None,
-              "final_loss": round(float(ls_b["loss"].detach()), 4), "launch_shapes_on_bf16x6": nbx,
-              "what": "same step with ZSG_MATRIX=bf16x6: implicit-GEMM forward/data-gradient launches may run the exact-split bf16x6 "
-                      "matrix path where the autotuner finds it faster (fp32-grade results; algorithmic FLOPs / fp32-MFMA peak)"}
-        os.environ["ZSG_MATRIX"] = "fp32"
-        net._plans = {}                          # back to the fp32-only plan (its tile choices are cached) for the legs below
-        step()
     roof, prof_rows = None, []
     if not a.no_roofline:
         # EVERY rank runs the profiled steps (they contain the data-parallel collectives); rank 0 reports its own kernels
@@ -394,7 +356,7 @@ def main():
             "rccl": rccl,
             "final_loss": round(loss_val, 4), "final_acc": acc,
             "forward": fwd, "source_stamp": source_stamp(),
-            "bf16x6": bx, "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu,
         }
     if world > 1:
         dist.barrier()

@@ -84,8 +84,7 @@ typedef struct {
     int32_t nseg;
     int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16) | variant bits; chosen by the host autotuner.
                            * bit 24: 8-wave workgroup (igemm, wgrad) / four position groups (wino); bit 25: 32-pixel K tiles
-                           * (wgrad); bit 26 (igemm): bf16x6 matrix path — every fp32 operand value split exactly into three
-                           * bf16 terms, six bf16 MFMAs per product block, fp32 accumulation; dropped terms <= 2^-26 |a*b|   */
+                           * (wgrad); bit 27 (igemm): 64-deep K tiles                                                         */
     zsg_seg seg[ZSG_MAX_SEG];
 } zsg_conv_desc;
 
@@ -105,21 +104,6 @@ int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, fl
 size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                    size_t ws_bytes, void* stream);
-/* The same launch WITHOUT its slab reduction (also zsg_conv_wgrad_wino_partial below): when the launch splits K
- * (*n_slabs > 1, written on the host before the call returns) the partial tiles stay in ws as [n_slabs][N][taps*C] and dw is
- * untouched; *n_slabs == 1 means dw was written / accumulated directly.  A step gives every such launch its own workspace
- * region and sums the slabs of MANY layers in one launch — autograd's per-parameter AccumulateGrad of utils.py:412
- * (`loss.backward()`) as a handful of batched reductions instead of one tiny dependent launch per convolution:
- *   blocks = zsg_wgrad_reduce_job(d, ws, dw, accumulate, n_slabs, blk0, job)   fills one job record (host memory,
- *            zsg_wgrad_reduce_job_bytes() bytes) from the launch's descriptor; returns its block count (blk0 accumulates),
- *   zsg_wgrad_reduce_batched(jobs_dev, njobs, total_blocks, bytes_for_profile, stream)   dw (+)= sum over slabs for every job
- *            of the device array; fixed summation order per element (deterministic). */
-int zsg_conv_wgrad_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                           size_t ws_bytes, int32_t* n_slabs, void* stream);
-int32_t zsg_wgrad_reduce_job_bytes(void);
-int32_t zsg_wgrad_reduce_job(const zsg_conv_desc* d, const float* ws, float* dw, int32_t accumulate, int32_t n_slabs, int32_t blk0,
-                             void* job_out);
-int zsg_wgrad_reduce_batched(const void* jobs_dev, int32_t njobs, int32_t total_blocks, double total_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Winograd F(2x2,3x3) convolution on fp32 MFMA: the 3x3 / stride 1 / pad 1 convolutions (forward and data gradient)
@@ -132,17 +116,6 @@ int zsg_wgrad_reduce_batched(const void* jobs_dev, int32_t njobs, int32_t total_
  * ------------------------------------------------------------------------------------------------------------- */
 int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
                   const float* add_src, const float* mask_src, float* bn_partials, void* stream);
-
-/* The same two convolutions reading the INPUT of a train-mode BatchNorm + ReLU whose output they logically consume — the
- * conv -> bn -> relu -> conv chains of fpn_resnet.py:86-97 (Bottleneck conv1/bn1/relu -> conv2, conv2/bn2/relu -> conv3) and
- * :48-52 (BasicBlock): the operand loader stages max(fmaf(x, scale[c], shift[c]), 0) of every pixel it loads (zero padding is of
- * the normalised activation and stays zero), src_affine = (scale[C] | shift[C]) from zsg_bn_affine_from_partials.  The
- * nn.BatchNorm2d + nn.ReLU launches between the two convolutions leave the forward's dependent chain; zsg_bn_apply_affine
- * materialises the same numbers (bit-identical) for the backward, off the chain. */
-int zsg_conv_igemm_pre(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                       const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream);
-int zsg_conv_wino_pre(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
-                      const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream);
 
 /* Data gradient that COMPLETES dout of a train-mode BatchNorm (out = dgrad [+ add_src]; autograd's conv backward followed by
  * native_batch_norm_backward of fpn_resnet.py:86-97's conv-bn-relu chains): the epilogue also reduces that BatchNorm's
@@ -178,8 +151,6 @@ int zsg_wino_weights(const void* jobs, int32_t njobs, int32_t total_blocks, void
 size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                         size_t ws_bytes, void* stream);
-int zsg_conv_wgrad_wino_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                                size_t ws_bytes, int32_t* n_slabs, void* stream);
 
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */
@@ -207,14 +178,6 @@ int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean, float* in
                  float* running_var, float momentum, float eps, void* ws, size_t ws_bytes, void* stream);
 int zsg_bn_stats_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, float* mean, float* invstd,
                                float* running_mean, float* running_var, float momentum, float eps, void* stream);
-/* zsg_bn_stats_from_partials + the BatchNorm as ONE fma per value: affine[c] = gamma[c] * invstd[c], affine[C + c] =
- * beta[c] - mean[c] * affine[c] (nn.BatchNorm2d's y = (x - mean) / sqrt(var + eps) * gamma + beta, fpn_resnet.py:87,90). */
-int zsg_bn_affine_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, const float* gamma, const float* beta,
-                                float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
-                                float* affine, void* stream);
-/* out = [relu](fmaf(x, affine[c], affine[C + c])); relu_mask as zsg_bn_apply */
-int zsg_bn_apply_affine(const float* x, int64_t rows, int32_t C, const float* affine, int32_t relu, float* out, uint8_t* relu_mask,
-                        void* stream);
 /* Stem: nn.BatchNorm2d -> nn.ReLU -> nn.MaxPool2d(3, 2, 1) (mdl.py:149-152 on fpn_resnet.py's conv1 / bn1) in ONE pass over the
  * stem activation x [B][H][W][C] (the network's largest tensor): out [B][Ho][Wo][C] = maxpool(relu(bn(x))), idx = window position
  * of the first maximum (uint8, as zsg_maxpool_fwd).  The backward takes d(out): per-channel sums over the pooled gradient (the only
@@ -360,13 +323,15 @@ int zsg_iou(const float* boxes, const float* anchors, int32_t B, int32_t A, floa
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused Adam over a flat parameter buffer — torch.optim.Adam(betas=(0.9,0.99)) at main_dist.py:50 / utils.py:413.
- * step_count: device int32[1], incremented by the kernel (graph-capturable).  grad_scale folds 1/world_size.
+ * step_count: device int32[2], zero-initialised by the caller: [0] = steps taken, incremented by the kernel (graph-capturable);
+ * [1] = the kernel's completion ticket (0 between launches).  grad_scale folds 1/world_size.
  * ------------------------------------------------------------------------------------------------------------- */
 int zsg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, int32_t* step_count, void* stream);
 /* The same step as several launches over disjoint ranges (pointers offset by the caller, 16-byte aligned): every launch computes with
- * t = counter + 1; exactly the last one passes publish = 1.  Lets the update of the parameters whose gradients are complete overlap
- * the tail of the backward (the stem's weight gradient). */
+ * t = counter + 1; exactly the last one passes publish = 1 — and it must be ordered behind the others (same stream, or an event
+ * edge): it advances the counter they read.  Lets the update of the parameters whose gradients are complete overlap the tail of
+ * the backward (the stem's weight gradient). */
 int zsg_adam_step_range(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, float grad_scale, int32_t* step_count, int32_t publish, void* stream);
 

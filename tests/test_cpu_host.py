@@ -191,6 +191,62 @@ def _reducer_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _tsync_worker(rank, world, port, ret):
+    """ranks meet the query-length buckets in DIFFERENT orders (the collater cuts qvec to each rank's own longest query)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from zsgnet_pytorch_amd import ops
+    from zsgnet_pytorch_amd.dist import DistributedDataParallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Store:
+        pass
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.store = Store()
+            self.store.flat, self.store.grad = torch.zeros(8), torch.zeros(8)
+            self._rmv = torch.zeros(8)
+            self._nbt = torch.tensor([0])
+            self._plans, self.lowered = {}, []
+
+        def plan_geometry(self, inp):
+            return (2, 96, 96, 20 if inp["qvec"].shape[1] <= 20 else 50)
+
+        def _plan_for(self, B, H, W, T):
+            self._plans[(B, H, W, T, self.training)] = True
+            self.lowered.append(T)
+            ops._TUNE_CACHE[("fake", B, H, W, T)] = 7          # "rank 0 tuned something"
+
+        def forward(self, inp):
+            return inp["qvec"].sum()
+    m = Fake().train()
+    ddp = DistributedDataParallel(m)
+    # step:        0   1   2   3          (rank 1 meets bucket 50 two steps before rank 0 does)
+    lens = [[12, 18, 31, 40], [33, 15, 9, 44]][rank]
+    for T in lens:
+        ddp({"qvec": torch.zeros(2, T, 4)})
+        x = torch.ones(1)
+        dist.all_reduce(x)                                     # the step's gradient collective: must pair up on both ranks
+        assert float(x) == world
+    m.eval()
+    ddp({"qvec": torch.zeros(2, lens[0], 4)})                  # a mode switch is a new (symmetric) key
+    ret[rank] = (len(ddp._tuned), dict(ops._TUNE_CACHE), list(m.lowered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_tuning_sync_is_rank_symmetric_gloo_world2():
+    """the tuning broadcast must not depend on the per-rank query-length bucket"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tsync_worker, args=(2, _free_port(), ret), nprocs=2, join=True)          # (a collective mismatch would hang / raise)
+    assert ret[0][0] == 2 and ret[1][0] == 2, "one broadcast per (B, H, W, mode), on every rank"
+    assert ret[0][2] == [20, 20] and ret[1][2] == [], "only rank 0 lowers ahead of the broadcast (its own bucket)"
+    assert ret[1][1] == ret[0][1] and ret[0][1], "rank 1 runs rank 0's table"
+
+
 def test_bucket_reducer_and_ddp_wrapper_gloo_world2():
     mgr = mp.Manager()
     ret = mgr.dict()

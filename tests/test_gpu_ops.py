@@ -683,7 +683,7 @@ def test_adam_matches_torch(Z):
     pr = p0.clone().requires_grad_()
     opt = torch.optim.Adam([pr], lr=1e-2, betas=(0.9, 0.99))
     pd, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    step = torch.zeros(2, dtype=torch.int32, device="cuda")          # [steps taken, completion ticket]
     for it in range(5):
         gr = torch.randn(n, generator=g)
         pr.grad = gr.clone()
@@ -691,7 +691,7 @@ def test_adam_matches_torch(Z):
         grd = dev(gr)
         L.check(L.lib.zsg_adam_step(pd.data_ptr(), grd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.99, 1e-8, 0.0, 1.0,
                                     step.data_ptr(), L.stream_ptr()), "adam")
-    assert int(step.item()) == 5
+    assert step.tolist() == [5, 0]
     assert_close(pd, pr.detach(), 1e-5, 1e-6, "adam params")
 
 

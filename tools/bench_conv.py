@@ -31,8 +31,6 @@ SHAPES = [
 ]
 TILES = [0, 128 | (128 << 8), 128 | (64 << 8), 64 | (64 << 8)]
 TILES_IG = TILES + [128 | (128 << 8) | (1 << 24), 128 | (64 << 8) | (1 << 24), 64 | (64 << 8) | (1 << 24)]
-BX = 1 << 26                             # bf16x6 matrix path
-TILES_IG += [t | BX for t in TILES_IG[1:]]
 
 
 def timeit(fn, n=20):
@@ -70,12 +68,12 @@ def main():
         for t in TILES_IG:
             d = ops.fwd_desc(xv, yv, Ci, Co, k, s, p, 1, wC=Ci, tile_hint=t)
             ms = timeit(lambda: check(lib.zsg_conv_igemm(C.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, None, None, st)))
-            line += f" f[{t & 0xff}x{(t >> 8) & 0xff}{chr(119) if (t >> 24) & 1 else chr(32)}{chr(120) if t & BX else chr(32)}] {gf / ms:5.1f}"
+            line += f" f[{t & 0xff}x{(t >> 8) & 0xff}{chr(119) if (t >> 24) & 1 else chr(32)}] {gf / ms:5.1f}"
         line += " |"
         for t in TILES_IG:
             d = ops.dgrad_desc(dyv, dxv, Co, Ci, k, s, p, 1, tile_hint=t)
             ms = timeit(lambda: check(lib.zsg_conv_igemm(C.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, None, st)))
-            line += f" d[{t & 0xff}x{(t >> 8) & 0xff}{chr(119) if (t >> 24) & 1 else chr(32)}{chr(120) if t & BX else chr(32)}] {gf / ms:5.1f}"
+            line += f" d[{t & 0xff}x{(t >> 8) & 0xff}{chr(119) if (t >> 24) & 1 else chr(32)}] {gf / ms:5.1f}"
         line += " | wgrad"
         for t in [] if os.environ.get("NO_WGRAD") else TILES + [128 | (128 << 8) | (1 << 25), 128 | (128 << 8) | (1 << 24), 128 | (128 << 8) | (1 << 24) | (1 << 25)]:
             d = ops.fwd_desc(xv, dyv, Ci, Co, k, s, p, 1, wC=Ci, tile_hint=t)

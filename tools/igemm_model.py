@@ -28,7 +28,7 @@ def t_single(fn, n=15):
 def main():
     st = stream_ptr()
     variants = [(64, 64, 0), (64, 64, 1), (128, 64, 0), (128, 64, 1), (128, 128, 0), (128, 128, 1)]
-    bx = (int(os.environ.get("BX", "0")) << 26) | (int(os.environ.get("K64", "0")) << 27) | (int(os.environ.get("PP", "0")) << 28) | (int(os.environ.get("R3", "0")) << 29)
+    bx = int(os.environ.get("K64", "0")) << 27          # variant bit: 64-deep K tiles
     print("time of ONE launch in us (median of 15, device idle before each)")
     shapes = ((5776, 256), (1600, 512), (23104, 128), (5776, 1024), (8192, 256), (16384, 256))
     ks = (64, 256, 1024, 2048)

@@ -1,5 +1,5 @@
 """Developer tool: launch ONE conv configuration a few times (for rocprofv3 --pmc runs).
-usage: python tools/one_conv.py <shape> <fwd|dgrad|wgrad> <BM> <BN> [w8] [splits] [bx]      (bx = 1: the bf16x6 matrix path)"""
+usage: python tools/one_conv.py <shape> <fwd|dgrad|wgrad> <BM> <BN> [w8] [splits]"""
 import ctypes as C
 import os
 import sys
@@ -29,7 +29,7 @@ xv = ops.TView(x.view(-1), B, Ci, Ci, [ops.Level(0, H, W, H * W * Ci)])
 yv = ops.TView(y.view(-1), B, Co, Co, [ops.Level(0, Ho, Wo, Ho * Wo * Co)])
 dyv = ops.TView(dy.view(-1), B, Co, Co, [ops.Level(0, Ho, Wo, Ho * Wo * Co)])
 dxv = ops.TView(dx.view(-1), B, Ci, Ci, [ops.Level(0, H, W, H * W * Ci)])
-hint = ops.tile_hint(bm, bn, sp, w8) | (ops.BX_FLAG if (len(sys.argv) > 7 and int(sys.argv[7])) else 0)
+hint = ops.tile_hint(bm, bn, sp, w8)
 st = stream_ptr()
 for _ in range(8):
     if mode == "fwd":

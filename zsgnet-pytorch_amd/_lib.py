@@ -55,10 +55,6 @@ SIGNATURES = {
     "zsg_comm_wait": (I32, [P, P]),
     "zsg_comm_destroy": (I32, [P]),
     "zsg_conv_wino": (I32, [DP, P, P, P, P, P, P, P, P]),
-    "zsg_conv_igemm_pre": (I32, [DP, P, P, P, P, P, P, P, P, P]),
-    "zsg_conv_wino_pre": (I32, [DP, P, P, P, P, P, P, P, P, P]),
-    "zsg_bn_affine_from_partials": (I32, [P, I32, I64, I32, P, P, P, P, P, P, F32, F32, P, P]),
-    "zsg_bn_apply_affine": (I32, [P, I64, I32, P, I32, P, P, P]),
     "zsg_bn_relu_maxpool_fwd": (I32, [P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P]),
     "zsg_bn_relu_maxpool_bwd": (I32, [P, P, P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, I32, P, SZ, P]),
     "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
@@ -71,11 +67,6 @@ SIGNATURES = {
     "zsg_conv_wgrad": (I32, [DP, P, P, P, I32, P, SZ, P]),
     "zsg_conv_wgrad_wino_workspace_bytes": (SZ, [DP]),
     "zsg_conv_wgrad_wino": (I32, [DP, P, P, P, I32, P, SZ, P]),
-    "zsg_conv_wgrad_partial": (I32, [DP, P, P, P, I32, P, SZ, P, P]),
-    "zsg_conv_wgrad_wino_partial": (I32, [DP, P, P, P, I32, P, SZ, P, P]),
-    "zsg_wgrad_reduce_job_bytes": (I32, []),
-    "zsg_wgrad_reduce_job": (I32, [DP, P, P, I32, I32, I32, P]),
-    "zsg_wgrad_reduce_batched": (I32, [P, I32, I32, C.c_double, P]),
     "zsg_transpose_w": (I32, [P, P, I32, I32, I32, I32, P]),
     "zsg_transpose_w_batched": (I32, [P, P, P, I32, I32, P]),
     "zsg_pad_rows": (I32, [P, I64, I32, I32, P, I32, P]),

@@ -2,10 +2,11 @@
 // reads p,g,m,v and writes p,m,v once: 28 B per parameter.
 #include "common.h"
 
-// The step counter lives on the device (the launch is hipGraph-capturable).  Every block reads it when it starts and uses t = count + 1;
-// the block that FINISHES last (ticket) publishes t and clears the ticket — by then every block has read the old value.  (A separate
-// one-thread "tick" launch ahead of the update was 8 us of dependent launch at the end of every step.)
-__device__ int g_adam_done;
+// The step counter lives on the device (the launch is hipGraph-capturable): step[0] = steps taken, step[1] = the ticket of the launch
+// in flight — both belong to ONE optimizer (two optimizers stepping on different streams never share a ticket).  Every block reads
+// step[0] when it starts and uses t = count + 1; the block that FINISHES last (ticket) publishes t and clears the ticket — by then
+// every block has read the old value.  (A separate one-thread "tick" launch ahead of the update was 8 us of dependent launch at the
+// end of every step.)
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n4, int64_t n, float lr, float b1, float b2, float eps,
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     if (!tick) return;          // (a partial update of the step: the launch that covers the rest publishes the counter)
     __syncthreads();
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&g_adam_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-        __hip_atomic_store(&g_adam_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(step + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(step + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(step, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -157,8 +157,7 @@ __device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ par
 
 __global__ __launch_bounds__(64 * BN_FW) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
                                                                        float* mean, float* invstd, float* rmean, float* rvar,
-                                                                       float momentum, float eps, const float* __restrict__ gamma,
-                                                                       const float* __restrict__ beta, float* affine) {
+                                                                       float momentum, float eps) {
     const int c = blockIdx.x * 4;
     double se, sse;
     bn_reduce_partials(part, chunks, C, c, se, sse);
@@ -171,40 +170,8 @@ __global__ __launch_bounds__(64 * BN_FW) void bn_stats_finalize_kernel(const flo
     mean[c + e] = (float)m;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     invstd[c + e] = is;
-    if (affine) {                                  // y = fmaf(x, scale, shift): what a consumer convolution applies while it loads x
-        const float sc = is * gamma[c + e];
-        affine[c + e] = sc;
-        affine[C + c + e] = fmaf(-(float)m, sc, beta[c + e]);
-    }
     if (rmean) rmean[c + e] = (1.f - momentum) * rmean[c + e] + momentum * (float)m;
     if (rvar) rvar[c + e] = (1.f - momentum) * rvar[c + e] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
-}
-
-// out = [relu](fmaf(x, scale[c], shift[c])) from the (scale | shift) pair of zsg_bn_affine_from_partials — bit-identical to what
-// the consumer convolutions' operand loaders compute from the same pair (zsg_conv_igemm_pre / zsg_conv_wino_pre), so the
-// materialised activation (read by the backward) and the values the forward multiplied are the same numbers.
-__global__ __launch_bounds__(256) void bn_apply_affine_kernel(const float* __restrict__ x, int64_t rows, int C, const float* __restrict__ affine,
-                                                              int relu, float* __restrict__ out, uint8_t* __restrict__ relu_mask, int lanes, int rpb) {
-    const int rowlanes = 256 / lanes;
-    const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
-    const int c = (blockIdx.y * lanes + l) * 4;
-    if (c >= C) return;
-    const f32x4 sc = *(const f32x4*)(affine + c);
-    const f32x4 sh = *(const f32x4*)(affine + C + c);
-    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
-    const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
-    for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-        f32x4 v = *(const f32x4*)(x + r * C + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-        if (relu) {
-            if (relu_mask)
-                relu_mask[(r * C + c) >> 2] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *(f32x4*)(out + r * C + c) = v;
-    }
 }
 
 __global__ void bn_eval_stats_kernel(const float* rmean, const float* rvar, int C, float eps, float* mean, float* invstd) {
@@ -416,7 +383,7 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     ZSG_LAUNCH((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
     ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
-                       running_mean, running_var, momentum, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                       running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats");
     return 0;
 }
@@ -428,7 +395,7 @@ extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks,
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
     ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
-                       running_mean, running_var, momentum, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                       running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats_from_partials");
     return 0;
 }
@@ -579,31 +546,6 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
         const f32x4 xh = (xv - mu) * is;
         *(f32x4*)(dx + r * C + c) = sc * (g - c1 - xh * c2);
     }
-}
-
-// Finalize + the (scale | shift) pair for consumers that apply this BatchNorm (+ ReLU) while they load its input.
-extern "C" int zsg_bn_affine_from_partials(const float* partials, int32_t chunks, int64_t rows, int32_t C, const float* gamma, const float* beta,
-                                           float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
-                                           float* affine, void* stream) {
-    ZSG_REQUIRE(partials && gamma && beta && mean && invstd && affine && chunks > 0 && rows > 0 && C > 0 && (C % 4) == 0,
-                "bn_affine_from_partials: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
-                       running_mean, running_var, momentum, eps, gamma, beta, affine);
-    ZSG_CHECK_LAUNCH("bn_affine_from_partials");
-    return 0;
-}
-
-extern "C" int zsg_bn_apply_affine(const float* x, int64_t rows, int32_t C, const float* affine, int32_t relu, float* out,
-                                   uint8_t* relu_mask, void* stream) {
-    ZSG_REQUIRE(x && affine && out && rows > 0 && C > 0 && (C % 4) == 0, "bn_apply_affine: bad argument");
-    BnGeom g = bn_geom(rows, C);
-    hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("bn_apply", st, 0, (double)rows * C * (8 + (relu_mask && relu ? 0.25 : 0)));
-    ZSG_LAUNCH(bn_apply_affine_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, x, rows, C, affine, relu, out, relu_mask, g.lanes, g.rpb);
-    ZSG_CHECK_LAUNCH("bn_apply_affine");
-    return 0;
 }
 
 extern "C" int zsg_bn_relu_maxpool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd,

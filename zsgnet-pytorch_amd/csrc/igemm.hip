@@ -39,8 +39,6 @@ struct IgParams {
     const float* bias;
     const float* add_src;
     const float* mask_src;
-    const float* pre; // PRE kernels: (scale[C] | shift[C]) of the BatchNorm (+ ReLU) that produced the logical source: the A loader
-                      // stages max(fmaf(x, scale[c], shift[c]), 0) of what it loads (padding / dead rows stay exact zeros)
     float* stats;     // optional BatchNorm partials [m_tiles][2][N]: per-tile column sums / sums of squares of the output
     int C, N, src_ld, out_ld, wS, wC, wc0, wt_ld, relu, nseg;
     int m_tiles, n_tiles;
@@ -48,8 +46,6 @@ struct IgParams {
     int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
     int bk64;         // tile_hint bit 27: 64-deep K tiles
-    int pp;           // tile_hint bit 28: staggered K groups (64x64 8-wave tile)
-    int r3;           // tile_hint bit 29: three-buffer LDS ring, fragments read one step ahead
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     IgSegDev seg[ZSG_MAX_SEG];
@@ -60,48 +56,18 @@ struct IgParams {
 // epilogue (intra-block split-K: fixed order, no atomics).  It puts KS times as many waves on a SIMD for the same tile —
 // what the small-grid layers (a few hundred 64x64 tiles for 256 CUs) need to hide LDS / barrier latency.
 //
-// BX ("bf16x6"): the same fp32 GEMM on the bf16 matrix pipeline, which on gfx950 runs 16x the rate of the fp32-input MFMA.
-// Each fp32 operand value is split EXACTLY into three bf16 terms (x = x1 + x2 + x3, round-to-nearest-even at every level:
-// |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|; in the registers->LDS stage) and the product a*b is accumulated in fp32 from the six
-// bf16 products a1b1, a1b2, a2b1, a2b2, a1b3, a3b1.  The three dropped terms a2b3 + a3b2 + a3b3 are <= 2^-26 |ab| — a quarter
-// of the rounding error of ONE fp32 product — and every bf16 product is exact in the fp32 accumulator.  Six v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32
-// (64 cycles each) per 16 k: 0.375 of the matrix-pipe time, measured error against fp64 equal to the native path's.
-// LDS rows hold the three planes side by side: 3 x 32 bf16 (64 B each) + 16 B pad = 52 floats (13 x 16 B: odd).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-//
-// PRE: the source tensor is the INPUT of a train-mode BatchNorm + ReLU whose output this convolution logically consumes
-// (fpn_resnet.py:86-97: conv -> bn -> relu -> conv).  The registers->LDS stage applies the BatchNorm as one fma per value with the
-// per-channel (scale, shift) pair of zsg_bn_affine_from_partials and the ReLU as one max: the normalised activation is never
-// read from HBM on the forward's critical path (its materialisation for the backward runs off the chain on the side stream).
-//
 // BK: K-tile depth.  32 = one barrier per 32 reduction elements; 64 halves the number of K steps — each step carries ~0.3-0.4 us
 // that no MFMA overlaps (address arithmetic, load issue, fragment-read latency, the barrier: tools/igemm_model.py, profiles/
 // r03_igemm_model_*.txt), which at one or two resident blocks per CU is 25-45 % of a step — at twice the LDS per block.
 //
-// PP ("staggered K groups", KS = 2 only): the two K groups of the 8-wave block run half a K tile out of phase.  While group 0 issues
-// its MFMAs on tile t, group 1 parks its share of tile t+1 in LDS, re-issues its global loads and reads its fragments of tile t;
-// after a barrier the roles swap.  A block that has the CU to itself serialises operand delivery (0.45 us per 64x64x32 tile at the
-// per-CU fetch cap) with MFMA issue (0.43 us) when all its waves walk the same phases (0.69 us per tile measured); staggered, each
-// SIMD always has one wave in the matrix pipe and one in the memory path.  Two barriers per K tile instead of one.
-//
-// SCH = 2 ("ring"): THREE LDS tile buffers and double-buffered fragment registers.  In the lock-step schedule a K step is
-// barrier -> fragment ds_reads -> (LDS latency) -> MFMAs -> wait for the loads -> ds_write -> barrier: everything between the barrier
-// and the first MFMA (~0.35 us per step whatever the tile: profiles/r03_igemm_ablation.txt) is exposed when the block has the CU
-// to itself.  With tile t+1 already complete in the ring, the fragments of step t+1 are read WHILE step t's MFMAs issue, so after the
-// barrier the next MFMA chain starts from registers.
 // __launch_bounds__' second argument (two waves per SIMD = at most 256 registers per lane): without it hipcc parks the accumulators
 // of the 4-wave tiles in AGPRs and copies one tile in and out of them every K step (32 v_accvgpr moves per 16 MFMAs — VALU-class
 // instructions that are paid in full next to fp32 MFMAs).  The 64-deep 128x128 4-wave tile needs more than 256 registers.
-template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, bool BX = false, bool PRE = false, int BK = IG_BK, int SCH = 0>
+template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, int BK = IG_BK>
 __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 128 && WM * WN * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
-    constexpr bool PP = SCH == 1;
-    constexpr bool R3 = SCH == 2;
-    constexpr int NB = R3 ? 3 : 2;           // LDS tile buffers
-    static_assert(BK == 32 || (BK == 64 && !BX && !MERGE_X), "K tile depth");
-    static_assert(!PP || (KS == 2 && !BX && !PRE && !MERGE_X), "staggered K groups: the 8-wave two-group tile only");
-    static_assert(!R3 || (!BX && !PRE && !MERGE_X && BK == 32), "ring schedule: fp32, 32-deep tiles");
-    constexpr int LDR = BX ? 52 : BK + 4;     // floats per LDS tile row (an odd number of 16-byte units: conflict-free b128 fragment reads)
+    constexpr int NB = 2;                    // LDS tile buffers
+    static_assert(BK == 32 || (BK == 64 && !MERGE_X), "K tile depth");
+    constexpr int LDR = BK + 4;              // floats per LDS tile row (an odd number of 16-byte units: conflict-free b128 fragment reads)
     constexpr int NT = 64 * WM * WN * KS;     // threads
     constexpr int KG = BK / 4;           // threads (16-byte groups) per tile row
     constexpr int RP = NT / KG;          // tile rows staged per pass
@@ -121,10 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
     const int wmn = wave % (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
     const int g = tid % KG;              // 16-byte k-group staged by this thread
-    // first staged row.  BX: the three 8-byte plane stores of a split value go out in 16-lane groups = two rows; at the 52-word row
-    // pitch rows r and r + 1 overlap on 4 of the 32 store banks, rows r and r + 4 do not (4 x 52 = 16 mod 32) — so lane bit 3 selects
-    // row bit 2 (PMC: 15.3 M conflict cycles on the head-sized launch with the linear order)
-    const int r0 = BX ? ((tid >> 6) << 3) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3) : tid / KG;
+    const int r0 = tid / KG;             // first staged row
 
     const int n_tiles_mn = p.m_tiles * p.n_tiles;
     const int split = blockIdx.x / n_tiles_mn;
@@ -183,11 +146,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
     // igemm_model.py) and the step lost 1.6 % to the registers (14.32 -> 14.55 ms): not what the K loop waits for.
     constexpr int NS = 2;
     f32x4 ra[NS][RA], rb[NS][RB];
-    struct PreStage { f32x4 sc, sh; int okm; };   // PRE: the tile's channel-group (scale, shift) and which of its rows are real pixels
-    PreStage ps[NS];
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.wt);
-    const rsrc_t rsrc_p = make_rsrc(PRE ? p.pre : p.src);
     // K-iteration counters of the NEXT tile to load (wave-uniform)
     int cc = it0 % n_cc;
     int jx = (it0 / n_cc) % n_jx;
@@ -200,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
     // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
     // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
     // outstanding loads exactly (a branch made it wait for ALL of them, vmcnt(0), before parking the previous tile).
-    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], PreStage& ps, bool live) {
+    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], bool live) {
         if ((IG_ABL & 2) && in_loop) return;
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
@@ -217,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
             koff = cc * BK + 4 * g;
             kok = live & (koff < Cdim);
         }
-        if constexpr (!MERGE_X && !PRE) {
+        if constexpr (!MERGE_X) {
             // Nothing co-issues with a SIMD's fp32 MFMA stream on gfx950 and a VALU instruction costs ~6 cycles on top of it
             // (tools/ubench/mfma_coissue.hip): the per-lane byte offsets of a tile (tap validity, channel group; out of range = zeros)
             // are STATE that changes only when the filter tap changes (or in the channel tail); inside a tap the channel offset
@@ -249,30 +209,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
             for (int j = 0; j < RB; ++j) rb[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_vo[j], so_b, 0));
             so_a += 4 * BK;
             so_b += 4 * BK;
-        } else {
-            const int wtap = (wr * p.wS + ws_) * p.wC + (MERGE_X ? 4 * g : koff);
-            const int toff = (dyy * srcW + (MERGE_X ? 0 : dxx)) * src_ld + (MERGE_X ? 4 * g : koff);      // (scalar part + this lane's k group)
-            int okm = 0;
-    #pragma unroll
+        } else {                          // (the 7x7x4 stem: one K tile per filter row, nothing to carry between tiles)
+            const int wtap = (wr * p.wS + ws_) * p.wC + 4 * g;
+            const int toff = dyy * srcW * src_ld + 4 * g;
+#pragma unroll
             for (int j = 0; j < RA; ++j) {
                 const int yy = a_by[j] + dyy, xx = a_bx[j] + dxx;
-                // branch-free validity (bitwise &): out-of-image taps / dead rows / channel tail get an out-of-range
-                // buffer offset, for which the hardware returns zeros
+                // branch-free validity (bitwise &): out-of-image taps / dead rows get an out-of-range buffer offset (zeros)
                 const bool ok = kok & ((unsigned)yy < (unsigned)srcH) & ((unsigned)xx < (unsigned)srcW);
-                const unsigned off = 4u * (unsigned)(a_off[j] + toff);
-                ra[j] = buf_load4(rsrc_a, ok ? off : ZSG_OOB);
-                if (PRE) okm |= ok ? (1 << j) : 0;
+                ra[j] = buf_load4(rsrc_a, ok ? 4u * (unsigned)(a_off[j] + toff) : ZSG_OOB);
             }
-            if (PRE) {
-                ps.okm = okm;
-                ps.sc = buf_load4(rsrc_p, kok ? 4u * (unsigned)koff : ZSG_OOB);
-                ps.sh = buf_load4(rsrc_p, kok ? 4u * (unsigned)(Cdim + koff) : ZSG_OOB);
-            }
-    #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const bool ok = kok & (b_off[j] >= 0);
-                rb[j] = buf_load4(rsrc_b, ok ? 4u * (unsigned)(b_off[j] + wtap) : ZSG_OOB);
-            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rb[j] = buf_load4(rsrc_b, (kok & (b_off[j] >= 0)) ? 4u * (unsigned)(b_off[j] + wtap) : ZSG_OOB);
         }
         // advance counters
         if (++cc == n_cc) {
@@ -283,47 +231,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
             }
         }
     };
-    // BX: x = x1 + x2 + x3 exactly, x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2 (round-to-nearest-even: 8 + 8 + 8
-    // significand bits with |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|); the planes are packed two values a word by the conversion
-    auto cvt_pk = [](float lo, float hi) {
-        unsigned r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
-    };
-    auto split_store = [&](float* row, const f32x4& v) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 q1, q2, q3;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float a = v[2 * h], b = v[2 * h + 1];
-            q1[h] = cvt_pk(a, b);
-            const float ra = a - __uint_as_float(q1[h] << 16), rb = b - __uint_as_float(q1[h] & 0xffff0000u);
-            q2[h] = cvt_pk(ra, rb);
-            q3[h] = cvt_pk(ra - __uint_as_float(q2[h] << 16), rb - __uint_as_float(q2[h] & 0xffff0000u));
-        }
-        *(u32x2*)(row + 2 * g) = q1;
-        *(u32x2*)(row + 16 + 2 * g) = q2;
-        *(u32x2*)(row + 32 + 2 * g) = q3;
-    };
-    auto store_tile = [&](int buf, f32x4 (&ra)[RA], const f32x4 (&rb)[RB], const PreStage& ps) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
         if ((IG_ABL & 4) && in_loop) return;
         float* a = As + buf * BM * LDR;
         float* b = Bs + buf * BN * LDR;
-        if (PRE) {
-#pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                const bool ok = (ps.okm >> j) & 1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ra[j][e] = ok ? fmaxf(fmaf(ra[j][e], ps.sc[e], ps.sh[e]), 0.f) : 0.f;
-            }
-        }
-        if (BX) {
-#pragma unroll
-            for (int j = 0; j < RA; ++j) split_store(a + (r0 + RP * j) * LDR, ra[j]);
-#pragma unroll
-            for (int j = 0; j < RB; ++j) split_store(b + (r0 + RP * j) * LDR, rb[j]);
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < RA; ++j) *(f32x4*)(a + (r0 + RP * j) * LDR + 4 * g) = ra[j];
 #pragma unroll
@@ -340,10 +251,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
 
     in_loop = false;
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
-        load_tile(ra[0], rb[0], ps[0], true);
-        store_tile(0, ra[0], rb[0], ps[0]);
+        load_tile(ra[0], rb[0], true);
+        store_tile(0, ra[0], rb[0]);
 #pragma unroll
-        for (int st = 0; st < NS - 1; ++st) load_tile(ra[st], rb[st], ps[st], n_it > st + 1);      // tiles 1 .. NS-1 stay in flight
+        for (int st = 0; st < NS - 1; ++st) load_tile(ra[st], rb[st], n_it > st + 1);      // tiles 1 .. NS-1 stay in flight
     }
     __syncthreads();
 
@@ -353,35 +264,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
 
     // one K tile: prefetch tile it+NS into `nxt` (the stage tile `it` has left), MFMA on LDS[it&1], then park tile it+1 (in `cur`,
     // requested NS-1 steps ago) in the other LDS buffer.
-    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p) {
-        load_tile(nxt_a, nxt_b, nxt_p, it + NS < n_it);
+    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB]) {
+        load_tile(nxt_a, nxt_b, it + NS < n_it);
         const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
         const float* b = Bs + (it & 1) * BN * LDR + b_row * LDR + 4 * lh;
-        if (BX) {
-            static_assert(!BX || KS <= 2, "two 16-deep sub-steps per K tile");
-#pragma unroll
-            for (int ss = 0; ss < 2 / KS; ++ss) {
-                const int sb = kg * (2 / KS) + ss;     // 16-deep sub-step: lane half h holds k = 16 sb + 8h .. +7 of its row
-                f32x4 fa[TM][3], fb[TN][3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i][pl] = *(const f32x4*)(a + i * 32 * LDR + pl * 16 + sb * 8);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j][pl] = *(const f32x4*)(b + j * 32 * LDR + pl * 16 + sb * 8);
-                }
-                // small terms first; tiles innermost so that consecutive MFMAs hit different accumulators
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[t]]),
-                                                                                __builtin_bit_cast(bf16x8, fb[j][PB[t]]), acc[i][j], 0, 0, 0);
-            }
-        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 8 / KS; ++kk) {
             const int kq = kg * (BK / 8 / KS) + kk;
@@ -412,100 +298,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 12
                     for (int j = 0; j < TN; ++j) acc[i][j][0] += fa[i][0] * fb[j][0];      // (keeps the fragment reads alive)
             }
         }
-        store_tile((it + 1) & 1, cur_a, cur_b, cur_p);      // (after the last tile: zeros into the idle buffer)
+        store_tile((it + 1) & 1, cur_a, cur_b);      // (after the last tile: zeros into the idle buffer)
         if (!(IG_ABL & 16)) __syncthreads();
     };
     in_loop = true;
-    if constexpr (R3) {
-        // ring schedule.  Invariant at the top of step t: tiles t and t+1 are complete in LDS[t % 3], LDS[(t+1) % 3]; register stage
-        // t & 1 holds tile t+2 (in flight); F[t & 1] holds this wave's fragments of tile t.
-        constexpr int NQ = BK / 8 / KS;
-        f32x4 Fa[2][NQ][TM], Fb[2][NQ][TN];
-        auto read_frags = [&](int t, f32x4 (&fa)[NQ][TM], f32x4 (&fb)[NQ][TN]) {
-            const int buf = t % 3;
-            const float* a = As + buf * BM * LDR + a_row * LDR + 4 * lh;
-            const float* b = Bs + buf * BN * LDR + b_row * LDR + 4 * lh;
-#pragma unroll
-            for (int kk = 0; kk < NQ; ++kk) {
-                const int kq = kg * NQ + kk;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[kk][i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[kk][j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
-            }
-        };
-        auto step_r3 = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p,
-                           f32x4 (&fa)[NQ][TM], f32x4 (&fb)[NQ][TN], f32x4 (&fa_n)[NQ][TM], f32x4 (&fb_n)[NQ][TN]) {
-            load_tile(nxt_a, nxt_b, nxt_p, it + 3 < n_it);              // tile it+3 -> the stage tile it+1 left last step
-            read_frags(it + 1, fa_n, fb_n);                             // in flight under this step's MFMAs
-#pragma unroll
-            for (int kk = 0; kk < NQ; ++kk)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
-            store_tile((it + 2) % 3, cur_a, cur_b, cur_p);               // tile it+2 (requested two steps ago)
-            __syncthreads();
-        };
-        // (the common prologue left tile 0 in LDS[0] and tile 1 in flight in stage 0, behind a barrier)
-        if (n_it > 0) {
-            store_tile(1, ra[0], rb[0], ps[0]);                          // tile 1 -> LDS[1]
-            load_tile(ra[0], rb[0], ps[0], n_it > 2);                    // tile 2 -> stage 0
-            __syncthreads();
-            read_frags(0, Fa[0], Fb[0]);
-        }
-        for (int it = 0; it < n_it; it += 2) {
-            step_r3(it, ra[0], rb[0], ps[0], ra[1], rb[1], ps[1], Fa[0], Fb[0], Fa[1], Fb[1]);
-            if (it + 1 < n_it) step_r3(it + 1, ra[1], rb[1], ps[1], ra[0], rb[0], ps[0], Fa[1], Fb[1], Fa[0], Fb[0]);
-        }
-    } else if constexpr (PP) {
-        const int kgu = __builtin_amdgcn_readfirstlane(kg);       // (wave-uniform: the two groups take different paths through the step)
-        auto frag_mfma_read = [&](int it, f32x4 (&fa)[BK / 16], f32x4 (&fb)[BK / 16]) {
-            const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
-            const float* b = Bs + (it & 1) * BN * LDR + b_row * LDR + 4 * lh;
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                const int kq = kgu * (BK / 16) + kk;
-                fa[kk] = *(const f32x4*)(a + kq * 8);
-                fb[kk] = *(const f32x4*)(b + kq * 8);
-            }
-        };
-        auto mfmas = [&](const f32x4 (&fa)[BK / 16], const f32x4 (&fb)[BK / 16]) {
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][e], fb[kk][e], acc[0][0], 0, 0, 0);
-        };
-        static_assert(!PP || (TM == 1 && TN == 1), "staggered K groups: one 32x32 sub-tile per wave");
-        auto step_pp = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], PreStage& cur_p, f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], PreStage& nxt_p) {
-            f32x4 fa[BK / 16], fb[BK / 16];
-            if (kgu == 0) {
-                frag_mfma_read(it, fa, fb);
-                mfmas(fa, fb);
-                __syncthreads();                                     // group 1 has parked its share of tile it+1 and holds its fragments
-                load_tile(nxt_a, nxt_b, nxt_p, it + NS < n_it);
-                store_tile((it + 1) & 1, cur_a, cur_b, cur_p);
-                __syncthreads();                                     // tile it+1 complete in LDS
-            } else {
-                load_tile(nxt_a, nxt_b, nxt_p, it + NS < n_it);
-                store_tile((it + 1) & 1, cur_a, cur_b, cur_p);
-                frag_mfma_read(it, fa, fb);
-                __syncthreads();
-                mfmas(fa, fb);
-                __syncthreads();
-            }
-        };
-        for (int it = 0; it < n_it; it += 2) {
-            step_pp(it, ra[0], rb[0], ps[0], ra[1], rb[1], ps[1]);
-            if (it + 1 < n_it) step_pp(it + 1, ra[1], rb[1], ps[1], ra[0], rb[0], ps[0]);
-        }
-    } else
     for (int it = 0; it < n_it; it += NS) {
 #pragma unroll
         for (int st = 0; st < NS; ++st)
-            if (it + st < n_it) k_step(it + st, ra[st], rb[st], ps[st], ra[(st + NS - 1) % NS], rb[(st + NS - 1) % NS], ps[(st + NS - 1) % NS]);
+            if (it + st < n_it) k_step(it + st, ra[st], rb[st], ra[(st + NS - 1) % NS], rb[(st + NS - 1) % NS]);
     }
 
     // ---- K groups: sum the accumulators into group 0 (fixed order) -----------------------------------------------------------
@@ -758,61 +558,42 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int WM, int WN, bool MX, int KS, bool BX, bool PRE, int BK, int SCH = 0>
+template <int BM, int BN, int WM, int WN, bool MX, int KS, int BK>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
-    const size_t lds = (size_t)(SCH == 2 ? 3 : 2) * (BM + BN) * (BX ? 52 : BK + 4) * sizeof(float) + BM * sizeof(int);
-    static bool attr_done = false;      // idempotent; a benign race sets it twice
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + BM * sizeof(int);
+    static bool attr_done[ZSG_MAX_DEV] = {};      // per device; idempotent (a benign race sets it twice)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "igemm: device %d", dev);
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    ZSG_LAUNCH((igemm_kernel<BM, BN, WM, WN, MX, KS, BX, PRE, BK, SCH>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    ZSG_LAUNCH((igemm_kernel<BM, BN, WM, WN, MX, KS, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
-// p.pre != nullptr selects the PRE instantiation (profile name = kname + "+pre")
-template <int BM, int BN, int WM, int WN, bool MX, int KS = 1, bool BX = false>
+// p.bk64 selects the 64-deep K tile (profile name = kname + "+k64")
+template <int BM, int BN, int WM, int WN, bool MX, int KS = 1>
 static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     if constexpr (!MX) {
-        if (p.pre) {
+        if (p.bk64) {
             static char nm[96];
-            snprintf(nm, sizeof(nm), "%s+pre", kname);
-            return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, true, IG_BK>(p, st, flops, nm);
-        }
-        if constexpr (!BX && KS == 2 && BM == 64 && BN == 64) {
-            if (p.pp && !p.bk64) {
-                static char nm[96];
-                snprintf(nm, sizeof(nm), "%s+pp", kname);
-                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK, 1>(p, st, flops, nm);
-            }
-        }
-        if constexpr (!BX && BM * BN <= 128 * 64) {
-            if (p.r3 && !p.bk64) {
-                static char nm[96];
-                snprintf(nm, sizeof(nm), "%s+r3", kname);
-                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK, 2>(p, st, flops, nm);
-            }
-        }
-        if constexpr (!BX) {
-            if (p.bk64) {
-                static char nm[96];
-                snprintf(nm, sizeof(nm), "%s+k64", kname);
-                return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, 64>(p, st, flops, nm);
-            }
+            snprintf(nm, sizeof(nm), "%s+k64", kname);
+            return launch_cfg1<BM, BN, WM, WN, MX, KS, 64>(p, st, flops, nm);
         }
     }
-    return launch_cfg1<BM, BN, WM, WN, MX, KS, BX, false, IG_BK>(p, st, flops, kname);
+    return launch_cfg1<BM, BN, WM, WN, MX, KS, IG_BK>(p, st, flops, kname);
 }
 
 // tile_hint = BM | (BN << 8) | (splits << 16); 0 = heuristic.  The Python lowering autotunes the hint per layer on
 // the device (measure, don't guess); the heuristic below is the fallback: blocks go out in rounds of one per CU and the
 // 64x64 tile (4 resident blocks per CU) hides latency best.
-static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int* w8, int* bx) {
+static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int* w8) {
     *splits = 1;
     *w8 = 0;
-    *bx = (d->tile_hint >> 26) & 1;              // bf16x6 matrix pipe (see igemm_kernel)
     if (d->tile_hint) {
         *BM = d->tile_hint & 0xff;
         *BN = (d->tile_hint >> 8) & 0xff;
@@ -840,15 +621,14 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int
 }
 
 static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
-                           const float* src_affine = nullptr) {
+                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
-    int BM = 64, BN = 64, splits = 1, w8 = 0, bx = 0;
-    pick_tile(d, &BM, &BN, &splits, &w8, &bx);
+    int BM = 64, BN = 64, splits = 1, w8 = 0;
+    pick_tile(d, &BM, &BN, &splits, &w8);
     if (d->merge_x && BN == 128) BN = 64;
     if (d->merge_x) w8 = 0;
     if (BM == 32) {                               // the filter-resident streaming kernel of the 1x1 layers (pw.hip); BN = unit width
-        ZSG_REQUIRE(!src_affine && !bx && splits <= 1, "conv_igemm: the streaming 1x1 kernel has no split-K / bf16x6 / fused-loader variant");
+        ZSG_REQUIRE(splits <= 1, "conv_igemm: the streaming 1x1 kernel has no split-K variant");
         return zsg_conv_pw_launch(d, BN, src, wt, out, bias, add_src, mask_src, bn_partials, bnb, (hipStream_t)stream);
     }
     IgParams p;
@@ -860,13 +640,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
     p.stats = bn_partials;
-    if (src_affine) {
-        ZSG_REQUIRE(!d->merge_x && ((uintptr_t)src_affine & 15) == 0, "conv_igemm_pre: needs a 16-byte aligned (scale | shift) pair and no merge_x");
-        p.pre = src_affine;
-    }
-    p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x && !bx && !src_affine;
-    p.pp = ((d->tile_hint >> 28) & 1) && !d->merge_x && !bx && !src_affine && w8 && BM == 64 && BN == 64;
-    p.r3 = ((d->tile_hint >> 29) & 1) && !d->merge_x && !bx && !src_affine && !p.pp && BM * BN <= 128 * 64;
+    p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x;
 
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
@@ -897,15 +671,6 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
         if (BM == 128) return launch_cfg<128, 64, 2, 2, true>(p, st, flops, "igemm_kernel<128, 64, 2, 2, true>");
         return launch_cfg<64, 64, 2, 2, true>(p, st, flops, "igemm_kernel<64, 64, 2, 2, true>");
     }
-    if (bx) {                                    // w8: two K groups (8 waves on the 128-wide tiles)
-        if (BM == 128 && BN == 128 && w8) return launch_cfg<128, 128, 2, 2, false, 2, true>(p, st, flops, "igemm_kernel<128, 128, 2, 2, false, 2, true>");
-        if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 2, false, 1, true>(p, st, flops, "igemm_kernel<128, 128, 2, 2, false, 1, true>");
-        if (BM == 128 && BN == 64 && w8) return launch_cfg<128, 64, 2, 2, false, 2, true>(p, st, flops, "igemm_kernel<128, 64, 2, 2, false, 2, true>");
-        if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2, false, 1, true>(p, st, flops, "igemm_kernel<128, 64, 2, 2, false, 1, true>");
-        if (BM == 64 && BN == 64 && w8) return launch_cfg<64, 64, 2, 2, false, 2, true>(p, st, flops, "igemm_kernel<64, 64, 2, 2, false, 2, true>");
-        if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2, false, 1, true>(p, st, flops, "igemm_kernel<64, 64, 2, 2, false, 1, true>");
-        ZSG_FAIL(-1, "conv_igemm: no bf16x6 variant for tile %dx%d", BM, BN);
-    }
     if (w8 && BM == 64 && BN == 64) {
         return launch_cfg<64, 64, 2, 2, false, 2>(p, st, flops, "igemm_kernel<64, 64, 2, 2, false, 2>");
     }
@@ -935,10 +700,3 @@ extern "C" int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, cons
     return conv_igemm_impl(d, src, wt, out, nullptr, add_src, nullptr, partials, &b, stream);
 }
 
-// Convolution whose logical input is relu(batchnorm(src)): src is the BatchNorm's INPUT and src_affine = (scale[C] | shift[C]) from
-// zsg_bn_affine_from_partials; the A loader applies max(fmaf(x, scale, shift), 0) to the pixels it stages (zero padding stays zero).
-extern "C" int zsg_conv_igemm_pre(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                                  const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream) {
-    ZSG_REQUIRE(src_affine, "conv_igemm_pre: null src_affine");
-    return conv_igemm_impl(d, src, wt, out, bias, add_src, mask_src, bn_partials, nullptr, stream, src_affine);
-}

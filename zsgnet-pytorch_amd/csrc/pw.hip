@@ -37,7 +37,6 @@
 #define PW_TB 68          // floats per row of a wave's tile buffer: 64 + 4 = 17 x 16 B (odd: conflict-free b128 rows)
 #define PW_WAVES 8
 #define PW_LDS_MAX (160 * 1024)
-#define PW_STAGGER_DEFAULT 0     // (start offsets measured: no gain — see pw_kernel; the switch stays for experiments)
 #include <stdlib.h>
 
 struct PwParams {
@@ -56,7 +55,6 @@ struct PwParams {
     int NS;               // column splits of a workgroup's panel: NB = NS x 32 NJ
     int NCB, NB;          // column blocks: the filter is cut into NCB panels of NB = N / NCB rows, one per workgroup
     int rt;               // row tiles: ceil(M / 32)
-    int stagger, stagger_mask;   // start offset of the waves with (wave & stagger_mask) != 0, in units of 512 cycles (see pw_kernel)
     int ns_shift;         // log2(NS)
 };
 
@@ -192,11 +190,8 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
     request(R[0], req_u, req_k);
     PW_ADVANCE();
     __syncthreads();
-    // Two waves share a SIMD and nothing ties them together — but started at the same instant on equal work they stay in LOCK-STEP
-    // (both in their MFMA phase, then both in their epilogue with the matrix pipe idle).  A start offset of about one MFMA phase for
-    // one wave of each pair breaks the symmetry: from then on one wave's loads / transposition / stores run under the other's MFMAs.
-    if (wave & p.stagger_mask)
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    // (The two waves of a SIMD are NOT decoupled by a start offset: while one streams fp32 MFMAs the other issues nothing at all on
+    // gfx950, tools/ubench/mfma_coissue.hip — offsets of 2 000 - 8 000 cycles measured neutral to slower, profiles/r03_pw_stagger.txt.)
 
     const bool has_add = p.add_src != nullptr, has_mask = p.mask_src != nullptr, has_bits = p.bnb.mask != nullptr;
     const rsrc_t rs_out = make_rsrc(p.out);
@@ -479,11 +474,14 @@ extern "C" int32_t zsg_conv_igemm_partial_rows(const zsg_conv_desc* d) {
 
 template <int NJ, int MODE>
 static int pw_launch2(const PwParams& p, int grid, size_t lds, hipStream_t st, double flops, const char* kname) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[ZSG_MAX_DEV] = {};       // per device (a process may drive several GPUs); idempotent
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_pw: device %d", dev);
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)pw_kernel<NJ, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_MAX);
         if (e != hipSuccess) ZSG_FAIL(-3, "conv_pw: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, 0);
     ZSG_LAUNCH((pw_kernel<NJ, MODE>), dim3(grid), dim3(64 * PW_WAVES), lds, st, p);
@@ -518,20 +516,6 @@ int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw_hint, const float* src, co
     p.NB = d->N / ncb;
     p.NS = p.NB / uw;
     p.rt = cdiv(p.M, 32);
-    {
-        static int stg = -2, msk = 4;
-        if (stg == -2) {      // ZSG_PW_STAGGER=<units of 512 cycles>[,<wave mask>] (experiments); default: one MFMA phase of the unit
-            const char* e = getenv("ZSG_PW_STAGGER");
-            stg = -1;
-            if (e) {
-                stg = atoi(e);
-                const char* c = strchr(e, ',');
-                if (c) msk = atoi(c + 1);
-            }
-        }
-        p.stagger_mask = msk;
-        p.stagger = stg >= 0 ? stg : PW_STAGGER_DEFAULT;
-    }
     p.ns_shift = p.NS == 8 ? 3 : p.NS == 4 ? 2 : p.NS == 2 ? 1 : 0;
     if (bnb) {
         ZSG_REQUIRE(bn_partials && bnb->x && bnb->mean && bnb->invstd && !bias && !d->relu && !mask_src, "conv_igemm_bnb: bad argument");

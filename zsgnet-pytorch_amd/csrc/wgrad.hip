@@ -60,21 +60,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgReduceJob p) 
     else wgrad_reduce_body<4>(p, blockIdx.x, sm);
 }
 
-
-// Batched form: ONE launch reduces the slabs of several weight-gradient launches (each left its partial tiles in its own
-// workspace region: zsg_conv_wgrad_partial / zsg_conv_wgrad_wino_partial).  A block finds its job by its index range.
-__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceJob* __restrict__ jobs, int njobs) {
-    __shared__ f32x4 sm[256];
-    int lo = 0, hi = njobs - 1;                      // last job whose blk0 <= blockIdx.x
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const WgReduceJob jb = jobs[lo];
-    if (jb.kl == 16) wgrad_reduce_body<16>(jb, blockIdx.x - jb.blk0, sm);
-    else wgrad_reduce_body<4>(jb, blockIdx.x - jb.blk0, sm);
-}
-
 void wg_reduce_job_fill(WgReduceJob& j, const zsg_conv_desc* d, const float* ws, float* dw, int accumulate, int splits) {
     memset(&j, 0, sizeof(j));
     j.ws = ws; j.dw = dw; j.accumulate = accumulate ? 1 : 0; j.splits = splits;
@@ -294,7 +279,7 @@ extern "C" size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d) {
 }
 
 static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                           size_t ws_bytes, void* stream, int32_t* n_slabs) {
+                           size_t ws_bytes, void* stream) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0,
@@ -366,18 +351,21 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
         p.ws = (float*)ws;
     }
     hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_wgrad: device %d", dev);
     const double wg_flops = 2.0 * rows_all * d->N * p.ncols;
     dim3 grid(nmn * p.splits);
 #define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_) WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, true)
 #define WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, AV_)                                                                          \
     do {                                                                                                                   \
         const size_t lds = (size_t)2 * BK_ * ((32 * TM_ * WM_ + WG_PAD) + (32 * TN_ * WN_ + WG_PAD)) * sizeof(float);       \
-        static bool attr_done = false;                                                                                     \
-        if (!attr_done) {                                                                                                  \
+        static bool attr_done[ZSG_MAX_DEV] = {};                                                                           \
+        if (!attr_done[dev]) {                                                                                             \
             hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>,                     \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
-            attr_done = true;                                                                                              \
+            attr_done[dev] = true;                                                                                         \
         }                                                                                                                  \
         ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, 0);                        \
         ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>), grid, dim3(64 * WM_ * WN_), lds, st, p);           \
@@ -401,9 +389,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     }
 #undef WG_LAUNCH
 #undef WG_LAUNCH_A
-    if (n_slabs) {
-        *n_slabs = p.splits;                        // the caller reduces (zsg_wgrad_reduce_batched)
-    } else if (p.splits > 1) {
+    if (p.splits > 1) {
         WgReduceJob j;
         wg_reduce_job_fill(j, d, p.ws, dw, p.accumulate, p.splits);
         wg_reduce_launch(j, st);
@@ -414,38 +400,5 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
 
 extern "C" int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                               size_t ws_bytes, void* stream) {
-    return conv_wgrad_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, nullptr);
-}
-
-// The same launch WITHOUT its slab reduction: when the K dimension is split (*n_slabs > 1) the partial tiles stay in ws as
-// [n_slabs][N][ncols] and dw is untouched — the caller sums them later, many layers at a time (zsg_wgrad_reduce_batched);
-// *n_slabs == 1: the result was written / accumulated into dw directly.
-extern "C" int zsg_conv_wgrad_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                                      size_t ws_bytes, int32_t* n_slabs, void* stream) {
-    ZSG_REQUIRE(n_slabs, "conv_wgrad_partial: null n_slabs");
-    return conv_wgrad_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, n_slabs);
-}
-
-extern "C" int32_t zsg_wgrad_reduce_job_bytes(void) { return (int32_t)sizeof(WgReduceJob); }
-
-// Fills one job record (host memory, zsg_wgrad_reduce_job_bytes() bytes) for the slabs a *_partial launch with the same
-// descriptor left in ws; returns the number of blocks the job needs (the caller accumulates blk0 over the jobs of a launch).
-extern "C" int32_t zsg_wgrad_reduce_job(const zsg_conv_desc* d, const float* ws, float* dw, int32_t accumulate, int32_t n_slabs,
-                                        int32_t blk0, void* job_out) {
-    if (!d || !ws || !dw || !job_out || n_slabs < 2) return -1;
-    WgReduceJob j;
-    wg_reduce_job_fill(j, d, ws, dw, accumulate, n_slabs);
-    j.blk0 = blk0;
-    memcpy(job_out, &j, sizeof(j));
-    return wg_reduce_blocks(j.N, j.ncols, j.kl);
-}
-
-// dw (+)= sum over slabs, for every job of the device array, in ONE launch (fixed summation order per element: deterministic).
-extern "C" int zsg_wgrad_reduce_batched(const void* jobs_dev, int32_t njobs, int32_t total_blocks, double total_bytes, void* stream) {
-    ZSG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "wgrad_reduce_batched: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    ZSG_PROF("wgrad_reduce_kernel", st, 0, total_bytes);
-    ZSG_LAUNCH(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, st, (const WgReduceJob*)jobs_dev, njobs);
-    ZSG_CHECK_LAUNCH("wgrad_reduce_batched");
-    return 0;
+    return conv_wgrad_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream);
 }

@@ -44,15 +44,13 @@ __device__ __forceinline__ int fdiv(int a, int d, float rcp) {   // a < 2^24, ex
     return q;
 }
 
-// One slab reduction: dw[n][col(q)] (+)= sum_s ws[s][n][q].  (Also the job record of zsg_wgrad_reduce_batched: plain data, filled
-// on the host by zsg_wgrad_reduce_job.)
+// One slab reduction: dw[n][col(q)] (+)= sum_s ws[s][n][q].
 struct WgReduceJob {
     const float* ws;
     float* dw;
     int N, ncols, splits, C, txn, wS, wC, wc0, wt_ld, accumulate;
     int ty_w0, ty_wstep, tx_w0, tx_wstep;
     int kl;           // split lanes per element (16 | 4)
-    int blk0;         // first block of this job in a batched launch
 };
 
 static inline int wg_reduce_kl(int N, int ncols, int splits) {

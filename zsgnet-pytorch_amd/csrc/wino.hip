@@ -45,7 +45,6 @@ struct WnParams {
     const float* bias;
     const float* add_src;
     const float* mask_src;
-    const float* pre;    // PRE kernels: (scale[C] | shift[C]): the A loader transforms max(fmaf(x, scale[c], shift[c]), 0) instead of x
     float* stats;        // optional BatchNorm partials [m_blocks][2][N]
     BnbDev bnb;          // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (common.h)
     int C, N, Npad, src_ld, out_ld, relu, nseg;
@@ -62,11 +61,7 @@ __device__ __forceinline__ float quad_other(float v) {
 
 // PS position groups per 32x32 sub-block: wave (ph, wm, wn) holds the 16/PS positions with i in {2ph, 2ph+1} (PS = 2) or
 // i = ph (PS = 4).  PS = 4 doubles the waves per SIMD for the same tile (64 instead of 128 accumulator registers each).
-// PRE: the source tensor is the INPUT of a train-mode BatchNorm + ReLU whose output this convolution logically consumes (Bottleneck
-// conv1 -> bn1 -> relu -> conv2, fpn_resnet.py:86-91): the loader applies the BatchNorm (one fma with the per-channel (scale, shift)
-// pair of zsg_bn_affine_from_partials, staged once per block into LDS) and the ReLU between the pixel loads and the row transform;
-// out-of-image pixels stay exact zeros (the padding is of the normalised activation, not of its input).
-template <int TM, int TN, int PS, bool PRE = false>
+template <int TM, int TN, int PS>
 __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnParams p) {
     constexpr int NT = 64 * PS * TM * TN;        // PS position groups x TM x TN waves
     constexpr int NP = 16 / PS;                  // positions (accumulator tiles) per wave
@@ -82,7 +77,6 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     float* As = smem;                            // [2][16][SA]
     float* Bs = smem + 2 * 16 * SA;              // [2][16][SB]
     int* rowinfo = (int*)(smem + 2 * 16 * (SA + SB));   // [TB][2]: output offset of pixel (2ty, 2tx) | -1 ; validity bits
-    float* aff = (float*)(rowinfo + 2 * TB);            // PRE: [2][chunks * 8] (scale | shift), zero beyond C
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -111,7 +105,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     // with a SIMD's fp32 MFMA stream (tools/ubench/mfma_coissue.hip: a partner wave retires ~0 instructions while its SIMD mate
     // multiplies, a wave's own VALU costs ~6 cycles each on top of its MFMAs), so every instruction of this loop is paid in full.
     unsigned a_voff[IA][4], a_voff_t[IA][4];       // a_voff_t: the last chunk of a C % 8 == 4 tensor (its upper channel quad is dead)
-    int a_lds[IA], a_mask[IA];
+    int a_lds[IA];
     const bool c_tail = (p.C & 4) != 0;
 #pragma unroll
     for (int ia = 0; ia < IA; ++ia) {
@@ -130,8 +124,6 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const bool pok = rok & ((unsigned)(x0 + c) < (unsigned)sg.W);
-            if (c == 0) a_mask[ia] = 0;
-            a_mask[ia] |= pok ? (1 << c) : 0;
             a_voff[ia][c] = pok ? 4u * (unsigned)((WN_ABL & 1) ? 4 * (tid & 7) : base + c * src_ld) : ZSG_OOB;
             a_voff_t[ia][c] = (pok && !(c_tail && g)) ? a_voff[ia][c] : ZSG_OOB;
         }
@@ -167,20 +159,12 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
         nc = min(per, p.chunks - c0);
     }
 
-    const int aff_ld = p.chunks * WN_CK;
-    if (PRE) {
-        for (int i = threadIdx.x; i < 2 * aff_ld; i += NT) {
-            const int h = i >= aff_ld, c = i - h * aff_ld;
-            aff[i] = (c < p.C) ? p.pre[h * p.C + c] : 0.f;
-        }
-        __syncthreads();
-    }
     f32x4 ra[IA][4];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto load_a = [&](int c, bool live) {          // c, live: wave-uniform
         if (!a_thr || !live || (WN_ABL & 16)) return;      // (a dead prefetch leaves ra as it is: it is stored into the idle buffer, never read)
         const int so = (WN_ABL & 1) ? 0 : c * (WN_CK * 4); // bytes, SGPR
-        if (PRE || !(c_tail && c == p.chunks - 1)) {
+        if (!(c_tail && c == p.chunks - 1)) {
 #pragma unroll
             for (int ia = 0; ia < IA; ++ia)
 #pragma unroll
@@ -208,21 +192,9 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     // V'[3] = t3 - t1 = -V[3] (zsg_wino_weights negates row 3 of U to match): every lane computes own + sgn * other with
     // ONE cross-lane operand, i.e. one v_fmac_f32 with a DPP source per value.
     const float sgn = (q == 1) ? 1.f : -1.f;
-    auto store_a = [&](int buf, int c) {           // c: the chunk held in ra (PRE: selects the channel group's scale / shift)
+    auto store_a = [&](int buf) {
         if (!a_thr || (WN_ABL & 16)) return;
         float* a = As + buf * 16 * SA;
-        if (PRE) {
-            const int ko = min(c, p.chunks - 1) * WN_CK + 4 * g;
-            const f32x4 sc = *(const f32x4*)(aff + ko), sh = *(const f32x4*)(aff + aff_ld + ko);
-#pragma unroll
-            for (int ia = 0; ia < IA; ++ia)
-#pragma unroll
-                for (int col = 0; col < 4; ++col) {
-                    const bool ok = (a_mask[ia] >> col) & 1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ra[ia][col][e] = ok ? fmaxf(fmaf(ra[ia][col][e], sc[e], sh[e]), 0.f) : 0.f;
-                }
-        }
 #pragma unroll
         for (int ia = 0; ia < IA; ++ia) {
             f32x4 t[4];                            // row transform (d B): this lane's patch row q
@@ -249,7 +221,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     if (nc > 0) {
         load_b(c0, 0);
         load_a(c0, true);
-        store_a(0, c0);
+        store_a(0);
         if (ph & 1) load_a(c0 + 1, nc > 1);        // the late groups transform FIRST in every chunk: their next chunk is prefetched here
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -290,7 +262,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pl = NP1; pl < NP; ++pl) mfma_pos(a, b, pl);
-            store_a((it + 1) & 1, c0 + it + 1);    // (after the last chunk: into the idle buffer, never read)
+            store_a((it + 1) & 1);    // (after the last chunk: into the idle buffer, never read)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -299,7 +271,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
             const float* a = As + (it & 1) * 16 * SA + frag_a;
             const float* b = Bs + (it & 1) * 16 * SB + frag_b;
             if (it + 1 < nc) load_b(c0 + it + 1, (it + 1) & 1);
-            store_a((it + 1) & 1, c0 + it + 1);
+            store_a((it + 1) & 1);
             load_a(c0 + it + 2, it + 2 < nc);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -560,46 +532,33 @@ extern "C" int zsg_wino_weights(const void* jobs_dev, int32_t njobs, int32_t tot
     return 0;
 }
 
-template <int TM, int TN, int PS, bool PRE>
-static int wino_launch1(const WnParams& p, hipStream_t st, double flops, const char* kname) {
+template <int TM, int TN, int PS>
+static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
     constexpr int TB = 32 * TM, BN = 32 * TN, NT = 64 * PS * TM * TN;
     constexpr int SA = TB * 8 + 8, SB = BN * 8;
     constexpr size_t stage = (size_t)2 * 16 * (SA + SB) * sizeof(float);
     constexpr size_t epi = ((size_t)TB * 4 * (BN + 4) + 2 * (NT / (BN / 4)) * BN) * sizeof(float);
     static_assert(epi <= stage, "the epilogue's transposed tile + statistics rows reuse the K-loop staging area (rowinfo sits behind it)");
     static_assert(stage + TB * 2 * sizeof(int) <= 160 * 1024, "staging area exceeds a CU's LDS");
-    // (PRE: the (scale | shift) table sits behind rowinfo; the epilogue no longer needs it)
-    const size_t lds = stage + TB * 2 * sizeof(int) + (PRE ? (size_t)2 * p.chunks * WN_CK * sizeof(float) : 0);
-    ZSG_REQUIRE(lds <= 160 * 1024, "conv_wino: %zu bytes of LDS (C = %d is too large for the source-transform variant)", lds, p.C);
-    static size_t attr_lds[ZSG_MAX_DEV] = {};      // per device (PRE: grows with C; a benign race sets it twice)
+    const size_t lds = stage + TB * 2 * sizeof(int);
+    static bool attr_done[ZSG_MAX_DEV] = {};       // per device (a benign race sets it twice)
     int dev = 0;
     (void)hipGetDevice(&dev);
     ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_wino: device %d", dev);
-    if (lds > attr_lds[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_lds[dev] = lds;
+        attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, 0);
-    ZSG_LAUNCH((wino_kernel<TM, TN, PS, PRE>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
+    ZSG_LAUNCH((wino_kernel<TM, TN, PS>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_wino");
     return 0;
 }
-template <int TM, int TN, int PS>
-static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
-    if (p.pre) {
-        static char nm[64];
-        snprintf(nm, sizeof(nm), "%s+pre", kname);
-        return wino_launch1<TM, TN, PS, true>(p, st, flops, nm);
-    }
-    return wino_launch1<TM, TN, PS, false>(p, st, flops, kname);
-}
-
 // tile_hint = TB | (BN << 8) | (split_k << 16) | (four position groups << 24), TB (tiles per block) and BN in {32, 64};
 // 0 = 64x64, two position groups, no split
 static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
-                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
-                          const float* src_affine = nullptr) {
+                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
     ZSG_REQUIRE(d && src && U && out, "conv_wino: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0, "conv_wino: C=%d src_ld=%d must be multiples of 4", d->C, d->src_ld);
@@ -611,7 +570,6 @@ static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float*
     WnParams p;
     memset(&p, 0, sizeof(p));
     p.src = src; p.U = U; p.out = out; p.bias = bias; p.add_src = add_src; p.mask_src = mask_src; p.stats = bn_partials;
-    p.pre = src_affine;
     p.C = d->C; p.N = d->N; p.Npad = (d->N + 63) / 64 * 64; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.relu = d->relu;
     p.nseg = d->nseg; p.chunks = (d->C + WN_CK - 1) / WN_CK; p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
@@ -687,9 +645,3 @@ extern "C" int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const
     return conv_wino_impl(d, src, U, out, nullptr, add_src, nullptr, partials, &b, stream);
 }
 
-// see zsg_conv_igemm_pre: the logical input is relu(batchnorm(src)), applied by the loader from src_affine = (scale[C] | shift[C])
-extern "C" int zsg_conv_wino_pre(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
-                                 const float* add_src, const float* mask_src, float* bn_partials, const float* src_affine, void* stream) {
-    ZSG_REQUIRE(src_affine, "conv_wino_pre: null src_affine");
-    return conv_wino_impl(d, src, U, out, bias, add_src, mask_src, bn_partials, nullptr, stream, src_affine);
-}

@@ -291,7 +291,7 @@ extern "C" size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d) {
 // Same contract as zsg_conv_wgrad (forward descriptor, dy in the "out" geometry, accumulate flag, split-K workspace,
 // deterministic slab reduction); 3x3 / stride 1 / pad 1 only.  tile_hint: split_k << 16 (0: heuristic).
 static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                                size_t ws_bytes, void* stream, int32_t* n_slabs) {
+                                size_t ws_bytes, void* stream) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad_wino: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0 && (d->out_ld % 4) == 0,
@@ -340,19 +340,20 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
     }
     hipStream_t stq = (hipStream_t)stream;
     const size_t lds = (size_t)4 * 16 * WW_SP * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[ZSG_MAX_DEV] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_wgrad_wino: device %d", dev);
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "wgrad_wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     {
         ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, 0);
         ZSG_LAUNCH(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
     }
-    if (n_slabs) {
-        *n_slabs = p.splits;       // the caller reduces (zsg_wgrad_reduce_batched)
-    } else if (p.splits > 1) {     // fixed-order slab sum -> dw (shared with the direct kernel)
+    if (p.splits > 1) {     // fixed-order slab sum -> dw (shared with the direct kernel)
         WgReduceJob r;
         wg_reduce_job_fill(r, d, p.ws, dw, p.accumulate, p.splits);
         wg_reduce_launch(r, stq);
@@ -363,12 +364,5 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
 
 extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                                    size_t ws_bytes, void* stream) {
-    return conv_wgrad_wino_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, nullptr);
-}
-
-// see zsg_conv_wgrad_partial
-extern "C" int zsg_conv_wgrad_wino_partial(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                                           size_t ws_bytes, int32_t* n_slabs, void* stream) {
-    ZSG_REQUIRE(n_slabs, "conv_wgrad_wino_partial: null n_slabs");
-    return conv_wgrad_wino_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream, n_slabs);
+    return conv_wgrad_wino_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream);
 }

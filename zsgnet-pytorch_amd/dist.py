@@ -217,16 +217,25 @@ class DistributedDataParallel(nn.Module):
     def _sync_tuning(self, inp):
         """Rank 0 lowers (and autotunes) the launch plan of a new input geometry first and broadcasts its tile choices; the other
         ranks lower from that table.  Every rank then runs the SAME kernel variant for the same layer (each rank tuning on its own
-        would pick by its own timing noise — harmless for the all-reduced gradients, but not reproducible, and 8x the tuning time)."""
+        would pick by its own timing noise — harmless for the all-reduced gradients, but not reproducible, and 8x the tuning time).
+
+        The decision to run the broadcast must be the same on every rank, so it is keyed on what all ranks share at a given step —
+        (B, H, W, training): equal-sized shards (DistributedSampler pads), one mode — and NOT on the query-length bucket: the collater
+        cuts qvec to the batch's longest query (dat_loader.py, as the reference's), so T_plan (20 / 50) differs from rank to rank
+        and step to step.  (Keyed on T, a rank that met a bucket earlier than its peers skipped the broadcast they were waiting
+        in: mismatched collectives.)  Rank 0 lowers the plan of ITS current bucket; the image branch — everything but the two
+        query-encoder input projections — does not depend on T, and a rank that later needs another bucket tunes those two
+        launches itself."""
         if not hasattr(self.module, "plan_geometry"):
             return
         from . import ops
-        key = self.module.plan_geometry(inp) + (self.module.training,)
+        geo = self.module.plan_geometry(inp)
+        key = tuple(geo[:3]) + (self.module.training,)
         if key in self._tuned:
             return
         self._tuned.add(key)
-        if get_rank() == 0 and key not in self.module._plans:
-            self.module._plan_for(*key[:4])
+        if get_rank() == 0 and (tuple(geo) + (self.module.training,)) not in self.module._plans:
+            self.module._plan_for(*geo[:4])
         payload = [dict(ops._TUNE_CACHE) if get_rank() == 0 else None]
         dist.broadcast_object_list(payload, src=0, group=self.group)
         if get_rank() != 0:

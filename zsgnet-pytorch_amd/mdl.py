@@ -67,21 +67,6 @@ class BnL:
 
 
 BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward sums in the epilogue of the data gradient that completes dout
-# conv -> bn -> relu -> conv chains: the second convolution applies the BatchNorm + ReLU while it loads the first one's output
-# (zsg_conv_*_pre); the normalised activation the backward needs is materialised off the forward's dependent chain (side stream)
-WG_BATCH_MAX = int(os.environ.get("ZSG_WG_BATCH_MAX", "8"))       # weight gradients per batched slab reduction ...
-WG_BATCH_MB = int(os.environ.get("ZSG_WG_BATCH_MB", "128"))      # ... or this many MB of slabs, whichever comes first
-
-
-def wg_batch() -> bool:
-    """ZSG_WG_BATCH=1 (default OFF): the weight-gradient launches leave their split-K slabs in workspace regions of their own and
-    one launch reduces several layers' slabs (tests/test_gpu_wgbatch.py: bit-identical to the per-layer reduction).  Measured in
-    round 3: 69 reduce launches -> 10-35, step 14.31 -> 14.45-14.56 ms at 2 / 3 / 4 / 8 layers per launch: the
-    per-layer reduce reads slabs its own weight-gradient kernel has just written (Infinity-Cache resident, one shared 256 MB
-    workspace), the batched one reads them cold."""
-    return os.environ.get("ZSG_WG_BATCH", "0") == "1"
-
-
 def prep_at() -> str:
     """ZSG_PREP_AT: where the backward's weight images are enqueued on the side stream during the forward (see _Plan._prep_index)."""
     return os.environ.get("ZSG_PREP_AT", "j2")
@@ -93,25 +78,15 @@ def lang_at() -> str:
     return os.environ.get("ZSG_LANG_AT", "j3")
 
 
-def prep_release_top() -> bool:
-    return os.environ.get("ZSG_PREP_RELEASE_TOP", "1") == "1"
-
-
 def adam_overlap() -> bool:
     """ZSG_ADAM_OVERLAP=1 (default OFF): with FusedAdam attached the backward does not join the side stream at its end; FusedAdam.step
     updates every parameter behind the stem / first block under the side stream's last weight gradients and the rest after the join
-    (bit-identical: tests/test_gpu_determinism.py).  Measured in round 3: 14.30 vs 14.28 ms — the 2048-block HBM-bound update and the
-    stem's weight gradient do not overlap to any profit; off by default (the plain join has the simpler contract)."""
+    (bit-identical: tests/test_gpu_determinism.py).  Measured in round 3: 14.30 vs 14.28 ms; off by default."""
     return os.environ.get("ZSG_ADAM_OVERLAP", "0") == "1"
 
 
-def bn_consumer_fuse() -> bool:
-    """ZSG_BN_CONSUMER_FUSE=1 (read when a plan is lowered; default OFF).  Built and measured in round 3 (profiles/
-    r03_prefuse_ab.txt): the fused loaders cost the consumer convolution 3-6 us (Winograd: the transform is redone by up to four
-    overlapping tiles; strided 3x3: 12-14 us) against 7-11 us per apply launch taken off the chain — and the materialising applies
-    do NOT overlap the head's Winograd launches on the side stream (those blocks own a CU's whole register file), so the forward
-    went 5.22 -> 5.39 ms and the step 14.32 -> 14.49 ms.  Kept as an opt-in, parity-tested path (tests/test_gpu_prefuse.py)."""
-    return os.environ.get("ZSG_BN_CONSUMER_FUSE", "0") == "1"
+def prep_release_top() -> bool:
+    return os.environ.get("ZSG_PREP_RELEASE_TOP", "1") == "1"
 
 
 class Act(TView):
@@ -498,6 +473,7 @@ class _Plan:
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
         self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
+        self._bwd_fwd = -2               # fwd_id of the forward whose backward ran last (a second backward re-runs the preparation)
         self._rel_ev = torch.cuda.Event()
         self._prep_idx_v = False
         self._adam_ev, self._adam_cut_v = None, False
@@ -534,7 +510,7 @@ class _Plan:
             self.prep_u.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
             self.prep_u.calls.insert(0, self.prep_u.calls.pop())          # (needed first)
             self.prep_u.lanes.insert(0, self.prep_u.lanes.pop())
-            wfns = (lib.zsg_conv_wino, lib.zsg_conv_wino_pre)
+            wfns = (lib.zsg_conv_wino,)
             self._wait_idx = min(self._wait_idx, next(i for i, c in enumerate(self.fwd.calls) if c[0] in wfns))
         elif wj.jobs:        # eval (after the BatchNorm fold): first launch after the image conversion
             self.fwd.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
@@ -642,14 +618,9 @@ class _Plan:
         tb = d.tile_hint & 0xff
         return sum((B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) + tb - 1) // tb for i in range(d.nseg))
 
-    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None, bn_fuse: Optional[BnL] = None,
-             bn_defer: bool = False) -> Act:
+    def conv(self, L: ConvL, src: Act, relu=False, out: Optional[Act] = None, name=None, bn_fuse: Optional[BnL] = None) -> Act:
         """bn_fuse: the output feeds a train-mode BatchNorm — let the epilogue emit the per-tile (sum, sum^2) partials
-        (no extra pass over the activation) unless the autotuner chose split-K for this layer.
-        bn_defer: that BatchNorm (+ ReLU) will be applied by the NEXT convolution's operand loader: finalize the statistics into a
-        (scale | shift) pair right here (see bn()).
-        src.pre = (y, affine): src is such a deferred BatchNorm output — the forward launch reads y and transforms it on the fly
-        (zsg_conv_igemm_pre / zsg_conv_wino_pre); the backward (tape) sees src itself, materialised off the critical chain."""
+        (no extra pass over the activation) unless the autotuner chose split-K for this layer."""
         if out is None:
             lv = src.levels
             assert len(lv) == 1
@@ -657,10 +628,8 @@ class _Plan:
                            conv_out(lv[0].W, L.k, L.stride, L.pad, L.dil), L.cout)
         d = fwd_desc(src, out, L.cpad, L.cout, L.k, L.stride, L.pad, L.dil, wC=L.cpad, relu=relu, merge_x=L.merge_x)
         bias = self.P(L.name + ".bias") if L.bias else None
-        pre = getattr(src, "pre", None) if self.training else None
-        rd = pre[0] if pre else src                    # the tensor the forward launch reads
-        tail = (pre[1],) if pre else ()
-        ig_fn, wn_fn = (lib.zsg_conv_igemm_pre, lib.zsg_conv_wino_pre) if pre else (lib.zsg_conv_igemm, lib.zsg_conv_wino)
+        rd = src
+        ig_fn, wn_fn = lib.zsg_conv_igemm, lib.zsg_conv_wino
         # a split-K choice would cost this layer its fused BatchNorm statistics: a statistics pass over the output at
         # ~4 TB/s plus two more dependent launches
         pen = 0.0
@@ -670,8 +639,8 @@ class _Plan:
         wargs = None
         if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
             U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
-            wargs = (rd.buf, U, out.buf, bias, None, None, None) + tail
-        autotune_conv("igemm", ig_fn, d, (rd.buf, wt, out.buf, bias, None, None, None) + tail, stream_ptr(),
+            wargs = (rd.buf, U, out.buf, bias, None, None, None)
+        autotune_conv("igemm", ig_fn, d, (rd.buf, wt, out.buf, bias, None, None, None), stream_ptr(),
                       split_penalty_ms=pen, wino_args=wargs, wino_fn=wn_fn)
         fn = ig_fn
         if d.use_wino:
@@ -694,19 +663,11 @@ class _Plan:
             lv0 = out.levels[0]
             self.prep_u.add(lib.zsg_memset_f32, out.buf[lv0.off:], out.B * lv0.bstride, 0.0, what="zero:" + L.name)
             pre_zero = out.buf
-        self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, pre_zero, None, partials, *tail, what=L.name + ("+pre" if pre else ""), lane=self._lane)
+        self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, pre_zero, None, partials, what=L.name, lane=self._lane)
         if pre_zero is not None:
             self._zero_calls.append(self.fwd.calls[-1])
-        out.bn_inline = out.bn_affine = None
-        if partials is not None and bn_defer and bn_consumer_fuse():
-            # finalize at once into mean / invstd AND the (scale | shift) pair the consumer convolution's loader applies
-            Lb = bn_fuse
-            rows = sum(src.B * d.seg[i].rows_y * d.seg[i].rows_x for i in range(d.nseg))
-            out.bn_mean, out.bn_invstd, out.bn_affine = self._buf(Lb.c), self._buf(Lb.c), self._buf(2 * Lb.c)
-            rm, rv = self.net._rm[Lb.index:Lb.index + Lb.c], self.net._rv[Lb.index:Lb.index + Lb.c]
-            self.fwd.add(lib.zsg_bn_affine_from_partials, partials, out.bn_chunks, rows, Lb.c, self.P(Lb.name + ".weight"), self.P(Lb.name + ".bias"),
-                         out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5, out.bn_affine, what="affine:" + Lb.name, lane=self._lane)
-        elif partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
+        out.bn_inline = None
+        if partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
             # few partial rows: the BatchNorm apply launch (the very next launch on this stream: the workspace is still intact)
             # reduces them itself — no finalize launch
             out.bn_inline = partials
@@ -726,15 +687,13 @@ class _Plan:
         self.tape.append(lambda: self._conv_bwd(L, src, out, completes_bn=completes))
         return out
 
-    def conv_bn(self, L: ConvL, Lb: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, yname=None,
-                defer: bool = False) -> Act:
+    def conv_bn(self, L: ConvL, Lb: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, yname=None) -> Act:
         """conv -> BatchNorm [-> + residual] [-> ReLU].  Training: the two lowered ops (batch statistics from the conv
         epilogue).  Eval: ONE convolution with the BatchNorm folded into its weights / bias (zsg_bn_fold refreshes the
         folded copies at the start of every eval forward), residual add and ReLU in its epilogue."""
         if self.training:
-            defer = defer and relu and residual is None
-            y = self.conv(L, x, name=yname or (L.name + ".y"), bn_fuse=Lb, bn_defer=defer)
-            return self.bn(Lb, y, relu, residual=residual, name=name, defer=defer)
+            y = self.conv(L, x, name=yname or (L.name + ".y"), bn_fuse=Lb)
+            return self.bn(Lb, y, relu, residual=residual, name=name)
         net = self.net
         n_w = L.cout * L.k * L.k * L.cpad
         w_off = self.fold_used
@@ -819,45 +778,7 @@ class _Plan:
         wino = (d.wR == 3 and d.wS == 3 and s0.sy == 1 and s0.ty.d0 == -1 and s0.ty.dstep == 1 and not d.merge_x
                 and dy.ld % 4 == 0 and wino_mode() != "0")       # 3x3 / stride 1 / pad 1: Winograd F(3x3,2x2) candidates
         autotune_conv("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
-        if not wg_batch():
-            self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
-            return
-        # Batched slab reduction: the launch leaves its split-K partial tiles in a workspace region of its own and ONE reduce launch
-        # sums the slabs of several layers (a per-layer reduce is a 3-10 us dependent launch between two weight-gradient kernels on
-        # the side stream: 69 of them per ResNet-50 step).  288 GB of HBM: no slab region is ever reused within a step.
-        import ctypes as C_
-        fn = lib.zsg_conv_wgrad_wino_partial if d.use_wino else lib.zsg_conv_wgrad_partial
-        need = int((lib.zsg_conv_wgrad_wino_workspace_bytes if d.use_wino else lib.zsg_conv_wgrad_workspace_bytes)(C_.byref(d)))
-        ws_own = self._buf(max(need // 4, 4))
-        ns = C_.c_int32(0)
-        check(fn(C_.byref(d), src.buf.data_ptr(), dy.buf.data_ptr(), self.tune_dw.data_ptr(), 0, ws_own.data_ptr(), need, C_.addressof(ns),
-                 C_.c_void_p(stream_ptr())), what)          # (one real launch into scratch: learns the effective slab count)
-        self.bwd.add(fn, d, src.buf, dy.buf, gw, 1, ws_own, need, C_.addressof(self._nslab_sink), what=what, lane=1)
-        if ns.value > 1:
-            self._wg_pending.append((d, ws_own, gw, ns.value, pname))
-            self._wg_pending_bytes += ns.value * d.N * d.seg[0].ty.n * d.seg[0].tx.n * d.C * 4
-            if len(self._wg_pending) >= WG_BATCH_MAX or self._wg_pending_bytes >= (WG_BATCH_MB << 20):
-                self._wg_flush()
-
-    def _wg_flush(self):
-        """ONE launch sums the slabs of every pending weight gradient into the flat gradient buffer (side stream, behind them)."""
-        if not self._wg_pending:
-            return
-        import ctypes as C_
-        jb = int(lib.zsg_wgrad_reduce_job_bytes())
-        host = (C_.c_char * (jb * len(self._wg_pending)))()
-        blk, nbytes = 0, 0.0
-        at = len(self.bwd.calls)                  # index of the reduce launch: the gradients below are complete only after it
-        for i, (d, ws_own, gw, nsl, pname) in enumerate(self._wg_pending):
-            nb = lib.zsg_wgrad_reduce_job(C_.byref(d), ws_own.data_ptr(), gw.data_ptr(), 1, nsl, blk, C_.addressof(host) + i * jb)
-            assert nb > 0, pname
-            blk += nb
-            nbytes += (nsl + 1) * d.N * d.seg[0].ty.n * d.seg[0].tx.n * d.C * 4.0
-            self.grad_ready[pname] = at
-            self.bwd.keep.append(ws_own)
-        jobs_dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.dev)
-        self.bwd.add(lib.zsg_wgrad_reduce_batched, jobs_dev, len(self._wg_pending), blk, nbytes, what=f"wgrad reduce x{len(self._wg_pending)}", lane=1)
-        self._wg_pending, self._wg_pending_bytes = [], 0
+        self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None, completes_bn: bool = False):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
@@ -907,11 +828,8 @@ class _Plan:
         covers_all = not d.zero_fill and mask is None and ((d.tile_hint >> 16) & 0xff) <= 1 and d.tile_hint and dx.ld == n and n % 4 == 0
         dx.last_writer = (len(self.bwd.calls) - 1, d, wargs if d.use_wino else args, "dgrad:" + L.name) if covers_all else None
 
-    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False, defer: bool = False) -> Act:
-        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2).
-        defer: the only forward consumer is the next convolution, which applies this BatchNorm + ReLU in its operand loader
-        (out.pre); the apply launch that materialises `out` and the packed ReLU mask for the BACKWARD is queued and released on the
-        side stream later (_flush_deferred) — it leaves the forward's dependent chain."""
+    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False) -> Act:
+        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2)."""
         net = self.net
         lv = x.levels[0]
         out = self.act(name or L.name, x.B, lv.H, lv.W, L.c)
@@ -930,11 +848,7 @@ class _Plan:
         rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
         lane = 2 if (join and self.training) else self._lane
         inl = getattr(x, "bn_inline", None) if fused else None
-        aff = getattr(x, "bn_affine", None) if (fused and defer and relu and residual is None) else None
-        if aff is not None:
-            self._deferred.append((x.buf, rows, L.c, aff, 1, out.buf, rmask, "apply:" + L.name))
-            out.pre = (x, aff)
-        elif inl is not None:
+        if inl is not None:
             self.fwd.add(lib.zsg_bn_apply_from_partials, x.buf, rows, L.c, inl, x.bn_chunks, gam, bet, residual.buf if residual is not None else None,
                          int(relu), out.buf, rmask, mean, invstd, rm, rv, 0.1, 1e-5, what=L.name, lane=lane)
         else:
@@ -997,9 +911,6 @@ class _Plan:
         self.wg_ws_bytes = 256 << 20     # split-K slabs of the weight-gradient kernel (largest: 64 splits x 1.2 M weights)
         self.wg_ws = self._buf(self.wg_ws_bytes // 4)
         self.tune_dw = self._buf(max(e.size for e in net.store.entries.values()) + 64)
-        self._deferred = []              # BatchNorm applies whose forward consumer reads the BatchNorm's input (see bn(defer=True))
-        import ctypes as C_
-        self._wg_pending, self._wg_pending_bytes, self._nslab_sink = [], 0, C_.c_int32(0)      # batched slab reduction (wgrad())
 
         # ---- static inputs ------------------------------------------------------------------------------------------
         self.in_qvec = self._buf(B * T * net.emb_dim)
@@ -1066,7 +977,6 @@ class _Plan:
         self.num_f_out_t = torch.tensor([len(feats)], dtype=torch.long, device=self.dev)
         self.tape.extend(lstm_tape)
         self._lower_head(feats, we)
-        self._flush_deferred()
         # image-independent head launches (language / grid maps of conv0) go to the side stream BEHIND the query encoder: a
         # side-stream launch waits for the main-stream work enqueued before it, so its place in the program decides what
         # it can overlap — here the whole image encoder
@@ -1104,15 +1014,7 @@ class _Plan:
         if self.training:
             for emit in reversed(self.tape):
                 emit()
-            self._wg_flush()
         self.tape = []
-
-    def _flush_deferred(self):
-        """Release the queued BatchNorm applies (activations + ReLU masks only the backward reads) as consecutive side-stream
-        launches: ONE event edge from the main stream for all of them; the forward's closing join waits for them."""
-        for (*args, what) in self._deferred:
-            self.fwd.add(lib.zsg_bn_apply_affine, *args, what=what, lane=1 if self.training else 0)
-        self._deferred = []
 
     def _lower_stem_fused(self, L: ConvL, Lb: BnL, x0: Act, H1: int, W1: int, H2: int, W2: int) -> Act:
         """conv1 -> bn1 -> relu -> maxpool (mdl.py:149-152) in training: the BatchNorm + ReLU + max-pool are ONE pass over the stem
@@ -1254,13 +1156,13 @@ class _Plan:
                 rd = self.conv_bn(C[q + "downsample.0"], BN[q + "downsample.1"], x, False, name=q + "rd", yname=q + "yd")
         join = blk["ds"]
         if net.block_kind == "bottleneck":
-            a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1", defer=True)
-            a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2", defer=True)
+            a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
+            a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2")
             if self.training:
                 y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
                 return self.bn(BN[q + "bn3"], y3, True, residual=rd, name=q + "out", join=join)
             return self.conv_bn(C[q + "conv3"], BN[q + "bn3"], a2, True, residual=rd, name=q + "out", yname=q + "y3")
-        a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1", defer=True)
+        a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
         if self.training:
             y2 = self.conv(C[q + "conv2"], a1, name=q + "y2", bn_fuse=BN[q + "bn2"])
             return self.bn(BN[q + "bn2"], y2, True, residual=rd, name=q + "out", join=join)
@@ -1545,7 +1447,6 @@ class _Plan:
             self.fwd.add(lib.zsg_bn_apply, lmap.buf, h1.rows(), 256, zero, one, one, self.P(L0.name + ".bias"), None, 1, h1.buf, None,
                          what=L0.name)
         h1.needs_mask = True
-        self._flush_deferred()       # (behind the head's first convolution: the applies run under the head's remaining five)
 
         def head0_back():
             dy = h1.grad
@@ -1737,11 +1638,17 @@ class _Plan:
         if g5.data_ptr() != self.g5_in.data_ptr():        # (the loss wrote it in place: see ZSGNet.forward)
             self.g5_in.view_as(g5).copy_(g5)
         ddp = getattr(net, "_ddp", None)
-        if self._prep_fwd == self.fwd_id:
+        if self._prep_fwd == self.fwd_id and self._bwd_fwd != self.fwd_id:
             torch.cuda.current_stream().wait_event(self._prep_ev)
             self._prep_pending = False
         else:
+            # no side-stream preparation for this forward, or a SECOND backward of it (retain_graph): the split-K / strided
+            # data-gradient targets the first one accumulated into must be zeroed again — the preparation is idempotent
+            if self._prep_fwd == self.fwd_id and self._prep_pending:
+                torch.cuda.current_stream().wait_event(self._prep_ev)
+                self._prep_pending = False
             self.prep.run(st)
+        self._bwd_fwd = self.fwd_id
         if ddp is not None and ddp.active:
             # The reducer SUM-all-reduces the whole (accumulating) gradient buffer: a second backward before zero_grad would
             # reduce the first one's gradients again.  FusedAdam.zero_grad / dropping the p.grad clears the flag.

@@ -219,7 +219,7 @@ SIDE_BATCH = int(os.environ.get("ZSG_SIDE_BATCH", "0"))
 COMPLETION_EVENTS = os.environ.get("ZSG_COMPLETION_EVENTS", "1") != "0"
 
 
-_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb, lib.zsg_conv_igemm_pre, lib.zsg_conv_wino_pre)
+_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb)
 
 
 _SIDE = {}
@@ -536,25 +536,107 @@ if os.environ.get("ZSG_TUNE_CACHE"):
     atexit.register(lambda: save_tune_cache(os.environ.get("ZSG_TUNE_CACHE", "")))
 
 
+# ---- the shipped tuning table ------------------------------------------------------------------------------------------------
+# Tile choices for the BASELINE.json shapes, made once on an MI355X by tools/make_tuning_table.py (median-of-5 interleaved tuner) and
+# committed as zsgnet-pytorch_amd/tuning/gfx950.json together with the sha256 stamp of the kernel sources they were timed on.  A
+# process preloads them when the stamp matches the sources it runs (else nothing is loaded and every shape is tuned on first use),
+# so two fresh processes lower the same launch programs: the headline number does not depend on the tuner's luck (round 3: fresh
+# tunings of one build spanned 13.89-14.21 ms).  Shapes that are not in the table are tuned as before.  ZSG_SHIPPED_TUNE=0 disables.
+SHIPPED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gfx950.json")
+TUNE_INFO = {"table": None, "stamp": None, "table_stamp": None, "loaded": 0, "tuned_now": 0}
+
+
+def source_stamp() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp): what a tuning table / a rocprof summary was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_shipped_table(path: str = SHIPPED_TABLE) -> int:
+    import ast
+    import json
+    TUNE_INFO["stamp"] = source_stamp()
+    if os.environ.get("ZSG_SHIPPED_TUNE", "1") == "0" or not os.path.exists(path):
+        return 0
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return 0
+    TUNE_INFO["table"], TUNE_INFO["table_stamp"] = os.path.relpath(path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), tj.get("source_stamp")
+    if tj.get("source_stamp") != TUNE_INFO["stamp"]:
+        return 0
+    n = 0
+    for k, v in tj.get("entries", {}).items():
+        key = ast.literal_eval(k)
+        if key not in _TUNE_CACHE:                 # (an explicit ZSG_TUNE_CACHE wins)
+            _TUNE_CACHE[key] = int(v)
+            n += 1
+    TUNE_INFO["loaded"] = n
+    return n
+
+
+load_shipped_table()
+
+
 def _sig(kind, d: ConvDesc, extra) -> tuple:
     segs = tuple((d.seg[i].rows_y, d.seg[i].rows_x, d.seg[i].src_H, d.seg[i].src_W, d.seg[i].sy, d.seg[i].osy,
                   d.seg[i].ty.n, d.seg[i].tx.n) for i in range(d.nseg))
     return (kind, d.B, d.C, d.N, d.src_ld, d.out_ld, d.wR, d.wC, d.wt_ld, d.relu, d.merge_x, segs, extra)
 
 
-def _time_launch(fn, args, stream, reps=10):
+def _time_launch(fn, args, stream, reps=6):
+    """one timing sample: the mean of `reps` back-to-back launches (inf when the library refuses the configuration)"""
     st = C.c_void_p(stream)
-    for _ in range(2):
-        rc = fn(*args, st)
-        if rc:
-            return float("inf")
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        fn(*args, st)
+        if fn(*args, st):
+            return float("inf")
     b.record()
     b.synchronize()
     return a.elapsed_time(b) / reps
+
+
+TUNE_ROUNDS = int(os.environ.get("ZSG_TUNE_ROUNDS", "5"))
+
+
+def _pick_best(trials, set_hint, stream, penalty):
+    """Median of TUNE_ROUNDS INTERLEAVED samples per candidate (round r times every surviving candidate once before round r + 1
+    starts, so clock / thermal drift and a noisy neighbour hit all candidates alike; one batch of 10 launches per candidate picked
+    tiles that differed from process to process and moved the step by +-1 %).  Candidates more than 25 % behind the leader after
+    the first round are dropped.  trials: [(fn, marshalled args, hint, flag)]; returns hint | flag of the winner."""
+    live, samples = [], []
+    for f, conv, h, flag in trials:
+        set_hint(h)
+        if f(*conv, C.c_void_p(stream)):            # warm-up launch; a refused configuration is not a candidate
+            continue
+        _time_launch(f, conv, stream, reps=1)
+        live.append((f, conv, h, flag))
+        samples.append([])
+    for r in range(TUNE_ROUNDS):
+        for i, (f, conv, h, flag) in enumerate(live):
+            if samples[i] is None:
+                continue
+            set_hint(h)
+            samples[i].append(_time_launch(f, conv, stream) + penalty(h))
+        if r == 0 and live:
+            lead = min(s[0] for s in samples if s)
+            for i, s_ in enumerate(samples):
+                if s_[0] > 1.25 * lead:
+                    samples[i] = None
+    best, best_t = 0, float("inf")
+    for (f, conv, h, flag), s_ in zip(live, samples):
+        if s_:
+            t = sorted(s_)[len(s_) // 2]
+            if t < best_t:
+                best, best_t = h | flag, t
+    return best
 
 
 WINO_FLAG = 1 << 30          # tuner result: the Winograd kernel won (its own tile hint in the low bits)
@@ -566,17 +648,7 @@ def wino_mode() -> str:
     return os.environ.get("ZSG_WINO", "1")
 
 
-BX_FLAG = 1 << 26            # tile_hint bit: the bf16x6 matrix path of the kernel
 K64_FLAG = 1 << 27           # tile_hint bit (igemm): 64-deep K tiles — half the K steps (barriers) at twice the LDS per block
-PP_FLAG = 1 << 28            # tile_hint bit (igemm, 64x64 8-wave tile): the two K groups run half a K tile out of phase
-R3_FLAG = 1 << 29            # tile_hint bit (igemm, tiles up to 128x64): three LDS tile buffers, fragments read one K step ahead
-
-
-def matrix_mode() -> str:
-    """ZSG_MATRIX: 'fp32' = fp32-input MFMA only (v_mfma_f32_32x32x2_f32); 'bf16x6' = the autotuner may also pick the
-    kernels' bf16x6 variants — every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per product block,
-    fp32 accumulation: fp32-grade results (tests/test_gpu_bx.py) at 0.375 of the matrix-pipe time."""
-    return os.environ.get("ZSG_MATRIX", "fp32")
 
 
 def deterministic() -> bool:
@@ -639,7 +711,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     in its epilogue: a separate statistics pass + finalize launch), added to the measured time of split candidates.
     wino_args: the same launch through zsg_conv_wino (args with the transformed filter image in place of the weight):
     its tile candidates are timed too; the result carries WINO_FLAG and d.use_wino is set when one of them wins.
-    wino_fn: the Winograd entry point that goes with `fn` (zsg_conv_wino_pre for zsg_conv_igemm_pre; default zsg_conv_wino)."""
+    wino_fn: the Winograd entry point that goes with `fn` (default zsg_conv_wino)."""
     d.use_wino = False
     mode = wino_mode() if wino_args is not None else "0"
     if mode == "0":
@@ -652,7 +724,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         return 0
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
-                         mode if wino_args is not None else "", deterministic(), matrix_mode(), fn.__name__,
+                         mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
                          os.environ.get("ZSG_PW", "1") != "0"))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
@@ -669,15 +741,9 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands.append(tile_hint(bm, bn, 1))
             if not d.merge_x and (bm == 128 or bn == 64):
                 cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup (64x64: two K groups)
-        if not d.merge_x and os.environ.get("ZSG_R3", "0") == "1":        # (measured round 3: 2-8 % slower than the two-buffer schedule)
-            cands += [tile_hint(bm, bn, 1, w8) | R3_FLAG for bm, bn in ((64, 64), (128, 64)) for w8 in (0, 1)]
-        if not d.merge_x and os.environ.get("ZSG_PP", "0") == "1":        # (measured round 3: never faster than the lock-step variant)
-            cands.append(tile_hint(64, 64, 1, 1) | PP_FLAG)
         if not d.merge_x and d.C % 64 == 0 and os.environ.get("ZSG_K64", "1") != "0":
             cands += [tile_hint(bm, bn, 1, w8) | K64_FLAG for bm, bn in tiles for w8 in (0, 1) if not (bm == 128 and bn == 128 and not w8)]
-        if matrix_mode() == "bf16x6" and not d.merge_x:
-            cands += [tile_hint(bm, bn, 1, w8) | BX_FLAG for bm, bn in tiles for w8 in (0, 1)]
-        if fn is lib.zsg_conv_igemm and matrix_mode() == "fp32" and os.environ.get("ZSG_PW", "1") != "0":
+        if fn is lib.zsg_conv_igemm and os.environ.get("ZSG_PW", "1") != "0":
             cands += pw_cands(d)
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
@@ -687,8 +753,6 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                     cands.append(tile_hint(64, 64, sp))
                     if d.C % 64 == 0 and 2 * sp <= n_it and os.environ.get("ZSG_K64", "1") != "0":
                         cands.append(tile_hint(64, 64, sp, 1) | K64_FLAG)
-                    if matrix_mode() == "bf16x6":
-                        cands.append(tile_hint(64, 64, sp, 1) | BX_FLAG)
                     if blocks64 * sp < 256:
                         cands.append(tile_hint(128, 64, sp))
     else:
@@ -722,16 +786,13 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             if sp not in seen and sp * d.N * 9 * d.C * 4 <= ws_bytes:
                 seen.add(sp)
                 trials.append((lib.zsg_conv_wgrad_wino, wconv, tile_hint(64, 64, sp), WINO_FLAG))
-    best, best_t = 0, float("inf")
-    for f, conv, h, flag in trials:
+    def set_hint(h):
         d.tile_hint = h
-        t = _time_launch(f, conv, stream)
-        if kind == "igemm" and ((h >> 16) & 0xff) > 1:
-            t += split_penalty_ms
-        if t < best_t:
-            best, best_t = h | flag, t
+
+    best = _pick_best(trials, set_hint, stream, lambda h: split_penalty_ms if (kind == "igemm" and ((h >> 16) & 0xff) > 1) else 0.0)
     d.tile_hint, d.use_wino = best & ~WINO_FLAG, bool(best & WINO_FLAG)
     _TUNE_CACHE[key] = best
     global _TUNE_DIRTY
     _TUNE_DIRTY = True
+    TUNE_INFO["tuned_now"] += 1
     return best

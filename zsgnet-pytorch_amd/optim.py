@@ -15,7 +15,8 @@ class FusedAdam(torch.optim.Optimizer):
         flat = net.store.flat
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
-        self.step_count = torch.zeros(1, dtype=torch.int32, device=flat.device)
+        self._step2 = torch.zeros(2, dtype=torch.int32, device=flat.device)      # [steps taken, the update kernel's completion ticket]
+        self.step_count = self._step2[:1]
         self.grad_scale = grad_scale
         # attached: a backward may leave its last weight gradients (the stem's) running on the side stream; step() updates everything
         # else under them (mdl._Plan.run_backward / ZSGNet.join_grads)
