@@ -64,6 +64,17 @@ def source_stamp() -> str:
     return _o.source_stamp()
 
 
+def tuning_info() -> dict:
+    """which tile choices this run used: the shipped table (when its stamp matches the kernel sources) and / or fresh tunings"""
+    from zsgnet_pytorch_amd import ops as _o
+    t = dict(_o.TUNE_INFO)
+    t["stamp_match"] = bool(t["table"]) and t["table_stamp"] == t["stamp"]
+    t["tune_cache_env"] = os.environ.get("ZSG_TUNE_CACHE") or None
+    t["what"] = ("tile / split-K choices: `loaded` entries from the shipped table (used only when its source stamp matches), `tuned_now` launch "
+                 "shapes autotuned by this process (median of interleaved samples)")
+    return t
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +204,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    red0 = next((p.reducer for p in net._plans.values() if p.reducer is not None), None) if model is not net else None
+    if red0 is not None:
+        red0.time_wait = True             # two event records per step: the exposed all-reduce time (rccl.exposed_allreduce_ms)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     fence()
     t0 = time.perf_counter()
@@ -211,6 +225,17 @@ def main():
                     "the host); how far ahead of the GPU the host was when it had enqueued the last timed step"}
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     median_ms = per_step[len(per_step) // 2]
+    exposed_ms = None
+    if red0 is not None:
+        red0.time_wait = False
+        exposed_ms = red0.exposed_ms()
+    per_rank = None
+    if world > 1:                            # every rank's own clock and exposed wait, for the first scaling curve
+        mine = torch.tensor([1e3 * dt / a.steps, median_ms, exposed_ms if exposed_ms is not None else -1.0], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(t[0]), 3) for t in allr], "median_ms_per_step": [round(float(t[1]), 3) for t in allr],
+                    "exposed_allreduce_ms": [round(float(t[2]), 3) for t in allr]}
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,6 +290,7 @@ def main():
                 rows.append(dict(kernel=e.name.decode(), launches_per_step=e.launches / nprof, ms_per_step=e.ms / nprof,
                                  tflops=(e.flops / (e.ms * 1e9)) if e.ms > 0 and e.flops > 0 else None,
                                  gbps=(e.bytes / (e.ms * 1e6)) if e.ms > 0 and e.bytes > 0 else None,
+                                 alg_bytes_per_launch=(e.bytes / e.launches) if e.launches and e.bytes > 0 else None,
                                  share=e.ms / tot if tot else 0))
             rows.sort(key=lambda x: -x["ms_per_step"])
             return rows, tot / nprof
@@ -300,6 +326,10 @@ def main():
             share_exec = (exe_all / flops_all) if flops_all else 1.0       # FLOP-weighted executed share over all MFMA kernels
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"] * er, 2), "peak": PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(dom["tflops"] * er / PEAK_TF, 4), "traffic": traffic, "traffic_note": tnote,
+                    "algorithmic_bytes_per_launch": round(dom["alg_bytes_per_launch"]) if dom.get("alg_bytes_per_launch") else None,
+                    "traffic_over_algorithmic": round(traffic / dom["alg_bytes_per_launch"], 3) if (traffic and dom.get("alg_bytes_per_launch")) else None,
+                    "traffic_note2": "algorithmic bytes = every operand and output element once, from the launch descriptors (zsg_conv_alg_bytes); "
+                                     "traffic / algorithmic > 1 = re-reads that reached the memory side of L2",
                     "flops": "EXECUTED MFMA FLOPs: algorithmic 2*MAC of the direct convolution" + (" x 4/9 (Winograd: 16 of 36 multiplies per 2x2 tile)" if er < 1 else ""),
                     "executed_over_algorithmic": round(er, 4),
                     "algorithmic_achieved": round(dom["tflops"], 2), "algorithmic_frac": round(dom["tflops"] / PEAK_TF, 4),
@@ -321,7 +351,8 @@ def main():
                                      "tflops_executed": round(r["tflops"] * exec_ratio(r["kernel"]), 1) if r["tflops"] else None,
                                      "tflops_algorithmic": round(r["tflops"], 1) if r["tflops"] else None,
                                      "frac": round(r["tflops"] * exec_ratio(r["kernel"]) / PEAK_TF, 3) if r["tflops"] else None,
-                                     "gbps": round(r["gbps"], 0) if r["gbps"] else None}
+                                     "gbps": round(r["gbps"], 0) if r["gbps"] else None,
+                                     "alg_mb_per_launch": round(r["alg_bytes_per_launch"] / 1e6, 2) if r.get("alg_bytes_per_launch") else None}
                                     for r in iso_rows[:10]]}
         else:
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["gbps"] or 0, 1), "peak": 8000.0, "unit": "GB/s",
@@ -340,7 +371,11 @@ def main():
                 "transport": "zsg_comm_* (RCCL inside libzsg.so)" if model.comm is not None else "torch.distributed all_reduce (ProcessGroupNCCL = RCCL)",
                 "buckets_per_step": len(red.buckets) if red else None,
                 "allreduce_bytes_per_step": int(sum(b.end - b.start for b in red.buckets) * 4) if red else None,
-                "bn_buffer_broadcast_bytes_per_step": int(net._rmv.numel() * 4)}
+                "bn_buffer_broadcast_bytes_per_step": int(net._rmv.numel() * 4),
+                "exposed_allreduce_ms": round(exposed_ms, 3) if exposed_ms is not None else None,
+                "exposed_note": "time the compute stream stands behind the last bucket's collective after the backward's last launch (rank 0; mean per step)",
+                "per_rank": per_rank,
+                "per_rank_min_max_ms_per_step": [min(per_rank["ms_per_step"]), max(per_rank["ms_per_step"])] if per_rank else None}
     if rank == 0:
         fwd_gf = FWD_GF.get((a.arch, a.img))
         step_frac = (ips / world) * (3 * fwd_gf) * 1e9 / (PEAK_TF * 1e12) if fwd_gf else None
@@ -355,7 +390,7 @@ def main():
             "step_mfma_frac_note": "whole step: ALGORITHMIC conv FLOPs (3 x forward 2*MAC) / time / fp32-MFMA peak; compare with roofline.ceiling_algorithmic, not with 1",
             "rccl": rccl,
             "final_loss": round(loss_val, 4), "final_acc": acc,
-            "forward": fwd, "source_stamp": source_stamp(),
+            "forward": fwd, "source_stamp": source_stamp(), "tuning": tuning_info(),
             "roofline": roof, "cpu_baseline": cpu,
         }
     if world > 1:

@@ -255,6 +255,13 @@ int zsg_nchw_to_nhwc4(const float* img, int32_t B, int32_t C, int32_t H, int32_t
 /* uint8 [pixels][3] (HWC, as PIL decodes) -> float [pixels][4] = (r,g,b)/255, 0 — `pil2tensor(img).float().div_(255)`
  * (dat_loader.py:26-33, 134) fused with the stem layout; IEEE division: equal to the host conversion bit for bit. */
 int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out, void* stream);
+/* `img.resize((Wo, Ho))` of the reference loader (dat_loader.py:121: PIL.Image.resize, default filter = bicubic) for one uint8
+ * [H][W][C] image, byte-identical to Pillow: its two fixed-point passes (horizontal into tmp [H][Wo][C], then vertical) with the
+ * per-axis tap tables the HOST computes from the two axis lengths (bounds[o] = {first tap, tap count}, coef[o][ksize] 22-bit
+ * fixed-point weights; zsgnet_pytorch_amd.dat_loader.resize_tables).  A NULL table pair = that axis keeps its length. */
+int zsg_resize_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, const int32_t* x_bounds, const int32_t* x_coef, int32_t x_ksize,
+                  const int32_t* y_bounds, const int32_t* y_coef, int32_t y_ksize, int32_t Ho, int32_t Wo, uint8_t* tmp, uint8_t* out,
+                  void* stream);
 /* Head input BackBone.concat_we (mdl.py:69-104) + head conv0 (mdl.py:216, 514 -> 256, 3x3 pad 1) without ever materialising
  * the concatenated tensor, and without its spatially-constant input channels: the language vector
  * is constant over the image and the grid channels do not depend on the batch index, so only the 256 feature channels

@@ -683,3 +683,51 @@ def cpu_train_step(sd_params: Dict[str, torch.Tensor], sd_buffers: Dict[str, tor
     ev = zsg_eval(out["att_out"].detach().squeeze(-1).numpy(), out["bbx_out"].detach().numpy(),
                   batch["annot"].numpy(), batch["img_size"].numpy(), anchors_f32.numpy())
     return ls, ev
+
+
+# ----------------------------------------------------------------------------------------------
+# PIL.Image.resize restatement (the reference's only resampling call, dat_loader.py:121: default filter = bicubic for RGB)
+# ----------------------------------------------------------------------------------------------
+def _pil_bicubic(x):
+    """Pillow Resample.c bicubic_filter (a = -0.5), vectorised in float64 with Pillow's operation order"""
+    a = -0.5
+    x = np.abs(np.asarray(x, np.float64))
+    near = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    far = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, near, np.where(x < 2.0, far, 0.0))
+
+
+def _pil_axis_pass(src: np.ndarray, out_size: int) -> np.ndarray:
+    """One pass of Pillow's ImagingResample over axis 0 of a uint8 array [n_in, ...]: per output index the window
+    [xmin, xmin + count), float64 weights normalised to 1, rounded to 22-bit fixed point (normalize_coeffs_8bpc), accumulated in
+    int32 from 1 << 21 and shifted / clipped to uint8 (clip8)."""
+    n_in = src.shape[0]
+    if n_in == out_size:                       # (ImagingResample skips a pass that does not change the size)
+        return src
+    scale = float(np.float32(n_in)) / out_size
+    fscale = max(scale, 1.0)
+    support = 2.0 * fscale
+    out = np.empty((out_size,) + src.shape[1:], np.uint8)
+    s32 = src.astype(np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), n_in) - xmin
+        w = _pil_bicubic((np.arange(xmax) + xmin - center + 0.5) * (1.0 / fscale))
+        ww = 0.0
+        for v in w:                            # (sequential sum, as the C loop)
+            ww += float(v)
+        if ww != 0.0:
+            w = w / ww
+        k = np.where(w < 0, (-0.5 + w * (1 << 22)).astype(np.int64), (0.5 + w * (1 << 22)).astype(np.int64))      # C cast: toward zero
+        acc = (1 << 21) + np.tensordot(k, s32[xmin:xmin + xmax], axes=(0, 0))
+        out[xx] = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_resize_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """PIL.Image.fromarray(img).resize((out_w, out_h)) for a uint8 [H, W, 3] image: horizontal pass, then vertical pass
+    (ImagingResample, Resample.c), each rounding to uint8."""
+    img = np.ascontiguousarray(img, np.uint8)
+    tmp = _pil_axis_pass(img.transpose(1, 0, 2), out_w).transpose(1, 0, 2)       # over x
+    return np.ascontiguousarray(_pil_axis_pass(tmp, out_h))                        # over y

@@ -103,9 +103,64 @@ def adversarial_boxes(rng, n, anchors32):
     return np.concatenate([b, np.array(extra, dtype=np.float32)], 0)
 
 
+def gen_resize(cfg):
+    """G14: the reference loader's image path at photo-like down-scaling ratios (dat_loader.py:98-146: PIL.Image.open -> convert("RGB")
+    -> resize(resize_img), PIL's default filter -> pil2tensor / 255): raw uint8 images of several sizes and what ImgQuDataset makes
+    of them, as uint8 (the float image x 255 is integral).  Pins oracle.pil_resize_u8 and the HIP kernel zsg_resize_u8."""
+    import re
+    import tempfile
+    import PIL.Image
+    rng = np.random.default_rng(14)
+    sizes = {"p.png": (125, 167), "q.png": (111, 160), "r.png": (160, 213), "s.png": (67, 50), "t.png": (100, 100), "u.png": (100, 151), "v.png": (240, 90)}
+    imgs = {}
+    for k, (h, w) in sizes.items():
+        # smooth structure + noise + saturated patches: exercises the negative bicubic lobes and the clipping at 0 / 255
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 127 + 100 * np.sin(yy / 7.0)[..., None] * np.cos(xx / 5.0)[..., None] * np.array([1.0, 0.7, -0.8])
+        a = np.clip(base + rng.normal(0, 30, (h, w, 3)), 0, 255)
+        a[h // 4:h // 2, w // 3:w // 2] = 255
+        a[h // 2:h // 2 + 9, : w // 4] = 0
+        imgs[k] = a.astype(np.uint8)
+
+    def fake_nlp(text):
+        class Tok:
+            def __init__(self, t):
+                self.text, self.vector = t, np.zeros(300, np.float32)
+        return [Tok(t) for t in re.findall(r"\w+|[^\w\s]", str(text))]
+    with tempfile.TemporaryDirectory() as td:
+        for k, v in imgs.items():
+            PIL.Image.fromarray(v).save(os.path.join(td, k))
+        with open(os.path.join(td, "d.csv"), "w") as f:
+            f.write("img_id,bbox,query\n")
+            for k in imgs:
+                f.write(f'{k},"[1, 2, 30, 40]","a thing"\n')
+        os.chdir(REF)
+        import dat_loader as DL
+        os.chdir(REPO)
+        DL.nlp = fake_nlp
+        if not hasattr(np, "float_"):
+            np.float_ = np.float64
+        c3 = cfg.__class__(dict(cfg))
+        c3.resize_img = [100, 100]
+        c3.ds_info = cfg.__class__({"refclef": cfg.__class__({"img_dir": td})})
+        ds = DL.ImgQuDataset(c3, os.path.join(td, "d.csv"), "refclef")
+        items = [ds[i] for i in range(len(ds))]
+    d = dict(resize_img=np.array([100, 100]), names=np.array(list(imgs)))
+    for i, (k, v) in enumerate(imgs.items()):
+        f = items[i]["img"].numpy().astype(np.float64) * 255.0              # [3, H, W] in [0, 1]
+        u8 = np.rint(f)
+        assert np.abs(f - u8).max() < 1e-3
+        d["raw_" + k[0]] = v
+        d["out_" + k[0]] = u8.astype(np.uint8).transpose(1, 2, 0)
+    save("g14_resize", **d)
+
+
 def main():
     R = import_reference()
     A, L, E, M, cfg = R["anchors"], R["loss"], R["evaluator"], R["mdl"], R["cfg"]
+    if ONLY and all(o.startswith("g14") for o in ONLY):
+        gen_resize(cfg)
+        return
     ratios = eval(cfg["ratios"], {})
     scales = cfg["scale_factor"] * np.array(eval(cfg["scales"], {}))
     cpu = torch.device("cpu")
@@ -558,6 +613,7 @@ def main():
         d["batch_" + k] = v.numpy()
         d["batchdtype_" + k] = np.array(str(v.dtype))
     save("g13_dataset", **d)
+    gen_resize(cfg)
     print("done")
 
 

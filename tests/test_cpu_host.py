@@ -184,6 +184,36 @@ def _reducer_worker(rank, world, port, ret):
     m.train()
     ddp(torch.zeros(1))
     ok = ok and float(m._rm[0]) == 5.0                                                                   # C2: buffers re-broadcast per forward
+    # the `comm="native"` control flow of the wrapper and the reducer (zsg_comm_* needs RCCL and a GPU per rank): a communicator
+    # object with NativeComm's interface, carried by gloo — parameter / buffer broadcasts and the bucket loop go through comm.*
+    class GlooComm:
+        def __init__(self):
+            self.calls = []
+
+        def all_reduce(self, t):
+            self.calls.append("ar")
+            dist.all_reduce(t)
+
+        def broadcast(self, t, src=0):
+            self.calls.append("bc")
+            dist.broadcast(t, src=src)
+
+        def wait(self):
+            self.calls.append("wait")
+
+        def close(self):
+            self.calls.append("close")
+    gc = GlooComm()
+    m2 = Fake()
+    ddp2 = DistributedDataParallel(m2, comm=gc)
+    ok = ok and float(m2.store.flat.sum()) == 0.0 and gc.calls[:2] == ["bc", "bc"]                     # flat weights, BatchNorm buffers
+    flat2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red2 = BucketReducer(flat2, plan_buckets(spans, 100), comm=gc)
+    red2.run(10, lambda i, j: None)
+    red2.wait()
+    ok = ok and torch.equal(flat2, expect) and gc.calls.count("ar") == len(red2.buckets) and gc.calls[-1] == "wait"
+    ddp2.close()
+    ok = ok and gc.calls[-1] == "close"
     rd = reduce_dict({"a": torch.tensor(float(rank + 1)), "b": torch.tensor(2.0)}, average=True)
     if rank == 0:
         ok = ok and abs(float(rd["a"]) - 1.5) < 1e-6 and abs(float(rd["b"]) - 2.0) < 1e-6

@@ -82,3 +82,54 @@ def test_distributed_sampler_rule():
     assert [i for p in parts for i in p] == perm and all(len(p) == 3 for p in parts)
     s = NewDistributedSampler(ds, num_replicas=4, rank=3, shuffle=False)
     assert list(s) == [9, 0, 1]
+
+
+def _two_pass(D, img, out_w, out_h):
+    """the product's tap tables (dat_loader.resize_tables) applied with plain integer arithmetic — what zsg_resize_u8 computes"""
+    def one(src, n_out):
+        n_in = src.shape[0]
+        if n_in == n_out:
+            return src
+        b, c, ks = D.resize_tables(n_in, n_out)
+        out = np.empty((n_out,) + src.shape[1:], np.uint8)
+        s = src.astype(np.int64)
+        for i in range(n_out):
+            x0, n = int(b[i, 0]), int(b[i, 1])
+            acc = (1 << 21) + np.tensordot(c[i, :n].astype(np.int64), s[x0:x0 + n], axes=(0, 0))
+            out[i] = np.clip(acc >> 22, 0, 255)
+        return out
+    return one(one(img.transpose(1, 0, 2), out_w).transpose(1, 0, 2), out_h)
+
+
+def test_pil_resize_restatement_and_tap_tables_vs_reference_loader(gold):
+    """N2 (GPU-side resize): the reference loader's `img.resize(...)` (dat_loader.py:121, PIL's default filter) — golden g14 holds raw
+    images of seven sizes and what the reference's ImgQuDataset made of them; g13 adds three up-scaling cases.  Both the oracle's
+    restatement of Pillow's resampler and the product's tap tables must reproduce them byte for byte."""
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import dat_loader as D
+    g = gold("g14_resize")
+    ow, oh = (int(v) for v in g["resize_img"])
+    for nm in g["names"]:
+        raw, ref = g["raw_" + str(nm)[0]], g["out_" + str(nm)[0]]
+        assert np.array_equal(O.pil_resize_u8(raw, ow, oh), ref), f"oracle restatement differs from the reference loader on {nm} {raw.shape}"
+        assert np.array_equal(_two_pass(D, raw, ow, oh), ref), f"tap tables differ from the reference loader on {nm} {raw.shape}"
+    g3 = gold("g13_dataset")
+    ow, oh = (int(v) for v in g3["resize_img"])
+    for i, nm in enumerate(g3["csv_img"]):
+        raw = g3["png_" + str(nm)[0]]
+        ref = np.rint(g3[f"item{i}_img"].astype(np.float64) * 255).astype(np.uint8).transpose(1, 2, 0)
+        assert np.array_equal(O.pil_resize_u8(raw, ow, oh), ref) and np.array_equal(_two_pass(D, raw, ow, oh), ref), (nm, raw.shape)
+
+
+def test_pil_resize_restatement_vs_installed_pillow():
+    """the same two implementations against the Pillow that is installed, on photo-sized geometries (500x375 -> 300x300 ...)"""
+    PIL = pytest.importorskip("PIL.Image")
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import dat_loader as D
+    rng = np.random.default_rng(5)
+    for (h, w, oh, ow) in [(375, 500, 300, 300), (480, 640, 300, 300), (200, 150, 300, 300), (300, 300, 300, 300), (301, 299, 300, 300),
+                           (683, 1024, 600, 600), (2, 3, 300, 300)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(PIL.fromarray(a).resize((ow, oh)))
+        assert np.array_equal(O.pil_resize_u8(a, ow, oh), ref), (h, w)
+        assert np.array_equal(_two_pass(D, a, ow, oh), ref), (h, w)

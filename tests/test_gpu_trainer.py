@@ -93,3 +93,39 @@ def test_real_data_loader_uint8_ingest_and_training(tmp_path, gold):
     res = learn.testing(learn.data.test_dl)
     preds = pickle.load(open(learn.predictions_dir / "test0_preds.pkl", "rb"))
     assert sorted(int(p["id"]) for p in preds) == [0, 1, 2, 3, 4] and 0.0 <= res["test0"]["Acc"] <= 1.0
+
+
+def test_gpu_resize_bit_identical_to_the_reference_loader(gold):
+    """N2: zsg_resize_u8 (through GpuResizer and through the raw C ABI) against what the reference's ImgQuDataset produced (golden
+    g14: seven image sizes -> 100x100; g13: three up-scaling cases -> 48x40) — byte for byte, then the fused /255 + NHWC4 step."""
+    import ctypes as C
+    from zsgnet_pytorch_amd import dat_loader as D
+    from zsgnet_pytorch_amd._lib import lib, stream_ptr
+    g = gold("g14_resize")
+    ow, oh = (int(v) for v in g["resize_img"])
+    rz = D.GpuResizer((oh, ow))
+    raws = [torch.from_numpy(np.ascontiguousarray(g["raw_" + str(nm)[0]])).cuda() for nm in g["names"]]
+    out = rz(raws)
+    torch.cuda.synchronize()
+    for i, nm in enumerate(g["names"]):
+        assert np.array_equal(out[i].cpu().numpy(), g["out_" + str(nm)[0]]), f"{nm} {tuple(raws[i].shape)}: the GPU resize differs from the reference loader"
+    g3 = gold("g13_dataset")
+    ow3, oh3 = (int(v) for v in g3["resize_img"])
+    rz3 = D.GpuResizer((oh3, ow3))
+    names = [str(n) for n in g3["csv_img"]]
+    out3 = rz3([torch.from_numpy(np.ascontiguousarray(g3["png_" + n[0]])).cuda() for n in names])
+    nhwc4 = torch.empty(len(names), oh3, ow3, 4, device="cuda")
+    assert lib.zsg_u8hwc_to_nhwc4(out3.data_ptr(), len(names) * oh3 * ow3, nhwc4.data_ptr(), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    for i in range(len(names)):
+        ref = torch.from_numpy(g3[f"item{i}_img"])                                   # [3, H, W] float, the reference's item
+        assert torch.equal(nhwc4[i, :, :, :3].permute(2, 0, 1).cpu(), ref), f"{names[i]}: resize + /255 differs from the reference item"
+    # raw C ABI: a size change without its tap table is an argument error (no silent copy), a same-size "resize" is a copy
+    x = raws[0]
+    o = torch.empty(oh, ow, 3, dtype=torch.uint8, device="cuda")
+    assert lib.zsg_resize_u8(x.data_ptr(), x.shape[0], x.shape[1], 3, None, None, 0, None, None, 0, oh, ow, None, o.data_ptr(), stream_ptr()) == -1
+    assert b"tap table" in lib.zsg_last_error()
+    same = torch.empty_like(x)
+    assert lib.zsg_resize_u8(x.data_ptr(), x.shape[0], x.shape[1], 3, None, None, 0, None, None, 0, x.shape[0], x.shape[1], None, same.data_ptr(), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(same, x)

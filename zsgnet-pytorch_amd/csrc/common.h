@@ -76,6 +76,18 @@ extern int g_zsg_prof_on;
 extern int g_zsg_deterministic;     // zsg_set_deterministic: reductions never combine partial sums with fp32 atomics
 #define ZSG_PROF(name, stream, flops, bytes) ZsgProfScope prof__(name, (hipStream_t)(stream), (flops), (bytes))
 
+// ALGORITHMIC HBM bytes of one convolution launch: every operand element and every output element once (input pixels x channels,
+// the filter, the output; + the output again when an add_src / accumulate operand is read).  What bench.py divides the measured
+// FETCH / WRITE traffic of a launch by (roofline.traffic_over_algorithmic).
+static inline double zsg_conv_alg_bytes(const zsg_conv_desc* d, bool reads_out) {
+    double e = (double)d->N * d->seg[0].ty.n * d->seg[0].tx.n * d->C;
+    for (int s = 0; s < d->nseg; ++s) {
+        const zsg_seg& a = d->seg[s];
+        e += (double)d->B * a.src_H * a.src_W * d->C + (double)d->B * a.rows_y * a.rows_x * d->N * (reads_out ? 2.0 : 1.0);
+    }
+    return 4.0 * e;
+}
+
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -46,6 +46,7 @@ struct IgParams {
     int remap;        // XCD-aware tile order (only when every segment carries the same amount of K work)
     int vec;          // 16-byte epilogue allowed (alignment of every operand checked on the host)
     int bk64;         // tile_hint bit 27: 64-deep K tiles
+    double alg_bytes; // host only: algorithmic HBM bytes of the launch (profile)
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     IgSegDev seg[ZSG_MAX_SEG];
@@ -570,7 +571,7 @@ static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const ch
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
-    ZSG_PROF(kname, st, flops, 0);
+    ZSG_PROF(kname, st, flops, p.alg_bytes);
     ZSG_LAUNCH((igemm_kernel<BM, BN, WM, WN, MX, KS, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
@@ -640,6 +641,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
     p.stats = bn_partials;
+    p.alg_bytes = zsg_conv_alg_bytes(d, add_src != nullptr);
     p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x;
 
     {

@@ -312,6 +312,68 @@ extern "C" int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out
     return 0;
 }
 
+// ---- PIL.Image.resize on the GPU (uint8, bit-identical) ------------------------------------------------------------------
+// `img.resize((W, H))` of the reference loader (dat_loader.py:121; Pillow's default filter: bicubic) as Pillow's ImagingResample runs
+// it for 8-bit channels: a horizontal pass, then a vertical pass, each a windowed sum of uint8 samples with 22-bit fixed-point
+// weights, started at 1 << 21, shifted right by 22 and clipped to [0, 255].  The weights (bounds[o] = first tap | tap count,
+// coef[o][0..ksize)) are Pillow's double-precision weights rounded on the HOST (dat_loader.resize_tables: they depend only on the two
+// axis lengths); the integer arithmetic here is exact, so the output equals Pillow's byte for byte.  One thread per output
+// (pixel, channel); byte work bound by launch latency, not by bandwidth (a 500 x 375 -> 300 x 300 image is 0.7 MB of traffic).
+// axis 0: out[y][o][c] = f(in[y][x0 + t][c]);  axis 1: out[o][x][c] = f(in[y0 + t][x][c]).
+template <int AXIS>
+__global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restrict__ in, int in_h, int in_w, int C, const int32_t* __restrict__ bounds,
+                                                          const int32_t* __restrict__ coef, int ksize, int out_h, int out_w, uint8_t* __restrict__ out) {
+    const int64_t total = (int64_t)out_h * out_w * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % out_w);
+        const int y = (int)(i / ((int64_t)C * out_w));
+        const int o = AXIS == 0 ? x : y;
+        const int first = bounds[2 * o], n = bounds[2 * o + 1];
+        const int32_t* k = coef + (int64_t)o * ksize;
+        int acc = 1 << 21;
+        if (AXIS == 0) {
+            const uint8_t* p = in + ((int64_t)y * in_w + first) * C + c;
+            for (int t = 0; t < n; ++t) acc += (int)p[(int64_t)t * C] * k[t];
+        } else {
+            const uint8_t* p = in + ((int64_t)first * in_w + x) * C + c;
+            for (int t = 0; t < n; ++t) acc += (int)p[(int64_t)t * in_w * C] * k[t];
+        }
+        acc >>= 22;                                  // (arithmetic shift, as Pillow's clip8 lookup index)
+        out[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+}
+
+// x_* / y_* = the tap tables of the horizontal / vertical pass (device memory), NULL when that axis keeps its length (Pillow skips
+// the pass); tmp: in_h x out_w x C bytes of scratch for the intermediate image.
+extern "C" int zsg_resize_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, const int32_t* x_bounds, const int32_t* x_coef, int32_t x_ksize,
+                             const int32_t* y_bounds, const int32_t* y_coef, int32_t y_ksize, int32_t Ho, int32_t Wo, uint8_t* tmp, uint8_t* out,
+                             void* stream) {
+    ZSG_REQUIRE(src && out && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "resize_u8: bad argument");
+    ZSG_REQUIRE((x_bounds != nullptr) == (x_coef != nullptr) && (y_bounds != nullptr) == (y_coef != nullptr), "resize_u8: a pass needs bounds AND coefficients");
+    ZSG_REQUIRE(x_bounds || W == Wo, "resize_u8: the width changes (%d -> %d) but no horizontal tap table was given", W, Wo);
+    ZSG_REQUIRE(y_bounds || H == Ho, "resize_u8: the height changes (%d -> %d) but no vertical tap table was given", H, Ho);
+    ZSG_REQUIRE(!(x_bounds && y_bounds) || tmp, "resize_u8: two passes need the scratch image");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("resize_u8", st, 0, (double)H * W * C + 2.0 * H * Wo * C + (double)Ho * Wo * C);
+    const uint8_t* cur = src;
+    int cur_w = W;
+    if (x_bounds) {
+        uint8_t* dst = y_bounds ? tmp : out;
+        ZSG_LAUNCH(resize_pass_kernel<0>, dim3(grid_for((int64_t)H * Wo * C)), dim3(256), 0, st, cur, H, W, C, x_bounds, x_coef, x_ksize, H, Wo, dst);
+        cur = dst;
+        cur_w = Wo;
+    }
+    if (y_bounds) {
+        ZSG_LAUNCH(resize_pass_kernel<1>, dim3(grid_for((int64_t)Ho * Wo * C)), dim3(256), 0, st, cur, H, cur_w, C, y_bounds, y_coef, y_ksize, Ho, Wo, out);
+    } else if (!x_bounds) {
+        hipError_t e = hipMemcpyAsync(out, src, (size_t)H * W * C, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) ZSG_FAIL(-3, "resize_u8: copy: %s", hipGetErrorString(e));
+    }
+    ZSG_CHECK_LAUNCH("resize_u8");
+    return 0;
+}
+
 // ---- weight transpose [N][T][C] -> [C][T][dst_ld >= N] (pad columns zeroed) ------------------------------------------
 __global__ void transpose_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int T, int C, int dst_ld) {
     __shared__ float tile[32][33];

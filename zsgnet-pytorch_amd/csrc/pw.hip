@@ -483,7 +483,7 @@ static int pw_launch2(const PwParams& p, int grid, size_t lds, hipStream_t st, d
         if (e != hipSuccess) ZSG_FAIL(-3, "conv_pw: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
-    ZSG_PROF(kname, st, flops, 0);
+    ZSG_PROF(kname, st, flops, 4.0 * ((double)p.M * (p.K + p.N * (p.add_src ? 2.0 : 1.0)) + (double)p.N * p.K));
     ZSG_LAUNCH((pw_kernel<NJ, MODE>), dim3(grid), dim3(64 * PW_WAVES), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_pw");
     return 0;

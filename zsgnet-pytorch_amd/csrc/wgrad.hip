@@ -355,6 +355,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     (void)hipGetDevice(&dev);
     ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_wgrad: device %d", dev);
     const double wg_flops = 2.0 * rows_all * d->N * p.ncols;
+    const double wg_bytes = zsg_conv_alg_bytes(d, accumulate != 0);      // (dw takes the filter's place, dy the output's: same count)
     dim3 grid(nmn * p.splits);
 #define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_) WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, true)
 #define WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, AV_)                                                                          \
@@ -367,7 +368,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
             attr_done[dev] = true;                                                                                         \
         }                                                                                                                  \
-        ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, 0);                        \
+        ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, wg_bytes);                     \
         ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>), grid, dim3(64 * WM_ * WN_), lds, st, p);           \
     } while (0)
     if (!avec) {                                      // dY rows not 16-byte addressable: the one scalar-load variant

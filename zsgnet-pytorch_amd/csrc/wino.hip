@@ -49,6 +49,7 @@ struct WnParams {
     BnbDev bnb;          // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (common.h)
     int C, N, Npad, src_ld, out_ld, relu, nseg;
     int m_blocks, n_blocks, splits, chunks, vec, add_is_out;
+    double alg_bytes;    // host only: algorithmic HBM bytes of the launch (profile)
     WnSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -550,7 +551,7 @@ static int wino_launch(const WnParams& p, hipStream_t st, double flops, const ch
         if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
-    ZSG_PROF(kname, st, flops, 0);
+    ZSG_PROF(kname, st, flops, p.alg_bytes);
     ZSG_LAUNCH((wino_kernel<TM, TN, PS>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_wino");
     return 0;
@@ -573,6 +574,7 @@ static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float*
     p.C = d->C; p.N = d->N; p.Npad = (d->N + 63) / 64 * 64; p.src_ld = d->src_ld; p.out_ld = d->out_ld; p.relu = d->relu;
     p.nseg = d->nseg; p.chunks = (d->C + WN_CK - 1) / WN_CK; p.splits = splits;
     p.add_is_out = (add_src == out) ? 1 : 0;
+    p.alg_bytes = zsg_conv_alg_bytes(d, add_src != nullptr);
     int blocks = 0;
     double fl = 0;
     bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;

@@ -350,7 +350,7 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
         attr_done[dev] = true;
     }
     {
-        ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, 0);
+        ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, zsg_conv_alg_bytes(d, accumulate != 0));
         ZSG_LAUNCH(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
     }
     if (p.splits > 1) {     // fixed-order slab sum -> dw (shared with the direct kernel)

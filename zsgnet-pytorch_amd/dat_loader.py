@@ -17,6 +17,8 @@ What is different, and why:
     undefined for flickr30k_c0/c1, vg_split_*) work: flickr30k* ids get the '.jpg' suffix, everything else is a path.
 """
 import ast
+import functools
+import math
 import re
 from pathlib import Path
 from typing import Dict, Iterator, List, Optional, Tuple
@@ -91,6 +93,100 @@ def embed_query(embedder, query: str, phrase_len: int = PHRASE_LEN) -> Tuple[np.
     vecs = embedder.vectors(query + (" " + PAD_TOKEN) * (phrase_len - qlen))[:phrase_len]
     assert vecs.shape[0] == phrase_len, "tokenisation of the padded query is not stable"
     return vecs, qlen
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU-side resize: PIL.Image.resize's default filter reproduced bit for bit on uint8
+# ---------------------------------------------------------------------------------------------------------------------
+_RESIZE_PRECISION_BITS = 32 - 8 - 2          # Pillow's Resample.c: 8-bit channels are filtered in 22-bit fixed point
+
+
+def _bicubic(x: float) -> float:
+    """Pillow's bicubic kernel (a = -0.5), evaluated in double precision in ITS operation order"""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@functools.lru_cache(maxsize=4096)
+def resize_tables(in_size: int, out_size: int):
+    """The per-axis tap tables `img.resize((W, H))` — the reference's only resampling call, dat_loader.py:121, PIL's default filter
+    (bicubic for RGB) — uses for one axis: Pillow's precompute_coeffs + normalize_coeffs_8bpc restated (double-precision weights
+    normalised to sum 1, then rounded to 22-bit fixed point).  Returns (bounds int32 [out, 2] = first tap, tap count; coefficients
+    int32 [out, ksize]; ksize).  The HIP kernel zsg_resize_u8 accumulates these integers exactly as Pillow does, so its uint8 output
+    is bit-identical to Pillow's (tests/test_cpu_loader.py pins the tables against Pillow itself, tests/test_gpu_trainer.py the kernel)."""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    coef = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        bounds[xx] = (xmin, xmax)
+        for x, w in enumerate(k):
+            v = w * (1 << _RESIZE_PRECISION_BITS)
+            coef[xx, x] = int(-0.5 + v) if w < 0 else int(0.5 + v)
+    return bounds, coef, ksize
+
+
+class GpuResizer:
+    """Resizes raw uint8 HWC images of ANY size to one [B, H, W, 3] uint8 batch on the GPU (zsg_resize_u8: Pillow's two-pass
+    fixed-point bicubic, bit-identical).  The tap tables of an axis length are computed once on the host and kept on the device."""
+
+    def __init__(self, out_hw, device="cuda"):
+        self.Ho, self.Wo, self.dev = int(out_hw[0]), int(out_hw[1]), device
+        self._tab = {}
+        self._tmp = None
+
+    def _tables(self, n_in, n_out):
+        key = (n_in, n_out)
+        if key not in self._tab:
+            if n_in == n_out:
+                self._tab[key] = None                    # Pillow skips a pass whose size does not change
+            else:
+                b, c, ks = resize_tables(n_in, n_out)
+                self._tab[key] = (torch.from_numpy(b).to(self.dev), torch.from_numpy(c).to(self.dev), ks)
+        return self._tab[key]
+
+    def __call__(self, imgs, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """imgs: list of uint8 [h, w, 3] DEVICE tensors; returns uint8 [B, Ho, Wo, 3]"""
+        from ._lib import check, lib, stream_ptr
+        B = len(imgs)
+        if out is None:
+            out = torch.empty(B, self.Ho, self.Wo, 3, dtype=torch.uint8, device=self.dev)
+        need = max(int(im.shape[0]) for im in imgs) * self.Wo * 3
+        if self._tmp is None or self._tmp.numel() < need:
+            self._tmp = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        st = stream_ptr()
+        for i, im in enumerate(imgs):
+            assert im.is_cuda and im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == 3 and im.is_contiguous()
+            h, w = int(im.shape[0]), int(im.shape[1])
+            tx, ty = self._tables(w, self.Wo), self._tables(h, self.Ho)
+            check(lib.zsg_resize_u8(im.data_ptr(), h, w, 3,
+                                    tx[0].data_ptr() if tx else None, tx[1].data_ptr() if tx else None, tx[2] if tx else 0,
+                                    ty[0].data_ptr() if ty else None, ty[1].data_ptr() if ty else None, ty[2] if ty else 0,
+                                    self.Ho, self.Wo, self._tmp.data_ptr(), out[i].data_ptr(), st), "zsg_resize_u8")
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------

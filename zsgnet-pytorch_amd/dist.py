@@ -129,6 +129,8 @@ class BucketReducer:
     def __init__(self, flat: torch.Tensor, buckets: List[Bucket], group=None, comm: Optional["NativeComm"] = None):
         self.flat, self.buckets, self.group, self.comm = flat, buckets, group, comm
         self.pending = []
+        self.time_wait = False          # bench.py: bracket wait() with events — how long the compute stream stands behind the last bucket
+        self.wait_events = []
 
     def run(self, n_launches: int, launch_range: Callable[[int, int], None], side_stream: Optional[Callable[[], Any]] = None):
         """launch_range(i, j) enqueues launches [i, j).  After the launch with index b.ready, bucket b is reduced.
@@ -162,11 +164,27 @@ class BucketReducer:
             self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
+        ev = None
+        if self.time_wait and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()              # completes with the backward's last launch on the compute stream
         if self.comm is not None:
             self.comm.wait()
         for w in self.pending:
             w.wait()
         self.pending = []
+        if ev is not None:
+            ev[1].record()              # completes once the stream has passed the waits: the difference is the EXPOSED all-reduce time
+            self.wait_events.append(ev)
+
+    def exposed_ms(self) -> Optional[float]:
+        """mean time the compute stream waited for the collectives per backward, over the brackets collected while time_wait was set"""
+        if not self.wait_events:
+            return None
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self.wait_events]
+        self.wait_events = []
+        return sum(v) / len(v)
 
 
 class DistributedDataParallel(nn.Module):
@@ -189,10 +207,13 @@ class DistributedDataParallel(nn.Module):
         self.tail_elems = int(tail_bucket_mb * (1 << 20) / 4)
         self.world = get_world_size()
         self.active = self.world > 1 or force_collectives
-        kind = comm or os.environ.get("ZSG_COMM", "torch")
-        if kind not in ("torch", "native"):
-            raise ValueError(f"comm={kind!r}: expected 'torch' or 'native'")
-        self.comm = NativeComm(process_group) if (kind == "native" and self.active) else None
+        kind = comm if comm is not None else os.environ.get("ZSG_COMM", "torch")
+        if not isinstance(kind, str):      # a communicator object with NativeComm's interface (all_reduce / broadcast / wait / close): tests
+            self.comm = kind if self.active else None
+        else:
+            if kind not in ("torch", "native"):
+                raise ValueError(f"comm={kind!r}: expected 'torch' or 'native'")
+            self.comm = NativeComm(process_group) if (kind == "native" and self.active) else None
         self._tuned = set()
         object.__setattr__(module, "_ddp", self)      # plain attribute: registering it as a sub-module would create a cycle
         if self.active:
