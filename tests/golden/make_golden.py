@@ -155,11 +155,63 @@ def gen_resize(cfg):
     save("g14_resize", **d)
 
 
+def gen_learnable(R, S=128, B=16, steps=160, lr=1e-3):
+    """G15: the Acc@IoU0.5 proxy's REFERENCE side.  The reference network (mdl.py get_default_net), loss (loss.py) and evaluator
+    (evaluator.py) trained on the CPU with torch.optim.Adam(betas=(0.9, 0.99)) (main_dist.py:50) on a task it can learn —
+    O.learnable_batch: the annotated box is a bright rectangle — from a seeded start, a fresh batch and fresh LSTM start states
+    every step; then eval mode on 256 held-out samples.  Recorded: every step's loss and the Acc@IoU0.5 hits per held-out batch.
+    tests/test_gpu_fullshape.py trains the HIP model on the same stream of batches and must learn the same thing."""
+    A, L, E, M, cfg = R["anchors"], R["loss"], R["evaluator"], R["mdl"], R["cfg"]
+    ratios = eval(cfg["ratios"], {})
+    scales = cfg["scale_factor"] * np.array(eval(cfg["scales"], {}))
+    cpu = torch.device("cpu")
+    sd = O.seeded_state_dict("resnet50", seed=3)
+    net = M.get_default_net(num_anchors=9, cfg=cfg)
+    net.load_state_dict(sd, strict=False)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=lr, betas=(0.9, 0.99))
+    lf = L.get_default_loss(ratios, scales, cfg)
+    ev = E.get_default_eval(ratios, scales, cfg)
+    gq = torch.Generator().manual_seed(8)
+    losses = []
+    for it in range(steps):
+        bt = O.learnable_batch(B, S, seed=100 + it)
+        h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
+        net.lstm_init_hidden = lambda bs, h0=h0, c0=c0: (h0, c0)
+        out = net(bt)
+        if it == 0:
+            fs = [tuple(int(v) for v in r) for r in out["feat_sizes"].tolist()]
+            anc = A.create_anchors(fs, ratios, scales, device=cpu).float()
+            lf.anchs = anc
+            ev.anchs = anc
+        ls = lf(out, bt)
+        opt.zero_grad()
+        ls["loss"].backward()
+        opt.step()
+        losses.append(float(ls["loss"].item()))
+        if it % 20 == 0:
+            print(f"  g15 step {it}: loss {losses[-1]:.4f}", flush=True)
+    net.eval()
+    hits = []
+    with torch.no_grad():
+        for bi in range(16):
+            bt = O.learnable_batch(16, S, seed=9000 + bi)
+            h0, c0 = torch.randn(2, 16, 128, generator=gq), torch.randn(2, 16, 128, generator=gq)
+            net.lstm_init_hidden = lambda bs, h0=h0, c0=c0: (h0, c0)
+            hits.append(float(ev(net(bt), bt)["Acc"].item()) * 16)
+    print(f"  g15: loss {losses[0]:.3f} -> {np.mean(losses[-10:]):.3f}; held-out Acc@IoU0.5 hits {sum(hits):.0f}/256")
+    save("g15_learnable", losses=np.array(losses, np.float64), hits=np.array(hits, np.float64), S=np.array([S]), B=np.array([B]),
+         steps=np.array([steps]), lr=np.array([lr]), seed=np.array([3]), feat_sizes=np.array(fs))
+
+
 def main():
     R = import_reference()
     A, L, E, M, cfg = R["anchors"], R["loss"], R["evaluator"], R["mdl"], R["cfg"]
-    if ONLY and all(o.startswith("g14") for o in ONLY):
-        gen_resize(cfg)
+    if ONLY and all(o.startswith("g14") or o.startswith("g15") for o in ONLY):
+        if any(o.startswith("g14") for o in ONLY):
+            gen_resize(cfg)
+        if any(o.startswith("g15") for o in ONLY):
+            gen_learnable(R)
         return
     ratios = eval(cfg["ratios"], {})
     scales = cfg["scale_factor"] * np.array(eval(cfg["scales"], {}))
@@ -614,6 +666,7 @@ def main():
         d["batchdtype_" + k] = np.array(str(v.dtype))
     save("g13_dataset", **d)
     gen_resize(cfg)
+    gen_learnable(R)
     print("done")
 
 

@@ -244,9 +244,12 @@ def _full_batch_properties(Z, arch, B, hw, kind, seed):
         sub = {k: (v[:SUB] if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in inp.items()}
         sub["h0"], sub["c0"] = torch.zeros(2, SUB, 128), torch.zeros(2, SUB, 128)
         part = net(sub)["att_bbx_out"]
-    e_sub = float((full[:SUB] - part).abs().max())
-    print(f"eval: rows 0..{SUB - 1} of the B={B} batch vs the same images as a batch of {SUB}: max abs diff {e_sub:.1e}")
-    assert e_sub <= 2e-3
+    mag = float(full[:SUB].abs().max())
+    e_sub = float((full[:SUB] - part).abs().max()) / max(mag, 1e-30)
+    # (relative: with the running statistics of two training steps the eval-mode activations of a random-init network are not O(1);
+    #  the two plans use different tiles / split-K factors = other fp32 summation orders)
+    print(f"eval: rows 0..{SUB - 1} of the B={B} batch vs the same images as a batch of {SUB}: max diff {e_sub:.1e} of the output range {mag:.3g}")
+    assert e_sub <= 1e-3
     return net
 
 
@@ -338,29 +341,27 @@ def test_training_trajectory_and_eval_argmax_agreement(Z):
     assert abs(acc_hip - acc_ref) <= (128 - n_sure)
 
 
-def test_learnable_task_reaches_the_same_accuracy(Z):
+def test_learnable_task_reaches_the_same_accuracy(Z, gold):
     """Acc@IoU0.5 proxy, part 2 (reference: evaluator.py:48-117 scoring the training of utils.py:353-414).
-    A task the network can actually learn — O.learnable_batch: the box is a bright rectangle in the image — is trained from the
-    same start by the HIP path (FusedAdam) and by the CPU oracle (torch.optim.Adam): ResNet-50 + FPN, 128x128, batch 16,
-    lr 1e-3, 160 steps, fresh batch and LSTM states every step.  The two fp32 trajectories drift apart step by step (see the
-    trajectory test above); what must agree is what they LEARN: both losses fall below 8 % of the first step's, and in eval mode on the
-    same 256 held-out samples each model scores Acc@IoU0.5 >= 0.95 with hit counts within 4 samples of each other (measured:
-    oracle 256/256)."""
+    A task the network can actually learn — O.learnable_batch: the box is a bright rectangle in the image.  Golden g15 holds what
+    the REFERENCE made of it (mdl.py / loss.py / evaluator.py on the CPU, torch.optim.Adam as main_dist.py:50; tests/golden/
+    make_golden.py gen_learnable): ResNet-50 + FPN, 128x128, batch 16, lr 1e-3, 160 steps from a seeded start, a fresh batch and
+    fresh LSTM states every step — every step's loss, then Acc@IoU0.5 on 256 held-out samples (256 / 256 hits).  The HIP model
+    trains on the same stream.  Two fp32 trajectories drift apart step by step (see the trajectory test above); what must agree is
+    what they LEARN: the same first loss, both losses below 8 % of it at the end, and Acc@IoU0.5 >= 0.95 with the hit count within
+    4 samples of the reference's.  (Rounds 2-3 trained the CPU oracle beside the HIP model inside the test: 8 minutes of the suite;
+    measured then: HIP 253 / 256, oracle 254 / 256.)"""
     config, evaluator, loss, mdl, optim = Z
-    import os
-    import time
-    from conftest import start_oracle_learn
-    S, steps = (int(v) for v in os.environ.get("ZSG_TEST_LEARN", "128,160").split(","))
-    B, lr_ = 16, 1e-3
-    job = start_oracle_learn(S, steps)            # (the CPU-oracle half: started at session start by conftest.py, here when run alone)
+    g = gold("g15_learnable")
+    S, B, steps, lr_ = int(g["S"][0]), int(g["B"][0]), int(g["steps"][0]), float(g["lr"][0])
+    ref_losses, ref_hits = g["losses"], float(g["hits"].sum())
     cfg = config.get_cfg(resnet_arch="resnet50", resize_img=[S, S])
-    sd = O.seeded_state_dict("resnet50", 3)
+    sd = O.seeded_state_dict("resnet50", int(g["seed"][0]))
     net = mdl.get_default_net(9, cfg)
     net.load_state_dict(sd)
     net.to("cuda").train()
     lf, ev = loss.get_default_loss(RATIOS, SCALES, cfg), evaluator.get_default_eval(RATIOS, SCALES, cfg)
     opt = optim.FusedAdam(net, lr=lr_, betas=(0.9, 0.99))
-    anc = torch.from_numpy(O.create_anchors(O.feat_sizes_for(S, S), RATIOS, SCALES).astype(np.float32))
     gq = torch.Generator().manual_seed(8)
     hip_losses = []
     for it in range(steps):
@@ -369,28 +370,22 @@ def test_learnable_task_reaches_the_same_accuracy(Z):
         inp = to_dev(bt)
         inp["h0"], inp["c0"] = h0, c0
         opt.zero_grad()
-        ls = lf(net(inp), inp)
+        out = net(inp)
+        if it == 0:
+            assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist()
+        ls = lf(out, inp)
         ls["loss"].mean().backward()
         opt.step()
         hip_losses.append(float(ls["loss"].detach()))
-    t0 = time.time()
-    while not os.path.exists(job["out"]):
-        assert job["proc"].poll() is None or os.path.exists(job["out"]), "the CPU-oracle training process died"
-        assert time.time() - t0 < 1500, "the CPU-oracle training did not finish"
-        time.sleep(2)
-    res = torch.load(job["out"])
-    print(f"(waited {time.time() - t0:.0f} s for the CPU oracle's {steps} steps)")
-    params_sd, ref_losses = res["sd"], res["losses"]
-    first = (hip_losses[0], ref_losses[0])
+    first = (hip_losses[0], float(ref_losses[0]))
     last = None
     for cur in zip(hip_losses, ref_losses):
         last = cur if last is None else (0.8 * last[0] + 0.2 * cur[0], 0.8 * last[1] + 0.2 * cur[1])
-    print(f"loss: first step hip {first[0]:.3f} / oracle {first[1]:.3f}; smoothed end hip {last[0]:.3f} / oracle {last[1]:.3f}")
+    print(f"loss: first step hip {first[0]:.3f} / reference {first[1]:.3f}; smoothed end hip {last[0]:.3f} / reference {last[1]:.3f}")
     np.testing.assert_allclose(first[0], first[1], rtol=5e-4)
     assert last[0] < 0.08 * first[0] and last[1] < 0.08 * first[1], (first, last)
-    sd_ref = params_sd
     net.eval()
-    hits_h = hits_o = 0.0
+    hits_h = 0.0
     with torch.no_grad():
         for bi in range(16):
             bt = O.learnable_batch(16, S, seed=9000 + bi)
@@ -398,9 +393,6 @@ def test_learnable_task_reaches_the_same_accuracy(Z):
             inp = to_dev(bt)
             inp["h0"], inp["c0"] = h0, c0
             hits_h += float(ev(net(inp), inp)["Acc"]) * 16
-            ref = O.zsgnet_forward(sd_ref, bt, h0, c0, arch="resnet50", training=False)
-            hits_o += float(O.zsg_eval(ref["att_out"].squeeze(-1).numpy(), ref["bbx_out"].numpy(), bt["annot"].numpy(), bt["img_size"].numpy(),
-                                       anc.numpy())["Acc"]) * 16
-    print(f"eval Acc@IoU0.5 on 256 held-out samples: hip {hits_h:.0f}/256, oracle {hits_o:.0f}/256")
-    assert hits_h >= 0.95 * 256 and hits_o >= 0.95 * 256, (hits_h, hits_o)
-    assert abs(hits_h - hits_o) <= 4, (hits_h, hits_o)
+    print(f"eval Acc@IoU0.5 on 256 held-out samples: hip {hits_h:.0f}/256, reference {ref_hits:.0f}/256")
+    assert hits_h >= 0.95 * 256 and ref_hits >= 0.95 * 256, (hits_h, ref_hits)
+    assert abs(hits_h - ref_hits) <= 4, (hits_h, ref_hits)

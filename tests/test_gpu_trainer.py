@@ -88,6 +88,15 @@ def test_real_data_loader_uint8_ingest_and_training(tmp_path, gold):
     assert torch.equal(x4[..., :3].cpu(), bf["img"].permute(0, 2, 3, 1)) and float(x4[..., 3].abs().max()) == 0.0
     # the network on either ingest path (split-K launches use fp32 atomics: equal up to summation order)
     assert float((of - ou).abs().max()) < 1e-5
+    # gpu_resize: the workers only decode; the prefetcher resizes the raw images (different sizes: a list) on the GPU — the batch it
+    # hands over is byte-identical to the one whose images PIL resized in the worker
+    ds_r = D.ImgQuDataset(cfg, tmp_path / "d.csv", "refclef", gpu_resize=True)
+    br = D.collater([ds_r[0], ds_r[1]])
+    assert isinstance(br["img"], list) and [tuple(t.shape) for t in br["img"]] == [(30, 40, 3), (47, 33, 3)]
+    got = next(iter(D.DevicePrefetcher([br], "cuda", resize_hw=(64, 96))))
+    torch.cuda.synchronize()
+    assert got["img"].dtype == torch.uint8 and torch.equal(got["img"].cpu(), bu["img"])
+    assert all(torch.equal(got[k].cpu(), bu[k]) for k in bu if k != "img")
     learn = main_dist("real0", **{k: str(v) for k, v in kw.items()})
     assert isinstance(learn.data.train_dl, D.DevicePrefetcher) and learn.num_it == 4        # 5 rows, bs 2, drop_last, 2 epochs
     res = learn.testing(learn.data.test_dl)

@@ -344,3 +344,24 @@ def test_basicblock_stage_and_trunk(gold):
     np.testing.assert_allclose(c3.numpy()[:, ::4], g["c3"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(c4.numpy()[:, ::8], g["c4"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(c5.numpy()[:, ::16], g["c5"], rtol=5e-4, atol=5e-5)
+
+
+def test_learnable_task_first_step_vs_reference(gold):
+    """G15 (the reference trained on O.learnable_batch, tests/golden/make_golden.py gen_learnable): the oracle's loss on the first
+    batch from the same seeded start equals the reference's — pins the proxy task's inputs (batch generator, start weights, LSTM start
+    states) that tests/test_gpu_fullshape.py::test_learnable_task_reaches_the_same_accuracy trains the HIP model on."""
+    import torch
+    g = gold("g15_learnable")
+    S, B = int(g["S"][0]), int(g["B"][0])
+    sd = O.seeded_state_dict("resnet50", int(g["seed"][0]))
+    bt = O.learnable_batch(B, S, seed=100)
+    gq = torch.Generator().manual_seed(8)
+    h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
+    with torch.no_grad():
+        out = O.zsgnet_forward(sd, bt, h0, c0, arch="resnet50")
+    assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist()
+    r, s = O.default_ratios_scales()
+    anc = torch.from_numpy(O.create_anchors([tuple(v) for v in out["feat_sizes"].tolist()], r, s).astype(np.float32))
+    ls = O.torch_loss(out, bt["annot"], anc)
+    np.testing.assert_allclose(float(ls["loss"]), g["losses"][0], rtol=2e-5)
+    assert g["losses"][-10:].mean() < 0.01 * g["losses"][0] and g["hits"].sum() >= 0.95 * 256      # (the reference did learn the task)

@@ -170,7 +170,12 @@ int main() {
     hipMalloc(&g_src, 1 << 20); hipMalloc(&g_out, 1 << 16); hipMalloc(&g_cnt, 1024 * 4);
     hipMemset(g_src, 0, 1 << 20);
     part1<0, 0, 1>();
-    part1<F_FMA, 0, 1>(); part1<F_DSR, 0, 1>(); part1<F_VMEM, 0, 1>();
+    part1<F_FMA, 0, 1>(); part1<F_DPP, 0, 1>(); part1<F_ADD, 0, 1>(); part1<F_DSR, 0, 1>(); part1<F_DSW, 0, 1>(); part1<F_VMEM, 0, 1>(); part1<F_SALU, 0, 1>(); part1<F_NOP, 0, 1>();
+    part1<F_FMA, 0, 2>(); part1<F_DSR, 0, 2>(); part1<F_VMEM, 0, 2>(); part1<F_SALU, 0, 2>();
+    part1<F_FMA, 0, 3>(); part1<F_DSR, 0, 3>(); part1<F_VMEM, 0, 3>();
+    part1<F_FMA, 0, 4>(); part1<F_DSR, 0, 4>();
+    part1<F_FMA, 1, 1>(); part1<F_DSR, 1, 1>(); part1<F_VMEM, 1, 1>();
+    part1<0, 2, 1>(); part1<F_FMA, 2, 1>(); part1<F_DSR, 2, 1>(); part1<F_VMEM, 2, 1>();
     part1<0, 3, 1>(); part1<F_FMA, 3, 1>(); part1<F_DSR, 3, 1>(); part1<F_VMEM, 3, 1>();
     part2<F_FMA, 0, 0>();
     part2<F_FMA, 0, 4>(); part2<F_FMA, 0, 8>(); part2<F_FMA, 0, 16>(); part2<F_FMA, 0, 32>();

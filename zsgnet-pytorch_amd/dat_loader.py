@@ -195,9 +195,14 @@ class GpuResizer:
 class ImgQuDataset(Dataset):
     """Any grounding dataset given as a CSV of (img_id, bbox, query) rows; the same image may appear on many rows."""
 
-    def __init__(self, cfg, csv_file, ds_name: str, split_type: str = "train", embedder=None, gpu_normalise: bool = False):
+    def __init__(self, cfg, csv_file, ds_name: str, split_type: str = "train", embedder=None, gpu_normalise: bool = False,
+                 gpu_resize: bool = False):
+        """gpu_normalise: the item's image stays uint8 HWC (converted on the GPU); gpu_resize (implies it): the image is NOT resized by
+        the worker either — it travels at its decoded size and DevicePrefetcher resizes it on the GPU (GpuResizer: Pillow's filter
+        bit for bit), which leaves a worker only the JPEG decode."""
         import pandas as pd
-        self.cfg, self.ds_name, self.split_type, self.gpu_normalise = cfg, ds_name, split_type, gpu_normalise
+        gpu_normalise = gpu_normalise or gpu_resize
+        self.cfg, self.ds_name, self.split_type, self.gpu_normalise, self.gpu_resize = cfg, ds_name, split_type, gpu_normalise, gpu_resize
         self.embedder = embedder if embedder is not None else get_embedder(cfg)
         self.img_dir = Path(cfg["ds_info"][ds_name]["img_dir"])
         self.phrase_len = PHRASE_LEN
@@ -222,7 +227,8 @@ class ImgQuDataset(Dataset):
         qvec, qlen = embed_query(self.embedder, q, self.phrase_len)
         x1, y1, x2, y2 = self.boxes[idx]
         rs = self.cfg["resize_img"]
-        img = img.resize((rs[0], rs[1]))                          # PIL's default filter, as the reference (dat_loader.py:121)
+        if not self.gpu_resize:
+            img = img.resize((rs[0], rs[1]))                      # PIL's default filter, as the reference (dat_loader.py:121)
         target = 2 * np.array([y1 / h, x1 / w, y2 / h, x2 / w]) - 1          # y1x1y2x2 in [-1, 1] (anchors are row, column)
         a = np.asarray(img)                                       # [H, W, 3] uint8
         if self.gpu_normalise:
@@ -240,6 +246,9 @@ def collater(batch: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
     max_qlen = int(max(int(b["qlens"]) for b in batch))
     out = {}
     for k in batch[0]:
+        if k == "img" and batch[0][k].dtype == torch.uint8 and len({tuple(b[k].shape) for b in batch}) > 1:
+            out[k] = [b[k] for b in batch]          # raw images of different sizes (gpu_resize): DevicePrefetcher resizes them on the GPU
+            continue
         t = torch.stack([b[k] for b in batch])
         out[k] = t if (k == "img" and t.dtype == torch.uint8) else t.float()
     out["qvec"] = out["qvec"][:, :max_qlen]
@@ -289,9 +298,13 @@ class DevicePrefetcher:
     """Wraps a loader of pinned host batches: the next batch is copied to the GPU on a side stream while the current one
     is being consumed (HIP copy engine overlaps the training step), and handed over with an event wait."""
 
-    def __init__(self, loader, device="cuda"):
+    def __init__(self, loader, device="cuda", resize_hw=None):
+        """resize_hw = (H, W): batches whose "img" is raw uint8 HWC (a list of differently sized images, or a stack at another size)
+        are resized on the GPU, on the upload stream (GpuResizer)."""
         self.loader, self.device = loader, torch.device(device)
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.resize_hw = tuple(resize_hw) if resize_hw is not None else None
+        self._resizer = None
 
     def __len__(self):
         return len(self.loader)
@@ -300,7 +313,16 @@ class DevicePrefetcher:
         if self.stream is None:
             return batch, None
         with torch.cuda.stream(self.stream):
-            dev = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            dev = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
+            img = batch.get("img")
+            raw = img if isinstance(img, list) else (list(img) if (self.resize_hw and torch.is_tensor(img) and img.dtype == torch.uint8
+                                                                   and tuple(img.shape[1:3]) != self.resize_hw) else None)
+            if raw is not None:
+                if self.resize_hw is None:
+                    raise RuntimeError("DevicePrefetcher: raw images of mixed sizes need resize_hw")
+                if self._resizer is None:
+                    self._resizer = GpuResizer(self.resize_hw, self.device)
+                dev["img"] = self._resizer([im.pin_memory().to(self.device, non_blocking=True).contiguous() for im in raw])
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return dev, ev
@@ -335,10 +357,12 @@ def get_data(cfg, embedder=None, prefetch: Optional[bool] = None):
     emb = embedder if embedder is not None else get_embedder(cfg)
     gpu = torch.cuda.is_available() and (cfg["gpu_img_normalise"] if "gpu_img_normalise" in cfg else True)
     prefetch = gpu if prefetch is None else prefetch
+    gpu_rs = bool(gpu and prefetch and (cfg["gpu_img_resize"] if "gpu_img_resize" in cfg else True))      # resize on the GPU too (N2)
+    rs = cfg["resize_img"]
 
     def make(csv_key, split, is_train):
-        ds = ImgQuDataset(cfg, info[csv_key], ds_name, split, emb, gpu_normalise=gpu)
+        ds = ImgQuDataset(cfg, info[csv_key], ds_name, split, emb, gpu_normalise=gpu, gpu_resize=gpu_rs)
         dl = get_dataloader(cfg, ds, is_train)
-        return DevicePrefetcher(dl, cfg["device"]) if prefetch else dl
+        return DevicePrefetcher(dl, cfg["device"], resize_hw=(rs[1], rs[0]) if gpu_rs else None) if prefetch else dl
     return DataWrap(make("trn_csv_file", "train", True), make("val_csv_file", "valid", False),
                     {"test0": make("test_csv_file", "valid", False)}, cfg["tmp_path"])
