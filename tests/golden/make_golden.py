@@ -155,7 +155,7 @@ def gen_resize(cfg):
     save("g14_resize", **d)
 
 
-def gen_learnable(R, S=128, B=16, steps=240, lr=1e-3):
+def gen_learnable(R, S=128, B=16, steps=240, lr=1e-3, decay_at=200):
     """G15: the Acc@IoU0.5 proxy's REFERENCE side.  The reference network (mdl.py get_default_net), loss (loss.py) and evaluator
     (evaluator.py) trained on the CPU with torch.optim.Adam(betas=(0.9, 0.99)) (main_dist.py:50) on a task it can learn —
     O.learnable_batch: the annotated box is a bright rectangle — from a seeded start, a fresh batch and fresh LSTM start states
@@ -175,6 +175,9 @@ def gen_learnable(R, S=128, B=16, steps=240, lr=1e-3):
     gq = torch.Generator().manual_seed(8)
     losses = []
     for it in range(steps):
+        if it == decay_at:              # the last steps at lr / 10: the weights settle and the BatchNorm running statistics catch up with them
+            for grp in opt.param_groups:
+                grp["lr"] = lr * 0.1
         bt = O.learnable_batch(B, S, seed=100 + it)
         h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
         net.lstm_init_hidden = lambda bs, h0=h0, c0=c0: (h0, c0)
@@ -201,7 +204,7 @@ def gen_learnable(R, S=128, B=16, steps=240, lr=1e-3):
             hits.append(float(ev(net(bt), bt)["Acc"].item()) * 16)
     print(f"  g15: loss {losses[0]:.3f} -> {np.mean(losses[-10:]):.3f}; held-out Acc@IoU0.5 hits {sum(hits):.0f}/256")
     save("g15_learnable", losses=np.array(losses, np.float64), hits=np.array(hits, np.float64), S=np.array([S]), B=np.array([B]),
-         steps=np.array([steps]), lr=np.array([lr]), seed=np.array([3]), feat_sizes=np.array(fs))
+         steps=np.array([steps]), lr=np.array([lr]), decay_at=np.array([decay_at]), seed=np.array([3]), feat_sizes=np.array(fs))
 
 
 def main():

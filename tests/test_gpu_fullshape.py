@@ -367,6 +367,9 @@ def test_learnable_task_reaches_the_same_accuracy(Z, gold):
     gq = torch.Generator().manual_seed(8)
     hip_losses = []
     for it in range(steps):
+        if it == int(g["decay_at"][0]):
+            for grp in opt.param_groups:
+                grp["lr"] = lr_ * 0.1
         bt = O.learnable_batch(B, S, seed=100 + it)
         h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
         inp = to_dev(bt)
