@@ -480,6 +480,7 @@ class _Plan:
         self.expect_backward = False
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
+        self.bwd.side_defer = 0 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_DEFER, measured)
         self.tape = []
         self.acts: Dict[str, Act] = {}
         self.bytes = 0
@@ -959,7 +960,7 @@ class _Plan:
                     dx.gfilled = True
                 self.tape.append(pool_back)
             taps, lat = {}, {}
-            early = self.training and os.environ.get("ZSG_FPN_LATERAL_EARLY", "0") != "0"
+            early = self.training and os.environ.get("ZSG_FPN_LATERAL_EARLY", "1") != "0"
             for blk in net.blocks:
                 x = self._lower_block(blk, x)
                 if blk["last"]:

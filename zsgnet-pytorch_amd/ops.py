@@ -203,9 +203,13 @@ GRAPH_WARMUP = 2                                             # eager replays of 
 
 # Backward: a side-stream (weight-gradient) launch is released only after this many further main-stream convolutions have
 # been enqueued.  1 = the weight gradient of a layer starts when that layer's data gradient has finished, i.e. it runs under
-# the BatchNorm backward of the next layer down (which otherwise has the GPU to itself) instead of splitting the CUs with the
-# data gradient: 15.27 -> 15.12 ms per step (tools/trace_overlap.py); 2-3 are no better.
-SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "1"))
+# the BatchNorm backward of the next layer down instead of splitting the CUs with the data gradient; 0 = it starts beside its own
+# layer's data gradient.  Round 2 (markers on every release, slower weight gradients): 1 won, 15.27 -> 15.12 ms.  Round 4, one
+# box each, tools/ab_env.sh (4 interleaved runs): configs[1] 13.64 -> 13.54 ms with 0 (+ the early laterals, mdl.py), ResNet-18
+# 7.61 -> 7.46, SSD-VGG B=32 38.32 -> 38.16; ResNet-101 @600^2 B=32 (launches of several hundred us, every one fills the chip)
+# 105.2 -> 107.3 with 0 — hence the plan picks 0 for small launches and 1 for large ones (Program.side_defer) unless
+# ZSG_SIDE_DEFER says otherwise.
+SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "-1"))
 # ... and only at every n-th main-stream convolution: every release costs the main stream an event record, i.e. a marker packet
 # the next kernel has to wait for (~4 us each: doubling the ~70 records of a ResNet-50 backward costs 0.28 ms).  Measured on
 # configs[1]: n = 1 / 2 / 3 / 4 / 5 / 6 -> 14.59 / 14.66 / 14.40 / 14.56 / 14.41 / 14.51 ms; SSD-VGG B=32 39.49 -> 39.15 ms;
@@ -251,6 +255,7 @@ class Program:
         self.keep = []          # ctypes structs / tensors that must outlive the program
         self._side = None
         self.side_batch = 1     # deferred side launches are released at every side_batch-th main-stream convolution
+        self.side_defer = 1     # ... and only after this many further main-stream convolutions (backward program; SIDE_DEFER above)
         self._side_busy = False
         self._graphs = {}       # (start, stop, side-stream mode) -> [eager replays so far, captured graph | None]
         self._sched = {}        # (start, stop, join, side stream busy at entry, release policy) -> compiled lane schedule
@@ -275,7 +280,7 @@ class Program:
         side = self._side
         st0, st1 = C.c_void_p(stream), C.c_void_p(side.cuda_stream)
         dirty, nev = True, 0
-        defer = SIDE_DEFER if self.name == "bwd" else 0
+        defer = (SIDE_DEFER if SIDE_DEFER >= 0 else self.side_defer) if self.name == "bwd" else 0
         pending = []            # deferred lane-1 launches: [index, main-stream convolutions still to enqueue before it]
         nconv, batch = 0, max(1, SIDE_BATCH or self.side_batch)
 
@@ -337,7 +342,7 @@ class Program:
         join to the last side-stream launch."""
         ops, nev = [], 0
         dirty, last_main, last_side = True, None, None
-        defer = SIDE_DEFER if self.name == "bwd" else 0
+        defer = (SIDE_DEFER if SIDE_DEFER >= 0 else self.side_defer) if self.name == "bwd" else 0
         pending, nconv, batch = [], 0, max(1, SIDE_BATCH or self.side_batch)
 
         def side_launch(i):
@@ -400,7 +405,7 @@ class Program:
         if self._side is None:
             self._side = shared_side_stream()
             self._ev_pool = []
-        key = (start, stop, join, self._side_busy, SIDE_DEFER, SIDE_BATCH or self.side_batch)
+        key = (start, stop, join, self._side_busy, SIDE_DEFER, self.side_defer, SIDE_BATCH or self.side_batch)
         sched = self._sched.get(key)
         if sched is None:
             sched = self._sched[key] = self._schedule(start, stop, join, self._side_busy)
