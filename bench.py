@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 # forward conv 2*MAC per image, keyed by (arch, input size); a training step is 3x
 FWD_GF = {("resnet50", 300): 32.569, ("ssd_vgg", 300): 75.003, ("resnet50", 600): 85.911, ("resnet101", 600): 140.609}
 PEAK_TF = 157.3                                                         # fp32-input MFMA, MI355X_MICROARCH.md
-ROUND = "r03"
+ROUND = "r04"
 
 
 def config_label(arch: str, backbone: str, img: int, bs: int, world: int) -> str:
