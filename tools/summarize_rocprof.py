@@ -19,14 +19,13 @@ if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 
-DEFAULTS = {"igemm_kernel": [None] * 5 + ["1", "false", "false", "32", "0"], "wino_kernel": [None] * 3 + ["false"],
-            "wgrad_kernel": [None] * 5 + ["true"]}
+DEFAULTS = {"igemm_kernel": [None] * 4 + ["1", "32"], "wino_kernel": [None] * 3, "wgrad_kernel": [None] * 5 + ["true"]}
 
 
 def klass(name):
-    """the kernel name as libzsg's event profiler reports it — 'igemm_kernel<64, 64, 2, 2, false, 2>', 'wino_kernel<2, 2, 4>',
+    """the kernel name as libzsg's event profiler reports it — 'igemm_kernel<64, 64, 4, false, 2>', 'wino_kernel<2, 2, 4>',
     'wgrad_kernel<2, 1, 16, 2, 4>': rocprofv3 prints every template argument, libzsg leaves trailing defaults out and writes the
-    source-transform / 64-deep-K variants as a '+pre' / '+k64' suffix"""
+    64-deep-K variant as a '+k64' suffix"""
     name = name.replace("void ", "").split("(")[0]
     if name.startswith("wgrad_reduce"):
         return "wgrad_reduce_kernel"
@@ -34,15 +33,9 @@ def klass(name):
     if base in DEFAULTS and "<" in name:
         args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
         suffix = ""
-        if base == "igemm_kernel" and len(args) >= 9:
-            suffix = ("+pre" if args[7] == "true" else "") + ("+k64" if args[8] == "64" else "")
-            args[7], args[8] = "false", "32"
-            if len(args) >= 10:
-                suffix += {"1": "+pp", "2": "+r3"}.get(args[9], "")
-                args[9] = "0"
-        if base == "wino_kernel" and len(args) >= 4:
-            suffix = "+pre" if args[3] == "true" else ""
-            args[3] = "false"
+        if base == "igemm_kernel" and len(args) >= 6:
+            suffix = "+k64" if args[5] == "64" else ""
+            args[5] = "32"
         dflt = DEFAULTS[base]
         while len(args) > 1 and len(args) <= len(dflt) and dflt[len(args) - 1] is not None and args[-1] == dflt[len(args) - 1]:
             args.pop()

@@ -52,7 +52,8 @@ struct IgParams {
     IgSegDev seg[ZSG_MAX_SEG];
 };
 
-// BM x BN block tile computed by WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), times KS "K groups": wave group
+// BM x BN block tile computed by NW = WM x WN waves (4: 2 x 2; 8: 2 x 4, or 4 x 2 for the 128x64 tile; each wave: TM x TN MFMA tiles
+// of 32x32), times KS "K groups": wave group
 // kg multiplies the kg-th 1/KS of every 32-deep K tile and the groups' accumulators are summed through LDS before the
 // epilogue (intra-block split-K: fixed order, no atomics).  It puts KS times as many waves on a SIMD for the same tile —
 // what the small-grid layers (a few hundred 64x64 tiles for 256 CUs) need to hide LDS / barrier latency.
@@ -64,8 +65,10 @@ struct IgParams {
 // __launch_bounds__' second argument (two waves per SIMD = at most 256 registers per lane): without it hipcc parks the accumulators
 // of the 4-wave tiles in AGPRs and copies one tile in and out of them every K step (32 v_accvgpr moves per 16 MFMAs — VALU-class
 // instructions that are paid in full next to fp32 MFMAs).  The 64-deep 128x128 4-wave tile needs more than 256 registers.
-template <int BM, int BN, int WM, int WN, bool MERGE_X, int KS = 1, int BK = IG_BK>
-__global__ __launch_bounds__(64 * WM * WN * KS, (BK == 64 && BM * BN >= 128 * 128 && WM * WN * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
+template <int BM, int BN, int NW, bool MERGE_X, int KS = 1, int BK = IG_BK>
+__global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && NW * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per K group");
+    constexpr int WM = (NW == 8 && BN == 64) ? 4 : 2, WN = NW / WM;     // the wave grid over the tile
     constexpr int NB = 2;                    // LDS tile buffers
     static_assert(BK == 32 || (BK == 64 && !MERGE_X), "K tile depth");
     constexpr int LDR = BK + 4;              // floats per LDS tile row (an odd number of 16-byte units: conflict-free b128 fragment reads)
@@ -559,7 +562,7 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int WM, int WN, bool MX, int KS, int BK>
+template <int BM, int BN, int NW, bool MX, int KS, int BK>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + BM * sizeof(int);
     static bool attr_done[ZSG_MAX_DEV] = {};      // per device; idempotent (a benign race sets it twice)
@@ -567,26 +570,26 @@ static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const ch
     (void)hipGetDevice(&dev);
     ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "igemm: device %d", dev);
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MX, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, MX, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, p.alg_bytes);
-    ZSG_LAUNCH((igemm_kernel<BM, BN, WM, WN, MX, KS, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * WM * WN * KS), lds, st, p);
+    ZSG_LAUNCH((igemm_kernel<BM, BN, NW, MX, KS, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * NW * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
 // p.bk64 selects the 64-deep K tile (profile name = kname + "+k64")
-template <int BM, int BN, int WM, int WN, bool MX, int KS = 1>
+template <int BM, int BN, int NW, bool MX, int KS = 1>
 static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     if constexpr (!MX) {
         if (p.bk64) {
             static char nm[96];
             snprintf(nm, sizeof(nm), "%s+k64", kname);
-            return launch_cfg1<BM, BN, WM, WN, MX, KS, 64>(p, st, flops, nm);
+            return launch_cfg1<BM, BN, NW, MX, KS, 64>(p, st, flops, nm);
         }
     }
-    return launch_cfg1<BM, BN, WM, WN, MX, KS, IG_BK>(p, st, flops, kname);
+    return launch_cfg1<BM, BN, NW, MX, KS, IG_BK>(p, st, flops, kname);
 }
 
 // tile_hint = BM | (BN << 8) | (splits << 16); 0 = heuristic.  The Python lowering autotunes the hint per layer on
@@ -670,20 +673,20 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
         }
     }
     if (d->merge_x) {
-        if (BM == 128) return launch_cfg<128, 64, 2, 2, true>(p, st, flops, "igemm_kernel<128, 64, 2, 2, true>");
-        return launch_cfg<64, 64, 2, 2, true>(p, st, flops, "igemm_kernel<64, 64, 2, 2, true>");
+        if (BM == 128) return launch_cfg<128, 64, 4, true>(p, st, flops, "igemm_kernel<128, 64, 4, true>");
+        return launch_cfg<64, 64, 4, true>(p, st, flops, "igemm_kernel<64, 64, 4, true>");
     }
     if (w8 && BM == 64 && BN == 64) {
-        return launch_cfg<64, 64, 2, 2, false, 2>(p, st, flops, "igemm_kernel<64, 64, 2, 2, false, 2>");
+        return launch_cfg<64, 64, 4, false, 2>(p, st, flops, "igemm_kernel<64, 64, 4, false, 2>");
     }
     if (w8) {
-        if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 4, false>(p, st, flops, "igemm_kernel<128, 128, 2, 4, false>");
-        if (BM == 128 && BN == 64) return launch_cfg<128, 64, 4, 2, false>(p, st, flops, "igemm_kernel<128, 64, 4, 2, false>");
+        if (BM == 128 && BN == 128) return launch_cfg<128, 128, 8, false>(p, st, flops, "igemm_kernel<128, 128, 8, false>");
+        if (BM == 128 && BN == 64) return launch_cfg<128, 64, 8, false>(p, st, flops, "igemm_kernel<128, 64, 8, false>");
         ZSG_FAIL(-1, "conv_igemm: no 8-wave variant for tile %dx%d", BM, BN);
     }
-    if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 2, false>(p, st, flops, "igemm_kernel<128, 128, 2, 2, false>");
-    if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2, false>(p, st, flops, "igemm_kernel<128, 64, 2, 2, false>");
-    if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2, false>(p, st, flops, "igemm_kernel<64, 64, 2, 2, false>");
+    if (BM == 128 && BN == 128) return launch_cfg<128, 128, 4, false>(p, st, flops, "igemm_kernel<128, 128, 4, false>");
+    if (BM == 128 && BN == 64) return launch_cfg<128, 64, 4, false>(p, st, flops, "igemm_kernel<128, 64, 4, false>");
+    if (BM == 64 && BN == 64) return launch_cfg<64, 64, 4, false>(p, st, flops, "igemm_kernel<64, 64, 4, false>");
     ZSG_FAIL(-1, "conv_igemm: unsupported tile %dx%d", BM, BN);
 }
 
