@@ -7,6 +7,7 @@ import os
 import sys
 
 os.environ["ZSG_SHIPPED_TUNE"] = "0"
+os.environ.setdefault("ZSG_TUNE_ROUNDS", "9")          # the table is made once: more interleaved samples per candidate than a run-time tuning takes
 os.environ.pop("ZSG_TUNE_CACHE", None)
 import torch
 
