@@ -324,7 +324,10 @@ def main():
             # so frac <= 1 by construction; the algorithmic rate (what the direct convolution would have needed) is carried beside it.
             er = exec_ratio(dom["kernel"])
             share_exec = (exe_all / flops_all) if flops_all else 1.0       # FLOP-weighted executed share over all MFMA kernels
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"] * er, 2), "peak": PEAK_TF, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": dom["kernel"],
+                    "what": "the kernel with the largest share of the step's isolated kernel time (it changes from round to round as kernels get "
+                            "faster: top_kernels lists the next ones with their own fractions, all_mfma_kernels is FLOP-weighted over all of them)",
+                    "achieved": round(dom["tflops"] * er, 2), "peak": PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(dom["tflops"] * er / PEAK_TF, 4), "traffic": traffic, "traffic_note": tnote,
                     "algorithmic_bytes_per_launch": round(dom["alg_bytes_per_launch"]) if dom.get("alg_bytes_per_launch") else None,
                     "traffic_over_algorithmic": round(traffic / dom["alg_bytes_per_launch"], 3) if (traffic and dom.get("alg_bytes_per_launch")) else None,
