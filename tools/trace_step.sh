@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-t}; shift; KS=${@:-3 5}; OUT=$R/gpurun_out/trace_$TAG; mkdir -p $OUT
 export ZSG_TUNE_CACHE=${ZSG_TUNE_CACHE:-$R/gpurun_out/r3m/tune.json}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt_$TAG
-rocprofv3 --kernel-trace -d /tmp/kt_$TAG --output-format csv -- python $R/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-roofline --no-bx 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
+rocprofv3 --kernel-trace -d /tmp/kt_$TAG --output-format csv -- python $R/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-roofline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
 F=$(find /tmp/kt_$TAG -name "*kernel_trace.csv" | head -1)
 cd $R
 for k in $KS; do
