@@ -30,6 +30,10 @@ extern "C" {
 #define ZSG_MAX_SEG 8
 
 int zsg_version(void);
+/* sha256 stamp (16 hex digits) of the kernel sources this library was BUILT from (csrc/stamp.py): the host ties the shipped tuning
+ * table and the committed rocprof summaries to the library that is actually loaded (ZSG_LIB_PATH may point at another build), not to the
+ * source files lying next to it.  No reference counterpart (the reference has no tuned native kernels). */
+const char* zsg_source_stamp(void);
 const char* zsg_last_error(void);
 /* on != 0: the column-sum kernels (bias gradients, the head's border sums) use one block per output element group
  * instead of combining block partials with fp32 atomics, so every kernel of the library sums in a fixed order

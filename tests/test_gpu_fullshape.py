@@ -183,12 +183,17 @@ def test_configs3_ssd_vgg_b2(Z):
     _fwd_bwd_vs_fp64(Z, "ssd_vgg", 2, 300, False, kind="ssd_vgg", seed=5)
 
 
-def _full_batch_properties(Z, arch, B, hw, kind, seed):
-    """Size-independent checks at a configuration's OWN per-GPU batch, where the CPU oracle cannot follow in test time: finite
-    outputs; loss and evaluator EXACT functions of the HIP outputs (the numpy oracle on what the network produced); two runs of
-    the same step bit-identical in deterministic mode is covered elsewhere — here: the step is repeatable to fp32 summation order;
-    the first SUB images agree with the same images run as a batch of SUB through eval-mode (BatchNorm folded, batch-independent)
-    plans, and the gradient norms of a sub-batch step against the CPU oracle."""
+def _full_batch_properties(Z, arch, B, hw, kind, seed, oracle_grads=False):
+    """Size-independent checks at a configuration's OWN per-GPU batch: finite outputs; loss and evaluator EXACT functions of the
+    HIP outputs (the numpy oracle on what the network produced); the step repeatable to fp32 summation order (bit-identical runs in
+    deterministic mode are covered by test_gpu_determinism.py); the first SUB images agree with the same images run as a batch of
+    SUB through eval-mode (BatchNorm folded, batch-independent) plans.
+    oracle_grads=True (the SSD-VGG16 configuration: no BatchNorm, so the full batch is a sum of per-sample terms and the CPU fp32
+    oracle follows in about a minute): outputs, loss and EVERY parameter gradient of the B-sample step against the CPU oracle's.
+    What stays UNCHECKED for ResNet-101 at 600^2, B=32: its gradients at that batch are compared with nothing but themselves (finite,
+    repeatable) — train-mode batch statistics make a sub-batch step a different function, the eval plans of this package are
+    forward-only, and the CPU oracle needs ~10 minutes for one such step in fp32 + fp64; the same network's gradients are checked
+    against the fp64 twin at B=1 and B=2 (test_configs4_resnet101_600)."""
     config, evaluator, loss, mdl, optim = Z
     flags = dict(resize_img=[hw, hw], bs=B)
     if kind == "ssd_vgg":
@@ -233,6 +238,28 @@ def _full_batch_properties(Z, arch, B, hw, kind, seed):
     print(f"{kind}/{arch} {hw}x{hw} B={B}: loss {ls['loss'].item():.5f} (oracle on the same outputs {lo['loss']:.5f}), Acc {float(em['Acc']):.3f}; "
           f"re-run: outputs differ by {d_out:.1e}, gradient by {d_g:.1e} (relative)")
     assert d_out <= 1e-4 and d_g <= 1e-4
+    if oracle_grads:
+        # the whole B-sample step against the CPU fp32 oracle (reference ssd_vgg.py:54-102 + mdl.py:338-403 + loss.py:43-143 + autograd)
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_()
+        ref = O.zsgnet_forward(sd, bt, h0, c0, arch=arch)
+        lr = O.torch_loss(ref, bt["annot"], torch.from_numpy(anc))
+        lr["loss"].backward()
+        o_cpu = torch.cat([ref["bbx_out"], ref["att_out"]], 2).detach()
+        e_out = float((ab.cpu() - o_cpu).abs().max())
+        np.testing.assert_allclose(ls["loss"].item(), lr["loss"].item(), rtol=2e-4)
+        worst_n, worst_r, n_par = 0.0, 0.0, 0
+        for n, _p in net.named_parameters():
+            gr = sd[n].grad
+            gh = net.store.view(n, gflat).cpu()          # (the FIRST step's gradients: the repeat above overwrote the live buffer)
+            nr = float(gr.norm()) + 1e-30
+            worst_n = max(worst_n, abs(float(gh.norm()) - nr) / nr)
+            worst_r = max(worst_r, rel_err(gh, gr))
+            n_par += 1
+        print(f"{kind} B={B} vs the CPU fp32 oracle: forward max abs diff {e_out:.2e}; {n_par} gradients: worst norm deviation {worst_n:.2e}, worst relative error {worst_r:.2e}")
+        assert e_out <= 2e-3 and n_par > 0
+        assert worst_n <= 1e-2 and worst_r <= 5e-3
     # eval mode is batch-independent: the first SUB images alone must reproduce their rows of the full batch
     # (zero LSTM start states: the reference hands h0 / c0 to the queries by their position in the batch's length ORDER
     #  (mdl.py:296-330), so a non-zero state ties a sample's output to the rest of the batch)
@@ -260,7 +287,7 @@ def test_configs4_resnet101_600_b32_properties(Z):
 
 def test_configs3_ssd_vgg_b32_properties(Z):
     """configs[3] at its batch: SSD-VGG16 backbone, 300x300, B=32 (ssd_vgg.py:54-102)"""
-    _full_batch_properties(Z, "ssd_vgg", 32, 300, "ssd_vgg", seed=5)
+    _full_batch_properties(Z, "ssd_vgg", 32, 300, "ssd_vgg", seed=5, oracle_grads=True)
 
 
 def test_training_trajectory_and_eval_argmax_agreement(Z):
@@ -351,7 +378,7 @@ def test_learnable_task_reaches_the_same_accuracy(Z, gold):
     at the end of one is a noisy statistic of it: five HIP runs of a 160-step version gave 232, 251, 254, 254, 255 of 256 (split-K
     tile choices and atomics change the summation order from process to process), which is why the training runs 240 steps.  What
     must agree is what the two LEARN: the same first loss, both smoothed losses below 8 % of it at the end and within 25 % of each
-    other, and Acc@IoU0.5 >= 0.95 on both sides.  (Rounds 2-3 trained the CPU oracle beside the HIP model inside the test: 8
+    other, and Acc@IoU0.5 >= 0.98 on both sides (round 5: 0.95 before; with the decayed tail both sides measure 256 / 256).  (Rounds 2-3 trained the CPU oracle beside the HIP model inside the test: 8
     minutes of the suite; measured then: HIP 253 / 256, oracle 254 / 256.)"""
     config, evaluator, loss, mdl, optim = Z
     g = gold("g15_learnable")
@@ -400,4 +427,11 @@ def test_learnable_task_reaches_the_same_accuracy(Z, gold):
             hits_h += float(ev(net(inp), inp)["Acc"]) * 16
     print(f"eval Acc@IoU0.5 on 256 held-out samples: hip {hits_h:.0f}/256, reference {ref_hits:.0f}/256")
     assert abs(last[0] - last[1]) <= 0.25 * last[1], last
-    assert hits_h >= 0.95 * 256 and ref_hits >= 0.95 * 256, (hits_h, ref_hits)
+    assert hits_h >= 0.98 * 256 and ref_hits >= 0.98 * 256, (hits_h, ref_hits)
+
+
+def test_configs0_resnet18_fpn_300_b2(Z):
+    """BASELINE configs[0]'s own workload on the HIP path (ResNet-18 FPN, bs=2, 20-token queries) at the 300x300 the config implies —
+    rounds 1-4 ran ResNet-18 at 96^2 / 600^2 only: forward, loss and every gradient against the CPU oracle and its
+    fp64 twin (fpn_resnet.py BasicBlock path, mdl.py:338-403)."""
+    _fwd_bwd_vs_fp64(Z, "resnet18", 2, 300, False, seed=3)

@@ -46,6 +46,7 @@ DP = C.POINTER(ConvDesc)
 SIGNATURES = {
     "zsg_version": (I32, []),
     "zsg_last_error": (C.c_char_p, []),
+    "zsg_source_stamp": (C.c_char_p, []),
     "zsg_set_deterministic": (I32, [I32]),
     "zsg_conv_igemm": (I32, [DP, P, P, P, P, P, P, P, P]),
     "zsg_comm_unique_id": (I32, [P]),

@@ -294,14 +294,28 @@ __global__ __launch_bounds__(256) void bn_apply_inl_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] = ss[e] = 0;
     if (c < C) {
-#pragma unroll 4
-        for (int k = rl; k < chunks; k += rowlanes) {
-            const f32x4 a = *(const f32x4*)(part + (size_t)k * 2 * C + c);
-            const f32x4 b = *(const f32x4*)(part + (size_t)k * 2 * C + C + c);
+        // every lane issues ALL its row loads of a batch (8 rows x 2 x 16 bytes) before it adds anything: one L2 round trip per batch
+        // (<= 2 batches for BN_INL_MAX rows at the >= 4 row lanes of a block) instead of one per unrolled group of four — this
+        // prologue, not the streaming body, was most of the small apply launches (11.5 us against 6.9 us for the plain apply of the
+        // same 5776 x 256 tensor, profiles/r05_fwd_listing.txt); same summation order as before
+        constexpr int U = 8;
+        for (int k0 = rl; k0 < chunks; k0 += U * rowlanes) {
+            f32x4 a[U], b[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] += (double)a[e];
-                ss[e] += (double)b[e];
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * rowlanes;
+                const int kk = k < chunks ? k : chunks - 1;
+                a[u] = *(const f32x4*)(part + (size_t)kk * 2 * C + c);
+                b[u] = *(const f32x4*)(part + (size_t)kk * 2 * C + C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = k0 + u * rowlanes < chunks;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += ok ? (double)a[u][e] : 0.0;
+                    ss[e] += ok ? (double)b[u][e] : 0.0;
+                }
             }
         }
     }

@@ -78,7 +78,10 @@ int wg_reduce_launch(const WgReduceJob& j, hipStream_t st) {
 
 // Block tile (32*TM*WM) x (32*TN*WN) computed by WM x WN waves, each TM x TN MFMA tiles of 32x32.
 // AVEC: dY rows are 16-byte addressable (out_ld % 4 == 0; a ragged channel count just reads the row's own padding).
-template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true>
+// WIDE: an image stride (src_bstride / out_bstride) does not fit mul24's 24 signed bits (an activation of >= 2^23 elements per image:
+// the stem / layer1 maps of inputs beyond ~724x724): the batch-index x image-stride products use the 32-bit multiply.  Only the
+// 64x64 tile is instantiated that way (the host maps every tile hint onto it): a correct fallback, not a tuned path.
+template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true, bool WIDE = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p
             int rem = rr - mul24(b, per);
             int y = fdiv(rem, sg.rows_x, sg.inv_rx);
             int x = rem - mul24(y, sg.rows_x);
-            const unsigned off = 4u * (unsigned)(sg.out_off + mul24(b, sg.out_bstride) +
+            const unsigned off = 4u * (unsigned)(sg.out_off + (WIDE ? b * sg.out_bstride : mul24(b, sg.out_bstride)) +
                                                   mul24(mul24(mul24(y, sg.osy) + sg.opy, sg.out_W) + (mul24(x, sg.osx) + sg.opx), p.out_ld) + na);
             if (AVEC) {
                 ra[j] = buf_load4(rs_a, (rok & a_colok) ? off : ZSG_OOB);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p
             int x = rem - mul24(y, sg.rows_x);
             const int yy = mul24(y, sg.sy) + b_dy, xx = mul24(x, sg.sx) + b_dx;
             const bool ok = rok & b_colok & ((unsigned)yy < (unsigned)sg.src_H) & ((unsigned)xx < (unsigned)sg.src_W);
-            const unsigned off = 4u * (unsigned)(sg.src_off + mul24(b, sg.src_bstride) + mul24(mul24(yy, sg.src_W) + xx, p.src_ld) + b_c);
+            const unsigned off = 4u * (unsigned)(sg.src_off + (WIDE ? b * sg.src_bstride : mul24(b, sg.src_bstride)) + mul24(mul24(yy, sg.src_W) + xx, p.src_ld) + b_c);
             rb[j] = buf_load4(rs_b, ok ? off : ZSG_OOB);
         }
         ++kt_next;
@@ -311,8 +314,11 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     p.ncols = p.ty.n * p.tx.n * d->C;
     int kt = 0;
     double rows_all = 0;
+    bool wide = false;
     const bool avec = (d->out_ld & 3) == 0;                       // else: the single scalar-load variant (64x64 tile, BK 16)
-    const int BKsel = (avec && ((d->tile_hint >> 25) & 1) && ((d->tile_hint >> 8) & 0xff) != 255) ? 32 : 16;       // tile_hint bit 25: 32-pixel K tiles
+    int BKsel = (avec && ((d->tile_hint >> 25) & 1) && ((d->tile_hint >> 8) & 0xff) != 255) ? 32 : 16;       // tile_hint bit 25: 32-pixel K tiles
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->seg[s].src_bstride >= (1 << 23) || d->seg[s].out_bstride >= (1 << 23)) BKsel = 16;       // (the wide fallback: 64x64 tile, 16-pixel K tiles)
     p.bk = BKsel;
     for (int s = 0; s < d->nseg; ++s) {
         const zsg_seg& a = d->seg[s];
@@ -323,10 +329,12 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
         ZSG_REQUIRE(a.src_off + (int64_t)d->B * a.src_bstride < (1ll << 29) && a.out_off + (int64_t)d->B * a.out_bstride < (1ll << 29),
                     "conv_wgrad: tensor exceeds 2^29 elements (2 GB window)");
         ZSG_REQUIRE((a.src_off % 4) == 0 && (a.src_bstride % 4) == 0, "conv_wgrad: seg %d source not 16-byte aligned", s);
-        // the loader multiplies with 24-bit operands (mul24, wgrad_common.h)
-        ZSG_REQUIRE(a.src_bstride < (1 << 23) && a.out_bstride < (1 << 23) && d->src_ld < (1 << 23) && d->out_ld < (1 << 23) &&
-                        (int64_t)a.src_H * a.src_W < (1 << 23) && (int64_t)(a.rows_y * a.osy + a.opy + 1) * a.out_W < (1 << 23),
-                    "conv_wgrad: seg %d: an image stride / pixel count exceeds 2^23", s);
+        // the loader multiplies with 24-bit operands (mul24, wgrad_common.h): row pitches and per-image pixel counts must fit; an image
+        // STRIDE beyond 2^23 elements (inputs larger than ~724x724 at the stem / layer1) selects the 32-bit-multiply variant below
+        ZSG_REQUIRE(d->src_ld < (1 << 23) && d->out_ld < (1 << 23) && (int64_t)a.src_H * a.src_W < (1 << 23) &&
+                        (int64_t)(a.rows_y * a.osy + a.opy + 1) * a.out_W < (1 << 23),
+                    "conv_wgrad: seg %d: a row pitch / per-image pixel count exceeds 2^23", s);
+        if (a.src_bstride >= (1 << 23) || a.out_bstride >= (1 << 23)) wide = true;
         WgSegDev& o = p.seg[s];
         o.rows_y = a.rows_y; o.rows_x = a.rows_x; o.rows = (int)rows; o.kt0 = kt;
         o.src_H = a.src_H; o.src_W = a.src_W; o.sy = a.sy; o.sx = a.sx;
@@ -352,7 +360,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
         want_splits = (d->tile_hint >> 16) & 0xff;
         w8 = ((d->tile_hint >> 24) & 1) && TM == 2 && TN == 2;      // 8-wave workgroup: 128x128 tile only
     }
-    if (!avec) { TM = 1; TN = 1; w8 = 0; }
+    if (!avec || wide) { TM = 1; TN = 1; w8 = 0; }
     p.m_tiles = cdiv(d->N, 64 * TM);
     p.n_tiles = cdiv(p.ncols, 64 * TN);
     const int nmn = p.m_tiles * p.n_tiles;
@@ -375,20 +383,24 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     const double wg_bytes = zsg_conv_alg_bytes(d, accumulate != 0);      // (dw takes the filter's place, dy the output's: same count)
     dim3 grid(nmn * p.splits);
 #define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_) WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, true)
-#define WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, AV_)                                                                          \
+#define WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, AV_) WG_LAUNCH_W(TM_, TN_, BK_, WM_, WN_, AV_, false)
+#define WG_LAUNCH_W(TM_, TN_, BK_, WM_, WN_, AV_, WD_)                                                                          \
     do {                                                                                                                   \
         const size_t lds = (size_t)2 * BK_ * ((32 * TM_ * WM_ + WG_PAD) + (32 * TN_ * WN_ + WG_PAD)) * sizeof(float);       \
         static bool attr_done[ZSG_MAX_DEV] = {};                                                                           \
         if (!attr_done[dev]) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>,                     \
+            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_, WD_>,                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
             attr_done[dev] = true;                                                                                         \
         }                                                                                                                  \
         ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, wg_bytes);                     \
-        ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_>), grid, dim3(64 * WM_ * WN_), lds, st, p);           \
+        ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_, WD_>), grid, dim3(64 * WM_ * WN_), lds, st, p);          \
     } while (0)
-    if (!avec) {                                      // dY rows not 16-byte addressable: the one scalar-load variant
+    if (wide) {                                       // an image stride >= 2^23 elements: 32-bit batch-offset multiplies
+        if (avec) WG_LAUNCH_W(1, 1, 16, 2, 2, true, true);
+        else WG_LAUNCH_W(1, 1, 16, 2, 2, false, true);
+    } else if (!avec) {                               // dY rows not 16-byte addressable: the one scalar-load variant
         WG_LAUNCH_A(1, 1, 16, 2, 2, false);
     } else if (w8) {
         if (BKsel == 32) WG_LAUNCH(2, 1, 32, 2, 4);
@@ -407,6 +419,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     }
 #undef WG_LAUNCH
 #undef WG_LAUNCH_A
+#undef WG_LAUNCH_W
     if (p.splits > 1) {
         WgReduceJob j;
         wg_reduce_job_fill(j, d, p.ws, dw, p.accumulate, p.splits);

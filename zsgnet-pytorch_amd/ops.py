@@ -551,8 +551,8 @@ SHIPPED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning
 TUNE_INFO = {"table": None, "stamp": None, "table_stamp": None, "loaded": 0, "tuned_now": 0}
 
 
-def source_stamp() -> str:
-    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp): what a tuning table / a rocprof summary was measured on"""
+def files_stamp() -> str:
+    """sha256 over the kernel sources lying next to the package (csrc/*.hip, *.h, *.cpp) — what csrc/stamp.py compiles into the library"""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -563,10 +563,19 @@ def source_stamp() -> str:
     return h.hexdigest()[:16]
 
 
+def source_stamp() -> str:
+    """The stamp of the sources the LOADED libzsg.so was built from (zsg_source_stamp(): the library may be stale against the files,
+    or another build selected with ZSG_LIB_PATH — ADVICE r04): what a tuning table / a rocprof summary was measured on."""
+    return lib.zsg_source_stamp().decode()
+
+
 def load_shipped_table(path: str = SHIPPED_TABLE) -> int:
+    """Preload the shipped tile choices — only when they were measured on the library that is loaded (its embedded source stamp) and on
+    the architecture this process drives (gfx950: the table's name); an entry that does not parse is skipped, never fatal."""
     import ast
     import json
     TUNE_INFO["stamp"] = source_stamp()
+    TUNE_INFO["files_stamp"] = files_stamp()          # != stamp: libzsg.so is stale against csrc/ (or ZSG_LIB_PATH selects another build)
     if os.environ.get("ZSG_SHIPPED_TUNE", "1") == "0" or not os.path.exists(path):
         return 0
     try:
@@ -578,21 +587,47 @@ def load_shipped_table(path: str = SHIPPED_TABLE) -> int:
         return 0
     n = 0
     for k, v in tj.get("entries", {}).items():
-        key = ast.literal_eval(k)
+        try:
+            key = ast.literal_eval(k)
+            val = int(v)
+        except Exception:
+            TUNE_INFO["bad_entries"] = TUNE_INFO.get("bad_entries", 0) + 1
+            continue
         if key not in _TUNE_CACHE:                 # (an explicit ZSG_TUNE_CACHE wins)
-            _TUNE_CACHE[key] = int(v)
+            _TUNE_CACHE[key] = val
+            _SHIPPED_KEYS.add(key)
             n += 1
     TUNE_INFO["loaded"] = n
     return n
 
 
-load_shipped_table()
+_SHIPPED_KEYS = set()
+_ARCH_CHECKED = False
+
+
+def _check_table_arch():
+    """First tuner call (the device is initialised by then — nothing here touches the GPU at import time, where a DDP rank has not
+    picked its device yet): the shipped table was measured on gfx950; on any other architecture its entries are dropped."""
+    global _ARCH_CHECKED
+    if _ARCH_CHECKED or not torch.cuda.is_available():
+        return
+    _ARCH_CHECKED = True
+    arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+    TUNE_INFO["device_arch"] = arch
+    if _SHIPPED_KEYS and "gfx950" not in arch:
+        for k in _SHIPPED_KEYS:
+            _TUNE_CACHE.pop(k, None)
+        TUNE_INFO["loaded"] = 0
+        _SHIPPED_KEYS.clear()
 
 
 def _sig(kind, d: ConvDesc, extra) -> tuple:
     segs = tuple((d.seg[i].rows_y, d.seg[i].rows_x, d.seg[i].src_H, d.seg[i].src_W, d.seg[i].sy, d.seg[i].osy,
                   d.seg[i].ty.n, d.seg[i].tx.n) for i in range(d.nseg))
     return (kind, d.B, d.C, d.N, d.src_ld, d.out_ld, d.wR, d.wC, d.wt_ld, d.relu, d.merge_x, segs, extra)
+
+
+load_shipped_table()
 
 
 def _time_launch(fn, args, stream, reps=6):
@@ -727,6 +762,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         return d.tile_hint | WINO_FLAG
     if no_tune:
         return 0
+    _check_table_arch()
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
                          mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
