@@ -138,6 +138,34 @@ int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, const float* wt
  * zsg_conv_igemm_partial_rows: rows of bn_partials / partials a zsg_conv_igemm / zsg_conv_igemm_bnb launch with this
  * descriptor (and its tile_hint) writes; -1 when the hint is 0 (heuristic) or the streaming kernel does not cover the geometry. */
 int32_t zsg_conv_igemm_partial_rows(const zsg_conv_desc* d);
+
+/* ---- BatchNorm statistics finalised INSIDE the producing convolution (round 5; csrc/bn_tail.h) -----------------------------------
+ * The tiles of one column block (BN output channels) take a ticket after writing their partial row; the tile that draws the last
+ * ticket reduces the column block's rows in a fixed order in fp64 (deterministic) and publishes the result, so no finalize launch
+ * (zsg_bn_stats_from_partials / the finalize half of zsg_bn_backward_from_partials) and no re-reduction in the apply pass remain on
+ * the conv -> BatchNorm -> conv chain (fpn_resnet.py:80-100 forward; its autograd backward).
+ * zsg_conv_bn_tail_tickets: the number of 32-bit ticket words the launch selected by d->tile_hint needs (its column blocks), or -1
+ * when that launch cannot finalise in-kernel (no hint, the streaming 1x1 kernel, split_k > 1, merge_x, or more than 128 partial rows
+ * per column block) — the caller then keeps the separate finalize.  is_wino != 0: the hint is zsg_conv_wino's.
+ * tickets must be ZERO at entry and are zero again when the launch ends (the caller allocates them zeroed once; one set per call
+ * site, never shared between launches that may be in flight together). */
+int32_t zsg_conv_bn_tail_tickets(const zsg_conv_desc* d, int32_t is_wino);
+/* zsg_conv_igemm / zsg_conv_wino with bn_partials (plain, bias-free convolution feeding a train-mode BatchNorm, fpn_resnet.py:86-97)
+ * + in-kernel finalize: mean / invstd (and running statistics, momentum as torch.nn.BatchNorm2d; NULL to skip) are valid when the
+ * launch ends; zsg_bn_apply follows directly. */
+int zsg_conv_igemm_bnstat(const zsg_conv_desc* d, const float* src, const float* wt, float* out, float* partials, uint32_t* tickets,
+                          float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps, void* stream);
+int zsg_conv_wino_bnstat(const zsg_conv_desc* d, const float* src, const float* U, float* out, float* partials, uint32_t* tickets,
+                         float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* zsg_conv_igemm_bnb / zsg_conv_wino_bnb + in-kernel finalize of the BatchNorm BACKWARD sums: coef[0][c] = sum g / n,
+ * coef[1][c] = sum g * xhat / n (coef: 2*N floats), d(gamma) = sum g * xhat and d(beta) = sum g written (accumulate == 0) or added;
+ * zsg_bn_bwd_apply is all that remains of the BatchNorm's backward. */
+int zsg_conv_igemm_bnb_tail(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* add_src,
+                            const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                            float* partials, uint32_t* tickets, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
+int zsg_conv_wino_bnb_tail(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* add_src,
+                           const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                           float* partials, uint32_t* tickets, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
 int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* add_src,
                       const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
                       float* partials, void* stream);
@@ -161,7 +189,8 @@ int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* d
 int zsg_transpose_w(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t dst_ld, void* stream);
 /* All dgrad weight images of a step in ONE launch.  jobs: device array of
  * {int64 src_off, dst_off; int32 N, T, C, dst_ld, tile0, tiles_c, tiles_n, pad} (offsets in elements from the bases;
- * tiles_c = ceil(C/32), tiles_n = ceil(dst_ld/32), tile0 = running sum of T*tiles_c*tiles_n). */
+ * tiles_c = ceil(C/64), tiles_n = ceil(dst_ld/64), tile0 = running sum of T*tiles_c*tiles_n; round 5: 64 x 64 tiles moved with
+ * 16-byte accesses — C, dst_ld and both offsets multiples of 4, bases 16-byte aligned). */
 int zsg_transpose_w_batched(const float* src_base, float* dst_base, const void* jobs, int32_t njobs, int32_t total_tiles,
                             void* stream);
 /* dst[r][0:dst_ld] = [ src[r*src_ld + 0:C] | 0 ... ] */
@@ -223,6 +252,10 @@ int zsg_bn_apply(const float* x, int64_t rows, int32_t C, const float* mean, con
 int zsg_bn_backward(const float* dout, const float* relu_out, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,
                     const float* mean, const float* invstd, const float* gamma, float* dx, float* g_out,
                     float* dgamma, float* dbeta, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The apply pass alone: dx = gamma*invstd*(g - coef[0] - xhat*coef[1]), g = dout * relu-bit, optional g_out = g; coef (2*C floats)
+ * as finalised by zsg_conv_igemm_bnb_tail / zsg_conv_wino_bnb_tail (native_batch_norm_backward's input-gradient formula). */
+int zsg_bn_bwd_apply(const float* dout, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C, const float* mean,
+                     const float* invstd, const float* gamma, const float* coef, float* dx, float* g_out, void* stream);
 /* The same from the partial rows [chunks][2][C] of zsg_conv_igemm_bnb / zsg_conv_wino_bnb (finalize + apply: one pass over
  * dout and x instead of two).  ws: >= 2*C floats. */
 int zsg_bn_backward_from_partials(const float* dout, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C,

@@ -138,4 +138,47 @@ def test_dgrad_with_bn_backward_sums(Z, case):
     dx_ref = gamma.double() * invstd.double() * (gref - dbeta_ref / n - xhat * dgamma_ref / n)
     assert float((outs[1][0].double() - dx_ref).abs().max()) < 3e-4 * float(dx_ref.abs().max())
     assert float((outs[1][2].double() - 1 - dgamma_ref).abs().max()) < 1e-4 * sc2 + 1e-5
+
+    # round 5: the same with the sums FINALISED inside the data-gradient launch by the last-arriving tile of each column block
+    # (zsg_conv_*_bnb_tail + zsg_bn_bwd_apply, csrc/bn_tail.h) — where the launch has <= 128 partial rows per column block
+    nt = int(L.lib.zsg_conv_bn_tail_tickets(C.byref(d1), 1 if kern == "wino" else 0))
+    if kern != "wino" and hint3[0] == 32:
+        assert nt == -1, "the streaming 1x1 kernel has no in-kernel finalize"
+    if nt <= 0:
+        assert chunks > 128 or (kern != "wino" and hint3[0] == 32)
+        return
+    fn_tail = L.lib.zsg_conv_wino_bnb_tail if kern == "wino" else L.lib.zsg_conv_igemm_bnb_tail
+    tickets = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    noise = torch.empty(64 << 20, device="cuda")
+    for rep in range(4):
+        dx2 = fresh()
+        d2 = ops.dgrad_desc(dyv, view_of(ops, dx2, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)
+        part2 = torch.full((chunks, 2, Ci), float("nan"), device="cuda")
+        coef = torch.full((2, Ci), float("nan"), device="cuda")
+        dga, dbe = torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda")
+        torch.cuda.synchronize()
+        if rep >= 2:                       # uneven load: an HBM-bound kernel on another stream while the tiles arrive
+            L.check(L.lib.zsg_memset_f32(noise.data_ptr(), noise.numel(), float(rep), C.c_void_p(side.cuda_stream)), "noise")
+        L.check(fn_tail(C.byref(d2), dyd.data_ptr(), wop.data_ptr(), dx2.data_ptr(), dx2.data_ptr() if acc else None, xd.data_ptr(), md.data_ptr(),
+                        isd.data_ptr(), maskb.data_ptr() if use_mask else None, part2.data_ptr(), tickets.data_ptr(), coef.data_ptr(),
+                        dga.data_ptr(), dbe.data_ptr(), 1, st), "dgrad + bn-backward sums + in-kernel finalize")
+        dxo, go = torch.empty(B, H, W, Ci, device="cuda"), torch.empty(B, H, W, Ci, device="cuda")
+        L.check(L.lib.zsg_bn_bwd_apply(dx2.data_ptr(), maskb.data_ptr() if use_mask else None, xd.data_ptr(), rows, Ci, md.data_ptr(), isd.data_ptr(),
+                                       gd.data_ptr(), coef.data_ptr(), dxo.data_ptr(), go.data_ptr(), st), "bn_bwd_apply")
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0, "tickets must be zero again after the launch"
+        assert torch.equal(dx2, dx1) and torch.equal(part2, part), "same stored values and partial rows as the launch without the finalize"
+        c_ref = torch.stack([part[:, 0].double().sum(0), part[:, 1].double().sum(0)]) / n
+        sc = float(c_ref.abs().max()) + 1e-30
+        assert float((coef.double() - c_ref).abs().max()) <= 3e-7 * sc, "coefficients = fp64 sum of the partial rows, rounded once"
+        assert torch.allclose(dga.cpu(), (1 + part[:, 1].double().sum(0).float()).cpu(), rtol=1e-6, atol=1e-6 * sc * n)
+        assert torch.allclose(dbe.cpu(), (1 + part[:, 0].double().sum(0).float()).cpu(), rtol=1e-6, atol=1e-6 * sc * n)
+        if rep == 0:
+            first = (coef.clone(), dga.clone(), dbe.clone(), dxo.clone())
+        else:
+            assert all(torch.equal(a_, b_) for a_, b_ in zip((coef, dga, dbe, dxo), first)), "run-to-run bit-identical (fixed reduction order)"
+        for a, b_, what in zip((dxo.cpu(), go.cpu()), outs[1][:2], ("dx", "g_out")):
+            assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5 * float(b_.abs().max())), what
+    side.synchronize()
     assert float((outs[1][3].double() - 1 - dbeta_ref).abs().max()) < 1e-4 * sc1 + 1e-5

@@ -252,6 +252,8 @@ def _full_batch_properties(Z, arch, B, hw, kind, seed, oracle_grads=False):
         worst_n, worst_r, n_par = 0.0, 0.0, 0
         for n, _p in net.named_parameters():
             gr = sd[n].grad
+            if gr is None:                               # (a parameter the SSD path does not use)
+                continue
             gh = net.store.view(n, gflat).cpu()          # (the FIRST step's gradients: the repeat above overwrote the live buffer)
             nr = float(gr.norm()) + 1e-30
             worst_n = max(worst_n, abs(float(gh.norm()) - nr) / nr)

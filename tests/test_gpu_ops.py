@@ -820,6 +820,30 @@ def test_wgrad_256_column_tile(Z, case):
     assert_close(dw[..., :Ci].permute(0, 3, 1, 2), ref, 5e-4, 5e-4 * float(ref.abs().max()), "wgrad, 256-column tile")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 16, 520, 520, 3, 1, 1, (128, 128, 24)), (2, 8, 32, 520, 520, 1, 1, 0, (64, 64, 64)), (2, 32, 16, 520, 520, 3, 1, 1, (0, 0, 0))],
+                         ids=["src_wide", "dy_wide", "heuristic"])
+def test_wgrad_image_stride_beyond_2p23(Z, case):
+    """zsg_conv_wgrad on activations of more than 2^23 elements PER IMAGE (the stem / layer1 maps of inputs beyond ~724x724; here 32 x
+    520 x 520): the loader's 24-bit multiplies cannot form batch-index x image-stride, the library falls back to its 32-bit-multiply
+    variant of the 64x64 tile whatever tile the hint names (round 4 refused the launch; the reference accepts any resize_img,
+    dat_loader.py:121) — vs torch's weight gradient."""
+    L, ops = Z
+    B, Ci, Co, H, W, k, s, p, (bm, bn, splits) = case
+    g = torch.Generator().manual_seed(11 + Ci)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    Ho, Wo = ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p)
+    gy = torch.randn(B, Co, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, k, k), gy, stride=s, padding=p)
+    cp, Cop = pad4(Ci), pad4(Co)
+    assert max(cp * H * W, Cop * Ho * Wo) >= (1 << 23)
+    xd, dyd = dev(nhwc(x)), dev(nhwc(gy, Cop))
+    src, dyv = view_of(ops, xd, B, H, W, cp), view_of(ops, dyd, B, Ho, Wo, Cop)
+    d = ops.fwd_desc(src, dyv, cp, Co, k, s, p, 1, wC=cp, tile_hint=ops.tile_hint(bm, bn, splits) if bm else 0)
+    dw = torch.zeros(Co, k, k, cp, device="cuda")
+    L.check(L.lib.zsg_conv_wgrad(C.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), 0, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad wide")
+    assert_close(dw[..., :Ci].permute(0, 3, 1, 2), ref, 1e-3, 1e-3 * float(ref.abs().max()), "wgrad, image stride >= 2^23")
+
+
 def test_completion_event_orders_another_stream(Z):
     """zsg_set_completion_event / zsg_stream_wait_event (include/zsg.h): a launch on stream A carries the armed event as its completion
     signal and stream B, made to wait for it, sees everything that launch wrote — without a marker in A's queue.  Also: the disarming

@@ -8,7 +8,7 @@ The fp32 CPU oracle (= the reference's arithmetic) runs the benchmark shape (Res
   f4     : the same layers by F(4x4,3x3) on the levels with >= 16 rows (38^2, 19^2), F(2x2,3x3) on the small ones
 and prints max |out - golden| over the golden's sampled anchors.  The emulation rounds every transform and the channel sum to fp32
 (the channel sum through torch's fp32 GEMM: blocked order, same error class as the MFMA K loop).
-usage: python tools/wino_f4_e2e.py [points]     points: std (0,+-1,+-2; default) | mix (0,1,-1,1/2,-2)"""
+usage: python tools/wino_f4_e2e.py [points] [enc]     points: std (0,+-1,+-2; default) | mix (0,1,-1,1/2,-2); enc: also layer1's conv2"""
 import os
 import sys
 
@@ -80,7 +80,8 @@ def main():
     h0, c0 = torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"])
     head_w = {id(v) for k, v in sd.items() if k.startswith("att_reg_box") and k.endswith("weight")}
     fpn_w = {id(v) for k, v in sd.items() if k.startswith("backbone.fpn.P") and k.endswith("_2.weight")}
-    MODE["hit"] = lambda w: (id(w) in head_w) or (id(w) in fpn_w)
+    enc_w = {id(v) for k, v in sd.items() if k.startswith("backbone.encoder.layer1.") and k.endswith("conv2.weight")} if "enc" in sys.argv else set()
+    MODE["hit"] = lambda w: (id(w) in head_w) or (id(w) in fpn_w) or (id(w) in enc_w)
     O.F.conv2d = patched
     res = {}
     with torch.no_grad():

@@ -60,6 +60,12 @@ SIGNATURES = {
     "zsg_bn_relu_maxpool_bwd": (I32, [P, P, P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, I32, P, SZ, P]),
     "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_conv_igemm_partial_rows": (I32, [DP]),
+    "zsg_conv_bn_tail_tickets": (I32, [DP, I32]),
+    "zsg_conv_igemm_bnstat": (I32, [DP, P, P, P, P, P, P, P, P, P, F32, F32, P]),
+    "zsg_conv_wino_bnstat": (I32, [DP, P, P, P, P, P, P, P, P, P, F32, F32, P]),
+    "zsg_conv_igemm_bnb_tail": (I32, [DP, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P]),
+    "zsg_conv_wino_bnb_tail": (I32, [DP, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P]),
+    "zsg_bn_bwd_apply": (I32, [P, P, P, I64, I32, P, P, P, P, P, P, P]),
     "zsg_conv_wino_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_bn_backward_from_partials": (I32, [P, P, P, I64, I32, P, P, P, P, P, P, P, I32, P, I32, P, SZ, P]),
     "zsg_wino_u_elems": (I64, [I32, I32]),

@@ -1,6 +1,8 @@
 // bn.hip — train-mode BatchNorm2d over NHWC [rows][C] (+ ReLU, + residual), forward and backward.  HBM-bound.
 // Each thread owns 4 consecutive channels (16-byte loads); a block spans up to 256 channels x a chunk of rows.
 // Statistics: per-chunk fp32 partial (sum, sum of squares) -> a finalize kernel merges them in fp64.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct BnGeom {
@@ -93,22 +95,27 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // launches sit on the step's dependent chain.
 #define BN_FW 4                       // waves per block
 #define BN_FU 3                       // rows in flight per lane
+// FW: waves per block.  BN_FW (4) everywhere but for thousands of partial rows (the stem's 5625 at the bench shape: 19.9 us with 4
+// waves — eight dependent memory round trips per lane — against ~7 us with 16 waves and two).
+#define BN_FW_MANY 16
+#define BN_MANY_ROWS 1536
+template <int FW>
 __device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int chunks, int C, int c, double& se, double& sse) {
-    __shared__ double red[BN_FW][8];
+    __shared__ double red[FW][8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = t; k0 < chunks; k0 += 64 * BN_FW * BN_FU) {
+    for (int k0 = t; k0 < chunks; k0 += 64 * FW * BN_FU) {
         f32x4 a[BN_FU], b[BN_FU];
 #pragma unroll
         for (int u = 0; u < BN_FU; ++u) {
-            const int k = k0 + u * 64 * BN_FW;
+            const int k = k0 + u * 64 * FW;
             const int kk = k < chunks ? k : chunks - 1;
             a[u] = *(const f32x4*)(part + (size_t)kk * 2 * C + c);
             b[u] = *(const f32x4*)(part + (size_t)kk * 2 * C + C + c);
         }
 #pragma unroll
         for (int u = 0; u < BN_FU; ++u) {
-            const bool ok = k0 + u * 64 * BN_FW < chunks;
+            const bool ok = k0 + u * 64 * FW < chunks;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] += ok ? (double)a[u][e] : 0.0;
@@ -148,19 +155,20 @@ __device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ par
     se = sse = 0;
     if (t < 4) {
 #pragma unroll
-        for (int w = 0; w < BN_FW; ++w) {
+        for (int w = 0; w < FW; ++w) {
             se += red[w][t];
             sse += red[w][4 + t];
         }
     }
 }
 
-__global__ __launch_bounds__(64 * BN_FW) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
-                                                                       float* mean, float* invstd, float* rmean, float* rvar,
-                                                                       float momentum, float eps) {
+template <int FW>
+__global__ __launch_bounds__(64 * FW) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
+                                                                    float* mean, float* invstd, float* rmean, float* rvar,
+                                                                    float momentum, float eps) {
     const int c = blockIdx.x * 4;
     double se, sse;
-    bn_reduce_partials(part, chunks, C, c, se, sse);
+    bn_reduce_partials<FW>(part, chunks, C, c, se, sse);
     const int e = threadIdx.x;
     if (e >= 4) return;                            // threads 0..3 write one channel each
     const double n = (double)rows;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(64 * BN_FW) void bn_bwd_finalize_kernel(const float
                                                                      float* coef, float* dgamma, float* dbeta, int accumulate) {
     const int c = blockIdx.x * 4;
     double se, sse;
-    bn_reduce_partials(part, chunks, C, c, se, sse);
+    bn_reduce_partials<BN_FW>(part, chunks, C, c, se, sse);
     const int e = threadIdx.x;
     if (e >= 4) return;
     coef[c + e] = (float)(se / (double)rows);
@@ -369,14 +377,24 @@ __global__ __launch_bounds__(256) void bn_apply_inl_kernel(const float* __restri
     }
 }
 
-extern "C" int32_t zsg_bn_inline_max_chunks(void) { return BN_INL_MAX; }
+// (ZSG_BN_INL_MAX overrides the threshold for A/B measurements; the kernel itself handles any row count)
+static int bn_inl_max() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ZSG_BN_INL_MAX");
+        v = (e && atoi(e) > 0) ? atoi(e) : BN_INL_MAX;
+        if (v > 1024) v = 1024;
+    }
+    return v;
+}
+extern "C" int32_t zsg_bn_inline_max_chunks(void) { return bn_inl_max(); }
 
 extern "C" int zsg_bn_apply_from_partials(const float* x, int64_t rows, int32_t C, const float* partials, int32_t chunks, const float* gamma,
                                           const float* beta, const float* residual, int32_t relu, float* out, uint8_t* relu_mask,
                                           float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
                                           float eps, void* stream) {
-    ZSG_REQUIRE(x && partials && gamma && beta && out && mean && invstd && rows > 0 && C > 0 && (C % 4) == 0 && chunks > 0 && chunks <= BN_INL_MAX,
-                "bn_apply_from_partials: bad argument (chunks=%d, at most %d)", chunks, BN_INL_MAX);
+    ZSG_REQUIRE(x && partials && gamma && beta && out && mean && invstd && rows > 0 && C > 0 && (C % 4) == 0 && chunks > 0 && chunks <= bn_inl_max(),
+                "bn_apply_from_partials: bad argument (chunks=%d, at most %d)", chunks, bn_inl_max());
     BnGeom g = bn_geom(rows, C);
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_apply", st, 0, (double)rows * C * (4 * (residual ? 3 : 2) + (relu_mask && relu ? 0.25 : 0)));
@@ -396,8 +414,12 @@ extern "C" int zsg_bn_stats(const float* x, int64_t rows, int32_t C, float* mean
     float* part = (float*)ws;
     ZSG_LAUNCH((bn_partial_kernel<0>), dim3(g.chunks, g.slabs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, C, g.lanes, g.rpb, part);
-    ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
-                       running_mean, running_var, momentum, eps);
+    if (g.chunks > BN_MANY_ROWS)
+        ZSG_LAUNCH(bn_stats_finalize_kernel<BN_FW_MANY>, dim3(C / 4), dim3(64 * BN_FW_MANY), 0, st, part, g.chunks, C, rows, mean, invstd,
+                           running_mean, running_var, momentum, eps);
+    else
+        ZSG_LAUNCH(bn_stats_finalize_kernel<BN_FW>, dim3(C / 4), dim3(64 * BN_FW), 0, st, part, g.chunks, C, rows, mean, invstd,
+                           running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats");
     return 0;
 }
@@ -408,8 +430,12 @@ extern "C" int zsg_bn_stats_from_partials(const float* partials, int32_t chunks,
     ZSG_REQUIRE(partials && mean && invstd && chunks > 0 && rows > 0 && C > 0 && (C % 4) == 0, "bn_stats_from_partials: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("bn_stats", st, 0, (double)chunks * C * 8);
-    ZSG_LAUNCH(bn_stats_finalize_kernel, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
-                       running_mean, running_var, momentum, eps);
+    if (chunks > BN_MANY_ROWS)
+        ZSG_LAUNCH(bn_stats_finalize_kernel<BN_FW_MANY>, dim3(C / 4), dim3(64 * BN_FW_MANY), 0, st, partials, chunks, C, rows, mean, invstd,
+                           running_mean, running_var, momentum, eps);
+    else
+        ZSG_LAUNCH(bn_stats_finalize_kernel<BN_FW>, dim3(C / 4), dim3(64 * BN_FW), 0, st, partials, chunks, C, rows, mean, invstd,
+                           running_mean, running_var, momentum, eps);
     ZSG_CHECK_LAUNCH("bn_stats_from_partials");
     return 0;
 }
@@ -676,6 +702,22 @@ extern "C" int zsg_bn_backward_from_partials(const float* dout, const uint8_t* r
     ZSG_LAUNCH(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, (const float*)nullptr, relu_mask, x, rows, C, mean,
                        invstd, gamma, coef, dx, g_out, g.lanes, g.rpb);
     ZSG_CHECK_LAUNCH("bn_backward_from_partials");
+    return 0;
+}
+
+// The apply pass of the BatchNorm backward on its own: the coefficients (coef[0][c] = sum g / n, coef[1][c] = sum g xhat / n) and
+// d(gamma) / d(beta) were finalised inside the data-gradient convolution that completed dout (zsg_conv_igemm_bnb_tail /
+// zsg_conv_wino_bnb_tail).  dx = gamma * invstd * (g - coef0 - xhat * coef1), g = dout * relu-bit; g_out (optional) receives g (the
+// residual branch's gradient).  Reference: native_batch_norm_backward's input-gradient formula.
+extern "C" int zsg_bn_bwd_apply(const float* dout, const uint8_t* relu_mask, const float* x, int64_t rows, int32_t C, const float* mean,
+                                const float* invstd, const float* gamma, const float* coef, float* dx, float* g_out, void* stream) {
+    ZSG_REQUIRE(dout && x && mean && invstd && gamma && coef && dx && rows > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad argument");
+    BnGeom g = bn_geom(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("bn_backward", st, 0, (double)rows * C * (4 * (2 + 1 + (g_out ? 1 : 0)) + (relu_mask ? 0.25 : 0)));
+    ZSG_LAUNCH(bn_bwd_apply_kernel, dim3(g.chunks, g.slabs), dim3(256), 0, st, dout, (const float*)nullptr, relu_mask, x, rows, C, mean,
+                       invstd, gamma, coef, dx, g_out, g.lanes, g.rpb);
+    ZSG_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bn_tail.h"
 
 #define IG_BK 32
 // IG_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong; 32 = no output stores in the plain
@@ -49,6 +50,7 @@ struct IgParams {
     double alg_bytes; // host only: algorithmic HBM bytes of the launch (profile)
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
+    BnTail tail;      // tail.tickets != nullptr: the last-arriving tile of a column block finalises the statistics (bn_tail.h)
     IgSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     }
 
     // ---- fused BatchNorm statistics: per-column (sum, sum^2) over this tile's rows (dead rows hold exact zeros) -----
+    const bool tail_on = p.tail.tickets != nullptr;       // (host: only with the vectorised epilogue, unsplit)
     if (p.stats && !p.bnb.x) {
         float* red = smem;                            // [2][WM][BN] — the K-loop tiles are no longer needed
 #pragma unroll
@@ -369,8 +372,13 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
                 s2 += red[(WM + w) * BN + tid];
             }
             float* o = p.stats + (size_t)mt * 2 * p.N;
-            o[n0 + tid] = s1;
-            o[p.N + n0 + tid] = s2;
+            if (tail_on) {                            // write-through: another CU's workgroup reduces the rows inside this launch
+                bn_tail_store(o + n0 + tid, s1);
+                bn_tail_store(o + p.N + n0 + tid, s2);
+            } else {
+                o[n0 + tid] = s1;
+                o[p.N + n0 + tid] = s2;
+            }
         }
     }
 
@@ -428,15 +436,17 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
                 is = *(const f32x4*)(p.bnb.invstd + n);
             }
             if (bnb) {                                // (bias / ReLU / float mask are excluded by the host for this mode)
+                // pass 1: the values this thread will store (kept in apre[]) and their share of the two sums; the stores themselves
+                // follow the partial row and the ticket (pass 2), so the ticket's round trip hides under them
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const int row = rr + RPP * i;
                     const int ro = rowout[row];
+                    mpre[i] = ro < 0 ? 0u : (mpre[i] | 0x100u);      // bit 8: this row is stored
                     if (ro < 0) continue;
-                    const size_t o = (size_t)ro + n;
                     f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
                     if (p.add_src) v += apre[i];
-                    *(f32x4*)(p.out + o) = v;
+                    apre[i] = v;
                     f32x4 g = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = ((mpre[i] >> e) & 1u) ? g[e] : 0.f;
@@ -478,8 +488,29 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
                     a2 += red[(RPP + r) * BN + tid];
                 }
                 float* o = p.stats + (size_t)mt * 2 * p.N;
-                o[n0 + tid] = a1;
-                o[p.N + n0 + tid] = a2;
+                if (tail_on) {
+                    bn_tail_store(o + n0 + tid, a1);
+                    bn_tail_store(o + p.N + n0 + tid, a2);
+                } else {
+                    o[n0 + tid] = a1;
+                    o[p.N + n0 + tid] = a2;
+                }
+            }
+            // pass 2: the output stores
+            if (n < p.N) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if (mpre[i] & 0x100u) *(f32x4*)(p.out + (size_t)rowout[rr + RPP * i] + n) = apre[i];
+            }
+        }
+        if (tail_on) {
+            // in-kernel BatchNorm finalize (bn_tail.h): the storing waves of every tile but the column block's last row tile drain and
+            // fire their arrival; the last row tile's workgroup waits for them, reduces the rows and publishes the statistics
+            if (mt != p.m_tiles - 1) {
+                if (tid < BN) bn_tail_arrive(p.tail.tickets + nt);
+            } else {
+                __syncthreads();                      // smem (ct / red) is free
+                bn_tail_reduce<NT, BN>(p.tail, p.tail.tickets + nt, p.stats, p.m_tiles, p.N, n0, (double*)smem);
             }
         }
         return;
@@ -625,7 +656,8 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int
 }
 
 static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
-                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
+                           const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
+                           const BnTail* tail = nullptr) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
     int BM = 64, BN = 64, splits = 1, w8 = 0;
     pick_tile(d, &BM, &BN, &splits, &w8);
@@ -633,6 +665,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     if (d->merge_x) w8 = 0;
     if (BM == 32) {                               // the filter-resident streaming kernel of the 1x1 layers (pw.hip); BN = unit width
         ZSG_REQUIRE(splits <= 1, "conv_igemm: the streaming 1x1 kernel has no split-K variant");
+        ZSG_REQUIRE(!tail, "conv_igemm: the streaming 1x1 kernel has no in-kernel BatchNorm finalize (zsg_conv_bn_tail_tickets says so)");
         return zsg_conv_pw_launch(d, BN, src, wt, out, bias, add_src, mask_src, bn_partials, bnb, (hipStream_t)stream);
     }
     IgParams p;
@@ -661,6 +694,16 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
         p.bnb = *bnb;
     } else if (bn_partials) {
         ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu, "conv_igemm: BN-statistics fusion needs a plain (bias-free, unsplit) convolution");
+    }
+    if (tail) {
+        ZSG_REQUIRE(tail->tickets && bn_partials && splits == 1 && p.vec && !d->merge_x && p.m_tiles <= BN_TAIL_MAX_ROWS,
+                    "conv_igemm: in-kernel BatchNorm finalize needs fused partials, the vectorised epilogue and at most %d row tiles (%d)",
+                    BN_TAIL_MAX_ROWS, p.m_tiles);
+        ZSG_REQUIRE((((uintptr_t)bn_partials) & 15) == 0 && (d->N % 4) == 0, "conv_igemm: partial rows not 16-byte aligned");
+        p.tail = *tail;
+        int64_t rows = 0;
+        for (int s = 0; s < d->nseg; ++s) rows += (int64_t)d->B * d->seg[s].rows_y * d->seg[s].rows_x;
+        p.tail.rows = rows;
     }
     hipStream_t st = (hipStream_t)stream;
     if (splits > 1) {
@@ -703,5 +746,53 @@ extern "C" int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, cons
                                   float* partials, void* stream) {
     BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
     return conv_igemm_impl(d, src, wt, out, nullptr, add_src, nullptr, partials, &b, stream);
+}
+
+// ---- in-kernel BatchNorm finalize (bn_tail.h) ---------------------------------------------------------------------------------
+// Column blocks (= ticket words) of the launch this descriptor + tile hint selects, or -1 when that launch cannot finalise the
+// statistics itself: no tile hint, the streaming 1x1 kernel, split-K, merge_x, or more than BN_TAIL_MAX_ROWS partial rows per column
+// block.  is_wino: the hint is zsg_conv_wino's.
+extern "C" int32_t zsg_conv_bn_tail_tickets(const zsg_conv_desc* d, int32_t is_wino) {
+    if (!d || !d->tile_hint || ((d->tile_hint >> 16) & 0xff) > 1 || d->merge_x) return -1;
+    const int bm = d->tile_hint & 0xff, bn = (d->tile_hint >> 8) & 0xff;
+    if (bm <= 0 || bn <= 0) return -1;
+    int64_t t = 0;
+    if (is_wino) {
+        if (!((bm == 32 || bm == 64) && (bn == 32 || bn == 64))) return -1;
+        for (int s = 0; s < d->nseg; ++s) t += cdiv((int64_t)d->B * ((d->seg[s].src_H + 1) / 2) * ((d->seg[s].src_W + 1) / 2), bm);
+    } else {
+        if (bm == 32 || !((bm == 64 && bn == 64) || (bm == 128 && (bn == 64 || bn == 128)))) return -1;
+        for (int s = 0; s < d->nseg; ++s) t += cdiv((int64_t)d->B * d->seg[s].rows_y * d->seg[s].rows_x, bm);
+    }
+    if (t > BN_TAIL_MAX_ROWS) return -1;
+    return cdiv(d->N, bn);
+}
+
+// zsg_conv_igemm with bn_partials whose LAST tile per column block also finalises the BatchNorm statistics: mean / invstd (and the
+// running statistics, momentum as torch) are ready when the launch ends — no zsg_bn_stats_from_partials launch, no re-reduction in the
+// apply pass.  tickets: zsg_conv_bn_tail_tickets(d, 0) zeroed 32-bit words, left zero.  Reference: nn.BatchNorm2d in training mode
+// behind the convolutions of fpn_resnet.py:80-100 (F.batch_norm's statistics pass).
+extern "C" int zsg_conv_igemm_bnstat(const zsg_conv_desc* d, const float* src, const float* wt, float* out, float* partials, uint32_t* tickets,
+                                     float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+    ZSG_REQUIRE(tickets && mean && invstd && partials, "conv_igemm_bnstat: null argument");
+    BnTail t;
+    memset(&t, 0, sizeof(t));
+    t.tickets = tickets; t.mean = mean; t.invstd = invstd; t.rmean = running_mean; t.rvar = running_var; t.momentum = momentum; t.eps = eps; t.mode = 0;
+    return conv_igemm_impl(d, src, wt, out, nullptr, nullptr, nullptr, partials, nullptr, stream, &t);
+}
+
+// zsg_conv_igemm_bnb whose last tile per column block also finalises the BatchNorm BACKWARD sums: coef[0][c] = sum g / n,
+// coef[1][c] = sum g xhat / n, d(gamma) / d(beta) written or accumulated — zsg_bn_bwd_apply is all that is left of the BatchNorm's
+// backward.  Reference: autograd's native_batch_norm_backward behind the convolution's backward (utils.py:412).
+extern "C" int zsg_conv_igemm_bnb_tail(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* add_src,
+                                       const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                                       float* partials, uint32_t* tickets, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
+                                       void* stream) {
+    ZSG_REQUIRE(tickets && coef && partials, "conv_igemm_bnb_tail: null argument");
+    BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
+    BnTail t;
+    memset(&t, 0, sizeof(t));
+    t.tickets = tickets; t.coef = coef; t.dgamma = dgamma; t.dbeta = dbeta; t.accumulate = accumulate ? 1 : 0; t.mode = 1;
+    return conv_igemm_impl(d, src, wt, out, nullptr, add_src, nullptr, partials, &b, stream, &t);
 }
 

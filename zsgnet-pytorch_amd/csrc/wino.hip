@@ -22,6 +22,7 @@
 // bit 3 of the row index, which makes the ds_read_b128 fragment reads (lane = row, half = k-group) conflict-free without
 // padding.  K permutation as in igemm.hip: value e of a lane's b128 feeds the e-th of four MFMAs.
 #include "common.h"
+#include "bn_tail.h"
 
 #define WN_CK 8
 // WN_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong): 1 = every patch load of a lane hits
@@ -47,6 +48,7 @@ struct WnParams {
     const float* mask_src;
     float* stats;        // optional BatchNorm partials [m_blocks][2][N]
     BnbDev bnb;          // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (common.h)
+    BnTail tail;         // tail.tickets != nullptr: the last-arriving block of a column block finalises the statistics (bn_tail.h)
     int C, N, Npad, src_ld, out_ld, relu, nseg;
     int m_blocks, n_blocks, splits, chunks, vec, add_is_out;
     double alg_bytes;    // host only: algorithmic HBM bytes of the launch (profile)
@@ -371,6 +373,8 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
         const int n = n0 + 4 * cg;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         const bool bnb = p.bnb.x != nullptr;
+        const bool tail_on = p.tail.tickets != nullptr;      // (host: only with this vectorised epilogue, unsplit)
+        static_assert(E_NR == TB * 4 / RPP && E_CG == CG, "one row schedule for the prefetch and both epilogue passes");
         if (n < p.N) {
             f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *(const f32x4*)(p.bias + n);
@@ -379,21 +383,40 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
                 is = *(const f32x4*)(p.bnb.invstd + n);
             }
             if (bnb) {                                // (bias / ReLU / float mask are excluded by the host for this mode)
+                // pass 1: the values this thread will store (kept in apre[]) and their share of the two sums; the stores follow the
+                // partial row and the ticket (pass 2)
 #pragma unroll
                 for (int i = 0; i < E_NR; ++i) {
                     const int row = rr + RPP * i;
                     const int tl = row >> 2, px = row & 3;
                     const int ro = rowinfo[2 * tl], fl = rowinfo[2 * tl + 1];
-                    if (ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2))) continue;
-                    const size_t o = (size_t)(ro + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
+                    const bool dead = ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2));
+                    mpre[i] = dead ? 0u : (mpre[i] | 0x100u);        // bit 8: this row is stored
+                    if (dead) continue;
                     f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
                     if (p.add_src) v += apre[i];
-                    *(f32x4*)(p.out + o) = v;
+                    apre[i] = v;
                     f32x4 g = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = ((mpre[i] >> e) & 1u) ? g[e] : 0.f;
                     s1 += g;
                     s2 += g * ((xpre[i] - mu) * is);
+                }
+            } else if (tail_on) {
+                // forward statistics with the in-kernel finalize: pass 1 reads this thread's rows (kept in apre[]) and sums them
+                // (plain convolution: no bias / residual / ReLU here, the host excludes them)
+#pragma unroll
+                for (int i = 0; i < E_NR; ++i) {
+                    const int row = rr + RPP * i;
+                    const int tl = row >> 2, px = row & 3;
+                    const int ro = rowinfo[2 * tl], fl = rowinfo[2 * tl + 1];
+                    const bool dead = ro < 0 || ((px & 1) && !(fl & 1)) || ((px & 2) && !(fl & 2));
+                    mpre[i] = dead ? 0u : 0x100u;
+                    if (dead) continue;
+                    const f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
+                    apre[i] = v;
+                    s1 += v;
+                    s2 += v * v;
                 }
             } else
 #pragma unroll 4
@@ -431,8 +454,32 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
                     a2 += red[(RPP + r) * BN + tid];
                 }
                 float* o = p.stats + (size_t)mb * 2 * p.N;
-                o[n0 + tid] = a1;
-                o[p.N + n0 + tid] = a2;
+                if (tail_on) {                        // write-through: another CU's workgroup reduces the rows inside this launch
+                    bn_tail_store(o + n0 + tid, a1);
+                    bn_tail_store(o + p.N + n0 + tid, a2);
+                } else {
+                    o[n0 + tid] = a1;
+                    o[p.N + n0 + tid] = a2;
+                }
+            }
+        }
+        if ((bnb || tail_on) && n < p.N) {           // pass 2: the output stores
+#pragma unroll
+            for (int i = 0; i < E_NR; ++i) {
+                if (!(mpre[i] & 0x100u)) continue;
+                const int row = rr + RPP * i;
+                const int tl = row >> 2, px = row & 3;
+                const size_t o = (size_t)(rowinfo[2 * tl] + ((px >> 1) * sg.W + (px & 1)) * p.out_ld) + n;
+                *(f32x4*)(p.out + o) = apre[i];
+            }
+        }
+        if (tail_on) {
+            // in-kernel BatchNorm finalize (bn_tail.h): producers drain and fire their arrival, the column block's last row block reduces
+            if (mb != p.m_blocks - 1) {
+                if (tid < BN) bn_tail_arrive(p.tail.tickets + nb);
+            } else {
+                __syncthreads();                     // ct / red are free
+                bn_tail_reduce<NT, BN>(p.tail, p.tail.tickets + nb, p.stats, p.m_blocks, p.N, n0, (double*)smem);
             }
         }
         return;
@@ -559,7 +606,8 @@ static int wino_launch(const WnParams& p, hipStream_t st, double flops, const ch
 // tile_hint = TB | (BN << 8) | (split_k << 16) | (four position groups << 24), TB (tiles per block) and BN in {32, 64};
 // 0 = 64x64, two position groups, no split
 static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
-                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream) {
+                          const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
+                          const BnTail* tail = nullptr) {
     ZSG_REQUIRE(d && src && U && out, "conv_wino: null argument");
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0, "conv_wino: C=%d src_ld=%d must be multiples of 4", d->C, d->src_ld);
@@ -612,6 +660,16 @@ static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float*
     } else if (bn_partials) {
         ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu && p.vec, "conv_wino: BN-statistics fusion needs a plain (bias-free, unsplit, 16-byte addressable) convolution");
     }
+    if (tail) {
+        ZSG_REQUIRE(tail->tickets && bn_partials && splits == 1 && p.vec && !mask_src && p.m_blocks <= BN_TAIL_MAX_ROWS,
+                    "conv_wino: in-kernel BatchNorm finalize needs fused partials, the vectorised epilogue and at most %d row blocks (%d)",
+                    BN_TAIL_MAX_ROWS, p.m_blocks);
+        ZSG_REQUIRE((((uintptr_t)bn_partials) & 15) == 0 && (d->N % 4) == 0, "conv_wino: partial rows not 16-byte aligned");
+        p.tail = *tail;
+        int64_t rows = 0;
+        for (int s = 0; s < d->nseg; ++s) rows += (int64_t)d->B * d->seg[s].rows_y * d->seg[s].rows_x;
+        p.tail.rows = rows;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (splits > 1) {
         ZSG_REQUIRE(!d->relu && d->nseg == 1 && d->out_ld == d->N && d->seg[0].out_bstride == (int64_t)d->seg[0].rows_y * d->seg[0].rows_x * d->N,
@@ -645,5 +703,27 @@ extern "C" int zsg_conv_wino_bnb(const zsg_conv_desc* d, const float* src, const
                                  float* partials, void* stream) {
     BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
     return conv_wino_impl(d, src, U, out, nullptr, add_src, nullptr, partials, &b, stream);
+}
+
+// The Winograd counterparts of zsg_conv_igemm_bnstat / zsg_conv_igemm_bnb_tail (igemm.hip): the last block of a column block finalises
+// the BatchNorm statistics / backward sums inside the launch (bn_tail.h); tickets: zsg_conv_bn_tail_tickets(d, 1) zeroed words.
+extern "C" int zsg_conv_wino_bnstat(const zsg_conv_desc* d, const float* src, const float* U, float* out, float* partials, uint32_t* tickets,
+                                    float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+    ZSG_REQUIRE(tickets && mean && invstd && partials, "conv_wino_bnstat: null argument");
+    BnTail t;
+    memset(&t, 0, sizeof(t));
+    t.tickets = tickets; t.mean = mean; t.invstd = invstd; t.rmean = running_mean; t.rvar = running_var; t.momentum = momentum; t.eps = eps; t.mode = 0;
+    return conv_wino_impl(d, src, U, out, nullptr, nullptr, nullptr, partials, nullptr, stream, &t);
+}
+extern "C" int zsg_conv_wino_bnb_tail(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* add_src,
+                                      const float* bn_x, const float* bn_mean, const float* bn_invstd, const uint8_t* bn_relu_mask,
+                                      float* partials, uint32_t* tickets, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
+                                      void* stream) {
+    ZSG_REQUIRE(tickets && coef && partials, "conv_wino_bnb_tail: null argument");
+    BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
+    BnTail t;
+    memset(&t, 0, sizeof(t));
+    t.tickets = tickets; t.coef = coef; t.dgamma = dgamma; t.dbeta = dbeta; t.accumulate = accumulate ? 1 : 0; t.mode = 1;
+    return conv_wino_impl(d, src, U, out, nullptr, add_src, nullptr, partials, &b, stream, &t);
 }
 

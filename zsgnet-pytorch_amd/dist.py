@@ -244,9 +244,11 @@ class DistributedDataParallel(nn.Module):
         (B, H, W, training): equal-sized shards (DistributedSampler pads), one mode — and NOT on the query-length bucket: the collater
         cuts qvec to the batch's longest query (dat_loader.py, as the reference's), so T_plan (20 / 50) differs from rank to rank
         and step to step.  (Keyed on T, a rank that met a bucket earlier than its peers skipped the broadcast they were waiting
-        in: mismatched collectives.)  Rank 0 lowers the plan of ITS current bucket; the image branch — everything but the two
-        query-encoder input projections — does not depend on T, and a rank that later needs another bucket tunes those two
-        launches itself."""
+        in: mismatched collectives.)  Rank 0 lowers the plan of ITS current bucket; the image branch — everything the autotuner
+        touches — does not depend on T.  The T-dependent launches (the query encoder's input projections and their weight gradients,
+        mdl._Plan._lower_lstm) are lowered with tile_hint 0, i.e. the library's deterministic shape heuristic, never the tuner: a rank
+        that later meets the other bucket lowers exactly the launches its peers lower for it, so the promise above holds for every
+        launch of the step (ADVICE r04 item 4 asked for rank 0 to lower both buckets: nothing of the second bucket is tuned)."""
         if not hasattr(self.module, "plan_geometry"):
             return
         from . import ops

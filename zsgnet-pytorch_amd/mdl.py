@@ -15,6 +15,7 @@ Execution model: for a given input geometry the network is lowered ONCE into two
 The whole forward is a single autograd node, so the reference trainer's `loss.backward()` / `optimizer.step()`
 keep working while no autograd graph is built per layer.
 """
+import ctypes as _ct
 import math
 import os
 import types
@@ -67,6 +68,11 @@ class BnL:
 
 
 BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward sums in the epilogue of the data gradient that completes dout
+# BatchNorm statistics / backward sums FINALISED by the last-arriving tile of the producing convolution (csrc/bn_tail.h, round 5): no
+# finalize launch, no re-reduction in the apply pass, wherever the launch has <= 128 partial rows per column block ("0": rounds 1-4's
+# separate finalize / inline apply; "fwd" / "bwd": one direction only — A/B switches)
+BN_TAIL = os.environ.get("ZSG_BN_TAIL", "1")
+BN_TAIL_MIN_ROWS = int(os.environ.get("ZSG_BN_TAIL_MIN_ROWS", "0"))      # (A/B: only launches with more partial rows than this finalise in-kernel)
 def prep_at() -> str:
     """ZSG_PREP_AT: where the backward's weight images are enqueued on the side stream during the forward (see _Plan._prep_index)."""
     return os.environ.get("ZSG_PREP_AT", "j2")
@@ -511,7 +517,7 @@ class _Plan:
             self.prep_u.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
             self.prep_u.calls.insert(0, self.prep_u.calls.pop())          # (needed first)
             self.prep_u.lanes.insert(0, self.prep_u.lanes.pop())
-            wfns = (lib.zsg_conv_wino,)
+            wfns = (lib.zsg_conv_wino, lib.zsg_conv_wino_bnstat)
             self._wait_idx = min(self._wait_idx, next(i for i, c in enumerate(self.fwd.calls) if c[0] in wfns))
         elif wj.jobs:        # eval (after the BatchNorm fold): first launch after the image conversion
             self.fwd.add(lib.zsg_wino_weights, wj.finish(self.dev), len(wj.jobs), wj.blocks, what="wino filter transforms")
@@ -664,11 +670,26 @@ class _Plan:
             lv0 = out.levels[0]
             self.prep_u.add(lib.zsg_memset_f32, out.buf[lv0.off:], out.B * lv0.bstride, 0.0, what="zero:" + L.name)
             pre_zero = out.buf
-        self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, pre_zero, None, partials, what=L.name, lane=self._lane)
+        tail_n = -1
+        if partials is not None and BN_TAIL in ("1", "fwd") and out.bn_chunks > BN_TAIL_MIN_ROWS:
+            tail_n = int(lib.zsg_conv_bn_tail_tickets(_ct.byref(d), 1 if d.use_wino else 0))
+        out.bn_inline = None
+        if tail_n > 0:
+            # the convolution's last tile per column block finalises the statistics itself (mean / invstd / running statistics are ready
+            # when the launch ends): the plain apply launch follows, nothing in between
+            Lb = bn_fuse
+            tk = self._buf(tail_n, dtype=torch.int32)
+            out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
+            rm, rv = self.net._rm[Lb.index:Lb.index + Lb.c], self.net._rv[Lb.index:Lb.index + Lb.c]
+            self.fwd.add(lib.zsg_conv_wino_bnstat if d.use_wino else lib.zsg_conv_igemm_bnstat, d, rd.buf, wt, out.buf, partials, tk,
+                         out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5, what=L.name + "+bnstat", lane=self._lane)
+        else:
+            self.fwd.add(fn, d, rd.buf, wt, out.buf, bias, pre_zero, None, partials, what=L.name, lane=self._lane)
         if pre_zero is not None:
             self._zero_calls.append(self.fwd.calls[-1])
-        out.bn_inline = None
-        if partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
+        if tail_n > 0:
+            pass
+        elif partials is not None and out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
             # few partial rows: the BatchNorm apply launch (the very next launch on this stream: the workspace is still intact)
             # reduces them itself — no finalize launch
             out.bn_inline = partials
@@ -745,7 +766,8 @@ class _Plan:
             return
         blob, tile0 = b"", 0
         for (so, do, N, T, Cc, ld) in self.wt_jobs:
-            tc, tn = (Cc + 31) // 32, (ld + 31) // 32
+            tc, tn = (Cc + 63) // 64, (ld + 63) // 64          # 64 x 64 tiles (csrc/misc.hip transpose_w_batched_kernel)
+            assert Cc % 4 == 0 and ld % 4 == 0 and so % 4 == 0 and do % 4 == 0
             blob += struct.pack("<qqiiiiiiii", so, do, N, T, Cc, ld, tile0, tc, tn, 0)
             tile0 += T * tc * tn
         self.wt_jobs_dev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.dev)
@@ -882,13 +904,25 @@ class _Plan:
                 fuse = chunks * 2 * L.c * 4 + 2 * L.c * 4 <= self.ws_bytes
             if fuse:
                 part = self.ws[2 * L.c:]              # (the first 2C floats of the workspace: the finalize launch's coefficients)
-                fn = lib.zsg_conv_wino_bnb if d.use_wino else lib.zsg_conv_igemm_bnb
                 # a = (src, wt|U, out, bias=None, add_src, mask=None, partials=None)
                 assert a[3] is None and a[5] is None and a[6] is None
-                self.bwd.calls[idx] = (fn, marshal(fn, (d, a[0], a[1], a[2], a[4], x.buf, mean, invstd, rmask, part), self.bwd.keep), what + "+bnb")
-                self.bwd.add(lib.zsg_bn_backward_from_partials, self.base(out.grad), rmask, x.buf, rows, L.c, mean, invstd, gam,
-                             dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, part, chunks, self.ws, self.ws_bytes,
-                             what="bnbwd:" + L.name)
+                tail_n = int(lib.zsg_conv_bn_tail_tickets(_ct.byref(d), 1 if d.use_wino else 0)) if (BN_TAIL in ("1", "bwd") and chunks > BN_TAIL_MIN_ROWS) else -1
+                if tail_n > 0:
+                    # the data gradient's last tile per column block finalises the coefficients and d(gamma) / d(beta): the apply pass
+                    # is all that is left of this BatchNorm's backward
+                    fn = lib.zsg_conv_wino_bnb_tail if d.use_wino else lib.zsg_conv_igemm_bnb_tail
+                    tk = self._buf(tail_n, dtype=torch.int32)
+                    coef = self._buf(2 * L.c)
+                    self.bwd.calls[idx] = (fn, marshal(fn, (d, a[0], a[1], a[2], a[4], x.buf, mean, invstd, rmask, part, tk, coef,
+                                                            self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1), self.bwd.keep), what + "+bnb+fin")
+                    self.bwd.add(lib.zsg_bn_bwd_apply, self.base(out.grad), rmask, x.buf, rows, L.c, mean, invstd, gam, coef, dx.buf, g_out,
+                                 what="bnbwd:" + L.name)
+                else:
+                    fn = lib.zsg_conv_wino_bnb if d.use_wino else lib.zsg_conv_igemm_bnb
+                    self.bwd.calls[idx] = (fn, marshal(fn, (d, a[0], a[1], a[2], a[4], x.buf, mean, invstd, rmask, part), self.bwd.keep), what + "+bnb")
+                    self.bwd.add(lib.zsg_bn_backward_from_partials, self.base(out.grad), rmask, x.buf, rows, L.c, mean, invstd, gam,
+                                 dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, part, chunks, self.ws, self.ws_bytes,
+                                 what="bnbwd:" + L.name)
             else:
                 self.bwd.add(lib.zsg_bn_backward, self.base(out.grad), None, rmask, x.buf, rows, L.c, mean, invstd, gam,
                              dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, self.ws, self.ws_bytes,

@@ -223,7 +223,8 @@ SIDE_BATCH = int(os.environ.get("ZSG_SIDE_BATCH", "0"))
 COMPLETION_EVENTS = os.environ.get("ZSG_COMPLETION_EVENTS", "1") != "0"
 
 
-_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb)
+_MAIN_CONVS = (lib.zsg_conv_igemm, lib.zsg_conv_wino, lib.zsg_conv_igemm_bnb, lib.zsg_conv_wino_bnb, lib.zsg_conv_igemm_bnstat,
+               lib.zsg_conv_wino_bnstat, lib.zsg_conv_igemm_bnb_tail, lib.zsg_conv_wino_bnb_tail)
 
 
 _SIDE = {}
