@@ -311,6 +311,13 @@ int zsg_u8hwc_to_nhwc4(const uint8_t* img, int64_t pixels, float* out, void* str
 int zsg_resize_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, const int32_t* x_bounds, const int32_t* x_coef, int32_t x_ksize,
                   const int32_t* y_bounds, const int32_t* y_coef, int32_t y_ksize, int32_t Ho, int32_t Wo, uint8_t* tmp, uint8_t* out,
                   void* stream);
+/* The same for a whole batch in TWO launches (round 5): jobs = device array of
+ * {int64 src, tmp, out; int64 x_bounds, x_coef, y_bounds, y_coef; int32 h, w, x_ksize, y_ksize, blk0_x, blk0_y, pad, pad} — absolute
+ * device addresses of the raw image [h][w][C], its scratch [h][Wo][C] and its result [Ho][Wo][C], the tap tables of its horizontal and
+ * vertical pass (an axis that keeps its length carries the identity table: one tap, coefficient 2^22), the first 1024-output block of
+ * the job in each launch (blocks_x / blocks_y = their totals).  Byte-identical to zsg_resize_u8 (dat_loader.py:98-146, :121). */
+int zsg_resize_u8_batched(const void* jobs_dev, int32_t njobs, int32_t C, int32_t Ho, int32_t Wo, int32_t blocks_x, int32_t blocks_y,
+                          void* stream);
 /* Head input BackBone.concat_we (mdl.py:69-104) + head conv0 (mdl.py:216, 514 -> 256, 3x3 pad 1) without ever materialising
  * the concatenated tensor, and without its spatially-constant input channels: the language vector
  * is constant over the image and the grid channels do not depend on the batch index, so only the 256 feature channels

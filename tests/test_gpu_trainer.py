@@ -92,11 +92,19 @@ def test_real_data_loader_uint8_ingest_and_training(tmp_path, gold):
     # hands over is byte-identical to the one whose images PIL resized in the worker
     ds_r = D.ImgQuDataset(cfg, tmp_path / "d.csv", "refclef", gpu_resize=True)
     br = D.collater([ds_r[0], ds_r[1]])
-    assert isinstance(br["img"], list) and [tuple(t.shape) for t in br["img"]] == [(30, 40, 3), (47, 33, 3)]
+    # (round 5: ONE flat uint8 tensor + the sizes — one upload, two launches for the whole batch)
+    assert br["img"].dtype == torch.uint8 and br["img"].dim() == 1 and br["img"].numel() == (30 * 40 + 47 * 33) * 3
+    assert br["img_hw"].tolist() == [[30, 40], [47, 33]]
     got = next(iter(D.DevicePrefetcher([br], "cuda", resize_hw=(64, 96))))
     torch.cuda.synchronize()
-    assert got["img"].dtype == torch.uint8 and torch.equal(got["img"].cpu(), bu["img"])
+    assert got["img"].dtype == torch.uint8 and torch.equal(got["img"].cpu(), bu["img"]) and "img_hw" not in got
     assert all(torch.equal(got[k].cpu(), bu[k]) for k in bu if k != "img")
+    # a caller that still hands over a LIST of raw images gets the same batch; several batches in a row reuse the job-table slots
+    raw_list = {k: v for k, v in br.items() if k not in ("img", "img_hw")}
+    raw_list["img"] = [ds_r[0]["img"], ds_r[1]["img"]]
+    for g2 in D.DevicePrefetcher([raw_list, br, raw_list, br, br, br], "cuda", resize_hw=(64, 96)):
+        torch.cuda.synchronize()
+        assert torch.equal(g2["img"].cpu(), bu["img"])
     learn = main_dist("real0", **{k: str(v) for k, v in kw.items()})
     assert isinstance(learn.data.train_dl, D.DevicePrefetcher) and learn.num_it == 4        # 5 rows, bs 2, drop_last, 2 epochs
     res = learn.testing(learn.data.test_dl)
@@ -118,6 +126,18 @@ def test_gpu_resize_bit_identical_to_the_reference_loader(gold):
     torch.cuda.synchronize()
     for i, nm in enumerate(g["names"]):
         assert np.array_equal(out[i].cpu().numpy(), g["out_" + str(nm)[0]]), f"{nm} {tuple(raws[i].shape)}: the GPU resize differs from the reference loader"
+    # the flat form (what the collater produces: one upload) gives the same bytes, and so does the per-image C entry point
+    flat, hw = D.flatten_raw([r.cpu() for r in raws])
+    out_f = rz.resize_flat(flat.cuda(), hw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_f, out)
+    # an axis that keeps its length (Pillow skips that pass; the batched launches run it with the identity table)
+    import PIL.Image
+    a = np.random.default_rng(0).integers(0, 256, (oh, 57, 3), dtype=np.uint8)
+    ref = np.asarray(PIL.Image.fromarray(a).resize((ow, oh)))
+    got1 = rz([torch.from_numpy(a).cuda()])
+    torch.cuda.synchronize()
+    assert np.array_equal(got1[0].cpu().numpy(), ref)
     g3 = gold("g13_dataset")
     ow3, oh3 = (int(v) for v in g3["resize_img"])
     rz3 = D.GpuResizer((oh3, ow3))

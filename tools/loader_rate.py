@@ -53,7 +53,7 @@ def main():
             host = mode.startswith("host")
             ds = Raw(files, resize=host)
             dl = torch.utils.data.DataLoader(ds, batch_size=16, num_workers=nw, pin_memory=True, persistent_workers=False,
-                                             collate_fn=(None if host else (lambda b: {"img": list(b)})))
+                                             collate_fn=(None if host else (lambda b: dict(zip(("img", "img_hw"), D.flatten_raw(b))))))
             it = dl if host else D.DevicePrefetcher(dl, "cuda", resize_hw=(300, 300))      # (side-stream copies + resize, as the trainer's loader)
             t0, cnt = None, 0
             for bi, b in enumerate(it):

@@ -103,6 +103,7 @@ SIGNATURES = {
     "zsg_nchw_to_nhwc4": (I32, [P, I32, I32, I32, I32, P, P]),
     "zsg_u8hwc_to_nhwc4": (I32, [P, I64, P, P]),
     "zsg_resize_u8": (I32, [P, I32, I32, I32, P, P, I32, P, P, I32, I32, I32, P, P, P]),
+    "zsg_resize_u8_batched": (I32, [P, I32, I32, I32, I32, I32, I32, P]),
     "zsg_interleave": (I32, [P, I64, I32, I32, P, I32, I32, I32, P]),
     "zsg_head_lang_map": (I32, [P, P, I32, I32, I32, I32, P, P]),
     "zsg_head_border_sums": (I32, [P, I32, I32, I32, I32, P, P]),

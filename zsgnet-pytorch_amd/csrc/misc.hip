@@ -374,6 +374,66 @@ extern "C" int zsg_resize_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C
     return 0;
 }
 
+// ---- batched form: every image of a batch in TWO launches (round 5) ------------------------------------------------------------
+// The per-image form above costs the consumer thread one call (two launches) and one upload per image: 1 323 img/s from one worker, but
+// only 3 680 img/s from sixteen (the host-side resize reached 6 367: profiles/r04_loader_rate.txt).  Here the whole batch is ONE flat
+// uint8 upload and one job table; launch 1 runs every image's horizontal pass, launch 2 every vertical pass (a job with a pass that
+// keeps its length carries the identity tap table: n = 1, coefficient 2^22 — the value passes through the fixed point exactly).
+// Same arithmetic as resize_pass_kernel (Pillow's two-pass fixed-point bicubic, dat_loader.py:121): byte-identical.
+struct ZsgResizeJob {
+    int64_t src, tmp, out;                 // absolute device addresses: raw image [h][w][C], scratch [h][Wo][C], result [Ho][Wo][C]
+    int64_t xb, xc, yb, yc;                // tap tables (int32): bounds [n_out][2], coefficients [n_out][ksize]
+    int32_t h, w, xk, yk, blk0_x, blk0_y, pad0, pad1;      // blk0_*: first block of the job in launch 1 / 2 (1024 outputs per block)
+};
+template <int AXIS>
+__global__ __launch_bounds__(256) void resize_batched_kernel(const ZsgResizeJob* __restrict__ jobs, int njobs, int C, int Ho, int Wo) {
+    int lo = 0, hi = njobs - 1;                      // last job whose first block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((AXIS == 0 ? jobs[mid].blk0_x : jobs[mid].blk0_y) <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ZsgResizeJob jb = jobs[lo];
+    const int lb = (int)blockIdx.x - (AXIS == 0 ? jb.blk0_x : jb.blk0_y);
+    const uint8_t* in = (const uint8_t*)(AXIS == 0 ? jb.src : jb.tmp);
+    uint8_t* out = (uint8_t*)(AXIS == 0 ? jb.tmp : jb.out);
+    const int32_t* bounds = (const int32_t*)(AXIS == 0 ? jb.xb : jb.yb);
+    const int32_t* coef = (const int32_t*)(AXIS == 0 ? jb.xc : jb.yc);
+    const int ksize = AXIS == 0 ? jb.xk : jb.yk;
+    const int in_w = AXIS == 0 ? jb.w : Wo, out_h = AXIS == 0 ? jb.h : Ho;
+    const int total = out_h * Wo * C;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = lb * 1024 + u * 256 + (int)threadIdx.x;
+        if (i >= total) break;
+        const int c = i % C;
+        const int x = (i / C) % Wo;
+        const int y = i / (C * Wo);
+        const int o = AXIS == 0 ? x : y;
+        const int first = bounds[2 * o], n = bounds[2 * o + 1];
+        const int32_t* k = coef + (int64_t)o * ksize;
+        int acc = 1 << 21;
+        if (AXIS == 0) {
+            const uint8_t* p = in + ((int64_t)y * in_w + first) * C + c;
+            for (int t = 0; t < n; ++t) acc += (int)p[(int64_t)t * C] * k[t];
+        } else {
+            const uint8_t* p = in + ((int64_t)first * in_w + x) * C + c;
+            for (int t = 0; t < n; ++t) acc += (int)p[(int64_t)t * in_w * C] * k[t];
+        }
+        acc >>= 22;
+        out[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+}
+extern "C" int zsg_resize_u8_batched(const void* jobs_dev, int32_t njobs, int32_t C, int32_t Ho, int32_t Wo, int32_t blocks_x, int32_t blocks_y,
+                                     void* stream) {
+    ZSG_REQUIRE(jobs_dev && njobs > 0 && C > 0 && Ho > 0 && Wo > 0 && blocks_x > 0 && blocks_y > 0, "resize_u8_batched: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("resize_u8", st, 0, 0);
+    ZSG_LAUNCH(resize_batched_kernel<0>, dim3(blocks_x), dim3(256), 0, st, (const ZsgResizeJob*)jobs_dev, njobs, C, Ho, Wo);
+    ZSG_LAUNCH(resize_batched_kernel<1>, dim3(blocks_y), dim3(256), 0, st, (const ZsgResizeJob*)jobs_dev, njobs, C, Ho, Wo);
+    ZSG_CHECK_LAUNCH("resize_u8_batched");
+    return 0;
+}
+
 // ---- weight transpose [N][T][C] -> [C][T][dst_ld >= N] (pad columns zeroed) ------------------------------------------
 __global__ void transpose_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int T, int C, int dst_ld) {
     __shared__ float tile[32][33];

@@ -29,8 +29,6 @@
 // History of the round (profiles/r05_wino4_microbench.txt): a first, strictly phased version with the filter slice staged through a
 // single LDS stage ran 5 us per chunk (177 us for P3_2 against 140 us for F(2x2,3x3)); patch rows by LDS-DMA made hipcc drain every
 // register load at the top of each chunk (vmcnt(0)), and hand-counted inline-asm loads around that cost 70 spilled registers.
-#include <stdlib.h>
-
 #include "common.h"
 
 #define W4_CK 8
@@ -58,8 +56,6 @@ struct W4Params {
     const float* mask_src;
     int C, N, Npad, src_ld, out_ld, relu, nseg;
     int m_blocks, n_blocks, chunks, vec;
-    int order;           // 1: channel-block-major tile order (an XCD's chunk of the grid shares ONE filter slice); 0: row-block-major
-    int abl;             // timing experiments only (wrong results): 1 no filter loads, 2 no patch loads
     double alg_bytes;    // host only
     W4SegDev seg[ZSG_MAX_SEG];
 };
@@ -103,7 +99,7 @@ __global__ __launch_bounds__(W4_NT, 3) void wino4_kernel(const W4Params p) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int bid = xcd_remap(blockIdx.x, p.m_blocks * p.n_blocks);
-    const int mb = p.order ? bid % p.m_blocks : bid / p.n_blocks, nb = p.order ? bid / p.m_blocks : bid % p.n_blocks;
+    const int mb = bid / p.n_blocks, nb = bid % p.n_blocks;      // (channel-block-major order — an XCD's chunk shares one filter slice — measured the same)
     int si = 0;
 #pragma unroll
     for (int s = 1; s < ZSG_MAX_SEG; ++s)
@@ -157,12 +153,12 @@ __global__ __launch_bounds__(W4_NT, 3) void wino4_kernel(const W4Params p) {
 #define W4_LOAD_A(c, live)                                                                                                       \
     {                                                                                                                            \
         const int so__ = (c) * (W4_CK * 4);                                                                                     \
-        const bool dead__ = !(live) | (c_tail & ((c) == nc - 1) & (tg != 0)) | ((p.abl & 2) != 0);                               \
+        const bool dead__ = !(live) | (c_tail & ((c) == nc - 1) & (tg != 0));                                                    \
         _Pragma("unroll") for (int col = 0; col < 6; ++col)                                                                     \
             ra[col] = __builtin_bit_cast(f32x2, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(                                      \
                 rsrc_a, (int)((!dead__ && ((a_ok >> col) & 1u)) ? a_base + (unsigned)(col * a_pix) : ZSG_OOB), so__, 0));          \
     }
-#define W4_LOAD_B(c, pl, live) rb[pl] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)(((live) && !(p.abl & 1)) ? b_voff : ZSG_OOB), (c) * b_chunk + (wi * 6 + (pl)) * b_pos, 0))
+#define W4_LOAD_B(c, pl, live) rb[pl] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)((live) ? b_voff : ZSG_OOB), (c) * b_chunk + (wi * 6 + (pl)) * b_pos, 0))
     // row transform d B of this lane's patch row tq (two channels), from registers into stage `st`
 #define W4_ST_ROW(c, v) *(f32x2*)(st__ + (tq * 6 + (c)) * SA + t_slot) = (v);
 #define W4_ROWS(stage)                                                                                                           \
@@ -433,12 +429,6 @@ extern "C" int zsg_conv_wino4(const zsg_conv_desc* d, const float* src, const fl
     ZSG_REQUIRE((int64_t)p.chunks * 36 * p.Npad * 8 < (1ll << 29), "conv_wino4: transformed weights exceed 2^29 elements");
     p.m_blocks = blocks;
     p.n_blocks = cdiv(d->N, W4_BN);
-    {
-        static int abl = -1, order = -1;
-        if (abl < 0) { const char* e = getenv("ZSG_W4_ABL"); abl = e ? atoi(e) : 0; }
-        if (order < 0) { const char* e = getenv("ZSG_W4_ORDER"); order = e ? atoi(e) : 1; }
-        p.abl = abl; p.order = order;
-    }
     const uintptr_t al = (uintptr_t)out | (uintptr_t)bias | (uintptr_t)add_src | (uintptr_t)mask_src;
     p.vec = (v && (al & 15) == 0) ? 1 : 0;
     constexpr size_t stage = (size_t)3 * 36 * W4_SA * sizeof(float);
