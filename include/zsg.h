@@ -329,6 +329,16 @@ int zsg_resize_u8_batched(const void* jobs_dev, int32_t njobs, int32_t C, int32_
  * zsg_head_border_sums accumulates level by level (caller zeroes Q) and zsg_head_border_finalize turns into S1, S2 and,
  * optionally, the bias gradient sum_b Q[0][b][:].  dy / out: one pyramid level [B][h*w][N]. */
 int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int32_t w, int32_t N, float* out, void* stream);
+/* Per-forward input staging in one launch (round 5): what `batch[k].to(device)` of the trainer (utils.py:403-405), the zero padding of
+ * the query bucket, lstm_init_hidden's host draws (mdl.py:279-294: hc_src = h0 | c0, hc_n floats, may be PINNED HOST memory) and the
+ * BatchNorm layers' num_batches_tracked += 1 (n_nbt int64 counters; 0 in eval mode) do at the head of ZSGNet.forward.
+ * qvec [B][T][E] device fp32 -> qbuf [B][Tplan][E] (zeros behind T); qlens int64 [B] -> qlens_dst float [B]. */
+int zsg_stage_inputs(const float* qvec, int32_t B, int32_t T, int32_t E, int32_t Tplan, float* qbuf, const int64_t* qlens, float* qlens_dst,
+                     const float* hc_src, int32_t hc_n, float* hc_dst, int64_t* nbt, int32_t n_nbt, void* stream);
+/* the same map for ALL pyramid levels in one launch (round 5): `out` [B][h_i*w_i][N] per level, levels packed level-major (level i
+ * starts at B * N * sum_{j<i} h_j w_j); G (or NULL) packed the same way with B = 1; hw = {h_0, w_0, h_1, w_1, ...} (host memory,
+ * nlev <= ZSG_MAX_SEG pairs).  A block sums V's taps once per border class instead of once per output element. */
+int zsg_head_lang_map_packed(const float* V, const float* G, int32_t B, int32_t nlev, const int32_t* hw, int32_t N, float* out, void* stream);
 int zsg_head_border_sums(const float* dy, int32_t B, int32_t h, int32_t w, int32_t N, float* Q /* [9][B][N], += */, void* stream);
 int zsg_head_border_finalize(const float* Q, int32_t B, int32_t N, float* S1, float* S2, float* bias_grad /* [N], += ; or NULL */,
                              void* stream);

@@ -342,6 +342,72 @@ def test_conv_pw_streaming(Z, case):
     torch.cuda.synchronize()
 
 
+MX_CASES = [
+    # B, H, W, k, stride, pad, bias+relu
+    (2, 45, 37, 7, 2, 3),          # the ResNet stem's window on an odd image: units that straddle image rows, a ragged last unit
+    (3, 64, 64, 7, 2, 3),          # 3 x 32 x 32 = 96 units
+    (1, 7, 9, 7, 2, 3),            # a window larger than the image on every side
+    (2, 31, 30, 3, 1, 1),          # SSD-VGG conv1_1's window
+    (16, 300, 300, 7, 2, 3),       # the bench shape: 11 250 units, 5-6 per wave, prefetch across units
+]
+
+
+@pytest.mark.parametrize("case", MX_CASES, ids=[f"m{i}" for i in range(len(MX_CASES))])
+def test_conv_mx_streaming(Z, case):
+    """The filter-resident streaming kernel of the network's first convolution (csrc/mx.hip: tile_hint BM = 32 on a merge_x
+    descriptor) against torch-CPU fp32 F.conv2d: plain + fused BatchNorm statistics (one partial row per workgroup), bias + ReLU,
+    two launches bit-identical, and against the implicit-GEMM merge_x tile.  Tolerances as test_conv_fwd_dgrad_wgrad."""
+    L, ops = Z
+    B, H, W, k, s, p = case
+    Ci, Co = 3, 64
+    g = torch.Generator().manual_seed(900 + H + k)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    y_lin = F.conv2d(x, w, None, s, p)
+    Ho, Wo = y_lin.shape[2:]
+    st = L.stream_ptr()
+    xd, wd, bd = dev(nhwc(x)), dev(ohwi(w)), dev(b)
+    src = view_of(ops, xd, B, H, W, 4)
+    out = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+    ov = view_of(ops, out, B, Ho, Wo, Co)
+    hint = ops.tile_hint(32, 64, 1)
+    probe = ops.fwd_desc(src, ov, 4, Co, k, s, p, 1, wC=4, merge_x=True)
+    assert ops.pw_cands(probe) == [hint], "the streaming first-layer kernel must cover this geometry"
+    d2 = ops.fwd_desc(src, ov, 4, Co, k, s, p, 1, wC=4, merge_x=True, tile_hint=hint)
+    rows = B * Ho * Wo
+    chunks = ops.igemm_partial_rows(d2)
+    assert chunks == min(256, ((rows + 31) // 32 + 7) // 8)
+    part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
+    L.check(L.lib.zsg_conv_igemm(C.byref(d2), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "mx fwd+stats")
+    assert_close(out.permute(0, 3, 1, 2), y_lin, 2e-4, 2e-4, "mx fwd")
+    yf = y_lin.permute(0, 2, 3, 1).reshape(-1, Co).double()
+    assert not torch.isnan(part).any()
+    assert_close(part[:, 0].double().sum(0), yf.sum(0), 1e-4, 1e-4 * float(yf.abs().sum(0).max()), "mx bn partial sums")
+    assert_close(part[:, 1].double().sum(0), (yf * yf).sum(0), 1e-4, 1e-6, "mx bn partial sums of squares")
+    mean, invstd = torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+    L.check(L.lib.zsg_bn_stats_from_partials(part.data_ptr(), chunks, rows, Co, mean.data_ptr(), invstd.data_ptr(), None, None, 0.1, 1e-5, st), "finalize")
+    assert_close(mean, yf.mean(0), 1e-4, 1e-5, "mx fused bn mean")
+    assert_close(invstd, 1 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5), 2e-4, 0, "mx fused bn invstd")
+    part2, out2 = torch.full_like(part, float("nan")), torch.full_like(out, float("nan"))
+    L.check(L.lib.zsg_conv_igemm(C.byref(d2), xd.data_ptr(), wd.data_ptr(), out2.data_ptr(), None, None, None, part2.data_ptr(), st), "mx again")
+    assert torch.equal(out, out2) and torch.equal(part, part2)
+    # the implicit-GEMM merge_x tile on the same operands: fp32 summation-order accuracy
+    out3 = torch.full_like(out, float("nan"))
+    d3 = ops.fwd_desc(src, view_of(ops, out3, B, Ho, Wo, Co), 4, Co, k, s, p, 1, wC=4, merge_x=True, tile_hint=ops.tile_hint(64, 64, 1))
+    L.check(L.lib.zsg_conv_igemm(C.byref(d3), xd.data_ptr(), wd.data_ptr(), out3.data_ptr(), None, None, None, None, st), "igemm tile")
+    assert_close(out, out3, 1e-5, 1e-5 * float(out3.abs().max()), "mx vs the 64x64 tile")
+    # bias + ReLU
+    out.fill_(float("nan"))
+    d1 = ops.fwd_desc(src, ov, 4, Co, k, s, p, 1, wC=4, relu=True, merge_x=True, tile_hint=hint)
+    L.check(L.lib.zsg_conv_igemm(C.byref(d1), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), bd.data_ptr(), None, None, None, st), "mx bias+relu")
+    assert_close(out.permute(0, 3, 1, 2), F.relu(y_lin + b.view(1, -1, 1, 1)), 2e-4, 2e-4, "mx fwd bias+relu")
+    # an add operand is not this kernel's: loud failure, no fallback
+    rc = L.lib.zsg_conv_igemm(C.byref(d1), xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, out.data_ptr(), None, None, st)
+    assert rc != 0
+    torch.cuda.synchronize()
+
+
 def test_conv_multilevel_shared_weights(Z):
     """grouped launch over pyramid levels (shared head), output scattered into the [B, A, 5]-style buffer"""
     L, ops = Z
@@ -478,6 +544,45 @@ def test_head_conv0_decomposition(Z, B, h, w):
     ref = ohwi(wt.grad, cp)
     assert not torch.isnan(dW).any(), "the three window launches must cover every weight column"
     assert_close(dW, ref, 5e-4, 5e-4 * float(ref.abs().max()), "dW0 (feat | lang | grid windows)")
+
+
+@pytest.mark.parametrize("B,sizes", [(16, [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1)]), (3, [(5, 7), (1, 4), (2, 1), (1, 1)]), (2, [(4, 4)])])
+def test_head_lang_map_packed(Z, B, sizes):
+    """zsg_head_lang_map_packed (all pyramid levels in one launch, border-class sums in LDS) against the per-level launch
+    zsg_head_lang_map (itself checked against F.conv2d in test_head_conv0_decomposition) and against the definition: fp32
+    summation-order accuracy; with and without the grid map; one-row / one-column / single-pixel levels."""
+    L, ops = Z
+    N = 256
+    g = torch.Generator().manual_seed(5 + B)
+    V = dev(torch.randn(B, N * 9, generator=g))
+    P = sum(h * w for h, w in sizes)
+    G = dev(torch.randn(P, N, generator=g))
+    hw = torch.tensor([v for s_ in sizes for v in s_], dtype=torch.int32)
+    st = L.stream_ptr()
+    for useG in (True, False):
+        out = torch.full((B * P * N,), float("nan"), device="cuda")
+        ref = torch.full((B * P * N,), float("nan"), device="cuda")
+        L.check(L.lib.zsg_head_lang_map_packed(V.data_ptr(), G.data_ptr() if useG else None, B, len(sizes), hw.data_ptr(), N, out.data_ptr(), st), "packed")
+        p0 = 0
+        for h, w in sizes:
+            L.check(L.lib.zsg_head_lang_map(V.data_ptr(), G[p0:].data_ptr() if useG else None, B, h, w, N, ref[B * p0 * N:].data_ptr(), st), "per level")
+            # definition: out[b][y][x][n] = G + sum over taps inside the image of V[b][n*9 + tap]
+            Vc = V.cpu().double().view(B, N, 3, 3)
+            want = torch.zeros(B, h, w, N, dtype=torch.float64)
+            for r in range(3):
+                for q in range(3):
+                    ys = [y for y in range(h) if 0 <= y + r - 1 < h]
+                    xs = [x for x in range(w) if 0 <= x + q - 1 < w]
+                    if ys and xs:
+                        want[:, ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] += Vc[:, None, None, :, r, q]
+            if useG:
+                want += G[p0:p0 + h * w].cpu().double().view(1, h, w, N)
+            got = out[B * p0 * N:B * (p0 + h * w) * N].view(B, h, w, N)
+            assert_close(got, want, 1e-5, 1e-5, f"packed lang map level {h}x{w}")
+            p0 += h * w
+        assert not torch.isnan(out).any()
+        assert_close(out, ref, 1e-5, 1e-5, "packed vs per-level")
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("rows,Cc", [(2 * 19 * 19, 64), (3 * 7 * 5, 256), (1000, 2048), (5000, 12)])

@@ -106,6 +106,8 @@ SIGNATURES = {
     "zsg_resize_u8_batched": (I32, [P, I32, I32, I32, I32, I32, I32, P]),
     "zsg_interleave": (I32, [P, I64, I32, I32, P, I32, I32, I32, P]),
     "zsg_head_lang_map": (I32, [P, P, I32, I32, I32, I32, P, P]),
+    "zsg_head_lang_map_packed": (I32, [P, P, I32, I32, P, I32, P, P]),
+    "zsg_stage_inputs": (I32, [P, I32, I32, I32, I32, P, P, P, P, I32, P, P, I32, P]),
     "zsg_head_border_sums": (I32, [P, I32, I32, I32, I32, P, P]),
     "zsg_head_border_finalize": (I32, [P, I32, I32, P, P, P, P]),
     "zsg_batch_sum": (I32, [P, I32, I64, P, P]),

@@ -26,6 +26,12 @@ struct BnbDev {
 int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
                        const float* mask_src, float* bn_partials, const BnbDev* bnb, hipStream_t st);
 
+// mx.hip: the filter-resident streaming kernel of the network's first convolution (merge_x descriptors) behind tile_hint BM = 32
+bool zsg_conv_mx_ok(const zsg_conv_desc* d, const char** why);
+int zsg_conv_mx_groups(const zsg_conv_desc* d);
+int zsg_conv_mx_launch(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
+                       const float* mask_src, float* bn_partials, hipStream_t st);
+
 #define ZSG_WAVE 64
 #define ZSG_NUM_CU 256
 #define ZSG_NUM_XCD 8

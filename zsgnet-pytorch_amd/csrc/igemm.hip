@@ -663,6 +663,10 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     pick_tile(d, &BM, &BN, &splits, &w8);
     if (d->merge_x && BN == 128) BN = 64;
     if (d->merge_x) w8 = 0;
+    if (BM == 32 && d->merge_x) {                 // the filter-resident streaming kernel of the network's first convolution (mx.hip)
+        ZSG_REQUIRE(splits <= 1 && !tail && !bnb, "conv_igemm: the streaming first-layer kernel has no split-K / in-kernel finalize / bnb variant");
+        return zsg_conv_mx_launch(d, src, wt, out, bias, add_src, mask_src, bn_partials, (hipStream_t)stream);
+    }
     if (BM == 32) {                               // the filter-resident streaming kernel of the 1x1 layers (pw.hip); BN = unit width
         ZSG_REQUIRE(splits <= 1, "conv_igemm: the streaming 1x1 kernel has no split-K variant");
         ZSG_REQUIRE(!tail, "conv_igemm: the streaming 1x1 kernel has no in-kernel BatchNorm finalize (zsg_conv_bn_tail_tickets says so)");

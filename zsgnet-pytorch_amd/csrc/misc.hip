@@ -721,6 +721,118 @@ extern "C" int zsg_head_lang_map(const float* V, const float* G, int32_t B, int3
     return 0;
 }
 
+// The per-forward input staging of ZSGNet.forward in ONE launch (round 5): the reference moves qvec / qlens to the device and draws the
+// LSTM's initial state on the host every forward (utils.py:403-405, mdl.py:279-294); as separate torch copies + the BatchNorm counters'
+// `add_` these were five ~5 us operations with 5-20 us between them at the head of every forward (rocprofv3: 45 us).  One kernel:
+//   qbuf[b][t][:] = t < T ? qvec[b][t][:] : 0   (the plan's zero-padded token bucket);   qlens (int64) -> float;
+//   hc_dst = hc_src (h0 | c0; hc_src may be PINNED HOST memory: read over the bus by this kernel, no copy engine);   nbt[i] += 1.
+__global__ void stage_inputs_kernel(const float* __restrict__ qvec, int B, int T, int E, int Tplan, float* __restrict__ qbuf,
+                                    const long long* __restrict__ qlens, float* __restrict__ qlens_dst, const float* __restrict__ hc_src, int hc_n,
+                                    float* __restrict__ hc_dst, long long* __restrict__ nbt, int n_nbt) {
+    const int64_t nq = (int64_t)B * Tplan * E;
+    const int64_t total = nq + B + hc_n + n_nbt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nq) {
+            const int e = (int)(i % E);
+            const int t = (int)((i / E) % Tplan);
+            const int b = (int)(i / ((int64_t)E * Tplan));
+            qbuf[i] = t < T ? qvec[((int64_t)b * T + t) * E + e] : 0.f;
+        } else if (i < nq + B) {
+            qlens_dst[i - nq] = (float)qlens[i - nq];
+        } else if (i < nq + B + hc_n) {
+            hc_dst[i - nq - B] = hc_src[i - nq - B];
+        } else {
+            nbt[i - nq - B - hc_n] += 1;
+        }
+    }
+}
+extern "C" int zsg_stage_inputs(const float* qvec, int32_t B, int32_t T, int32_t E, int32_t Tplan, float* qbuf, const int64_t* qlens, float* qlens_dst,
+                                const float* hc_src, int32_t hc_n, float* hc_dst, int64_t* nbt, int32_t n_nbt, void* stream) {
+    ZSG_REQUIRE(qvec && qbuf && qlens && qlens_dst && B > 0 && T > 0 && T <= Tplan && E > 0 && hc_n >= 0 && n_nbt >= 0 && (!hc_n || (hc_src && hc_dst)) &&
+                    (!n_nbt || nbt), "stage_inputs: bad argument");
+    const int64_t total = (int64_t)B * Tplan * E + B + hc_n + n_nbt;
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("stage_inputs", st, 0, 8.0 * total);
+    ZSG_LAUNCH(stage_inputs_kernel, dim3(grid_for(total)), dim3(256), 0, st, qvec, B, T, E, Tplan, qbuf, (const long long*)qlens, qlens_dst, hc_src, hc_n, hc_dst,
+               (long long*)nbt, n_nbt);
+    ZSG_CHECK_LAUNCH("stage_inputs");
+    return 0;
+}
+
+// All pyramid levels of the map in ONE launch (round 5).  The valid taps of a pixel depend only on which image borders it touches:
+// row state (top, bottom) x column state (left, right) = 16 classes, the same for every level, so a block first builds the 16 class
+// sums S[cls][n] = sum_{tap valid in cls} V[b][n*9+tap] of ITS image in LDS (9 loads per channel instead of up to 36 scalar loads per
+// output element) and then streams out[b][p][n] = G[p][n] + S[cls(p)][n] with 16-byte accesses.  Levels are packed level-major
+// (level i of `out` starts at B * N * sum_{j<i} h_j w_j, of G at N * sum_{j<i} h_j w_j — mdl.Lowering.packed).
+struct LangMapLevels {
+    int nlev;
+    int h[ZSG_MAX_SEG], w[ZSG_MAX_SEG];
+    int p0[ZSG_MAX_SEG + 1];           // first pixel of level i within an image's pixel list (prefix sums of h * w)
+};
+__global__ __launch_bounds__(256) void head_lang_map_packed_kernel(const float* __restrict__ V, const float* __restrict__ G, int B, int N, LangMapLevels L,
+                                                                   float* __restrict__ out, int blocks_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float S[];      // [16][N]
+    const int b = blockIdx.x / blocks_per_image, part = blockIdx.x % blocks_per_image;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = V[(int64_t)b * N * 9 + (int64_t)n * 9 + t];
+#pragma unroll
+        for (int cls = 0; cls < 16; ++cls) {       // bit 0: top row, 1: bottom row, 2: left column, 3: right column
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if ((r == 0 && (cls & 1)) || (r == 2 && (cls & 2))) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if ((q == 0 && (cls & 4)) || (q == 2 && (cls & 8))) continue;
+                    a += v[r * 3 + q];
+                }
+            }
+            S[cls * N + n] = a;
+        }
+    }
+    __syncthreads();
+    const int n4 = N / 4, P = L.p0[L.nlev];
+    const int64_t total = (int64_t)P * n4;
+    for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < total; i += (int64_t)blocks_per_image * 256) {
+        const int c = (int)(i % n4) * 4;
+        const int p = (int)(i / n4);
+        int lv = 0;
+#pragma unroll
+        for (int j = 1; j < ZSG_MAX_SEG; ++j)
+            if (j < L.nlev && p >= L.p0[j]) lv = j;
+        const int q = p - L.p0[lv], w = L.w[lv], h = L.h[lv];
+        const int y = q / w, x = q - y * w;
+        const int cls = (y == 0 ? 1 : 0) | (y == h - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == w - 1 ? 8 : 0);
+        f32x4 acc = *(const f32x4*)(S + cls * N + c);
+        if (G) acc += *(const f32x4*)(G + ((int64_t)L.p0[lv] + q) * N + c);
+        *(f32x4*)(out + ((int64_t)B * L.p0[lv] + (int64_t)b * h * w + q) * N + c) = acc;
+    }
+}
+extern "C" int zsg_head_lang_map_packed(const float* V, const float* G, int32_t B, int32_t nlev, const int32_t* hw, int32_t N, float* out, void* stream) {
+    ZSG_REQUIRE(V && out && hw && B > 0 && nlev > 0 && nlev <= ZSG_MAX_SEG && N > 0 && (N % 4) == 0 && N <= 2048, "head_lang_map_packed: bad argument");
+    LangMapLevels L;
+    memset(&L, 0, sizeof(L));
+    L.nlev = nlev;
+    for (int i = 0; i < nlev; ++i) {
+        ZSG_REQUIRE(hw[2 * i] > 0 && hw[2 * i + 1] > 0, "head_lang_map_packed: level %d is empty", i);
+        L.h[i] = hw[2 * i];
+        L.w[i] = hw[2 * i + 1];
+        L.p0[i + 1] = L.p0[i] + L.h[i] * L.w[i];
+    }
+    const int64_t per = (int64_t)L.p0[nlev] * (N / 4);
+    int bpi = (int)((per + 256 * 8 - 1) / (256 * 8));          // ~8 16-byte elements per thread
+    const int cap = (4 * ZSG_NUM_CU + B - 1) / B;
+    if (bpi > cap) bpi = cap;
+    if (bpi < 1) bpi = 1;
+    hipStream_t st = (hipStream_t)stream;
+    ZSG_PROF("head_lang_map_packed", st, 0, (double)B * L.p0[nlev] * N * 4);
+    ZSG_LAUNCH(head_lang_map_packed_kernel, dim3(B * bpi), dim3(256), (size_t)16 * N * sizeof(float), st, V, G, B, N, L, out, bpi);
+    ZSG_CHECK_LAUNCH("head_lang_map_packed");
+    return 0;
+}
+
 // The nine validity-masked sums follow by inclusion-exclusion from nine plain sums per (image, channel):
 //   Q[0] = all pixels, Q[1]/Q[2] = first / last row, Q[3]/Q[4] = first / last column, Q[5..8] = the four corners;
 //   S(r,q) = Q0 - R(r) - C(q) + X(r,q)   with R(0) = first row (tap row 0 reads y-1: invalid at y = 0), R(2) = last row, ...

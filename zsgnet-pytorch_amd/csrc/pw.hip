@@ -462,6 +462,7 @@ static int pw_row_groups(const zsg_conv_desc* d, int uw, int ncb) {
 extern "C" int32_t zsg_conv_igemm_partial_rows(const zsg_conv_desc* d) {
     if (!d || !d->tile_hint) return -1;
     const int bm = d->tile_hint & 0xff, bn = (d->tile_hint >> 8) & 0xff;
+    if (bm == 32 && d->merge_x) return zsg_conv_mx_ok(d, nullptr) ? zsg_conv_mx_groups(d) : -1;
     if (bm == 32) {
         int ncb = 0;
         return pw_geometry_ok(d, bn, nullptr, &ncb) ? pw_row_groups(d, bn, ncb) : -1;

@@ -71,6 +71,8 @@ BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward s
 # BatchNorm statistics / backward sums FINALISED by the last-arriving tile of the producing convolution (csrc/bn_tail.h, round 5): no
 # finalize launch, no re-reduction in the apply pass, wherever the launch has <= 128 partial rows per column block ("0": rounds 1-4's
 # separate finalize / inline apply; "fwd" / "bwd": one direction only — A/B switches)
+FPN_ORDER_DEFAULT = "p6m"
+STAGE_INPUTS = os.environ.get("ZSG_STAGE_INPUTS", "1") != "0"      # (A/B: 0 = the separate torch copies of rounds 1-4)
 BN_TAIL = os.environ.get("ZSG_BN_TAIL", "1")
 BN_TAIL_MIN_ROWS = int(os.environ.get("ZSG_BN_TAIL_MIN_ROWS", "0"))      # (A/B: only launches with more partial rows than this finalise in-kernel)
 def prep_at() -> str:
@@ -481,6 +483,7 @@ class _Plan:
         self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
         self._bwd_fwd = -2               # fwd_id of the forward whose backward ran last (a second backward re-runs the preparation)
         self._rel_ev = torch.cuda.Event()
+        self._hc_pin, self._hc_ev = None, None      # pinned ring of host-drawn LSTM states (run_forward)
         self._prep_idx_v = False
         self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
@@ -1232,14 +1235,39 @@ class _Plan:
             # the laterals lowered early on the side stream (P3_1 under layer3, P4_1 under layer4) are joined HERE, in front of the pyramid's
             # own side-stream launches: a join waits for the whole side stream
             self._join_side()
+        # ZSG_FPN_ORDER (round 5; rocprofv3 showed the head's first convolution waiting 56 us for the side stream's chain P5_2 -> P4_2 -> P6 ->
+        # ReLU -> P7 -> pool, which only started behind P5_1): "p6" = the P6 chain (it reads C5 only) is released BEFORE P5_1; "p6m" = also
+        # P4_2 on the main stream; "0" = round 3's order.
+        order = os.environ.get("ZSG_FPN_ORDER", FPN_ORDER_DEFAULT)
+        p6_early = order in ("p6", "p6m") and not net.six_hundred and self.training
+        if p6_early:
+            # (P5_1 stays the consumer whose data gradient completes layer4's last BatchNorm dout — it carries that BatchNorm's backward
+            # sums, which the strided P6 cannot — so the chain's backward entries go BEHIND P5_1's on the tape: the tape is replayed in reverse)
+            keep, n0 = getattr(c5, "_consumed", False), len(self.tape)
+            c5._consumed = True
+            p6, p7, p8 = self._lower_p6_chain(c5, o6, o7, o8)
+            p6_tape = self.tape[n0:]
+            del self.tape[n0:]
+            c5._consumed = keep
         p51 = self.conv(C[f + "P5_1"], c5, name="p51")
+        if p6_early:
+            self.tape.extend(p6_tape)
         with self.on_side_stream():
             p5 = self.conv(C[f + "P5_2"], p51, out=o5)
         if t4 is None:
             t4 = self.conv(C[f + "P4_1"], c4, name="t4")
         p41 = self._upsample_add(t4, p51, "p41")
-        with self.on_side_stream():
+        if order == "p6m" and p6_early:
             p4 = self.conv(C[f + "P4_2"], p41, out=o4)
+        else:
+            with self.on_side_stream():
+                p4 = self.conv(C[f + "P4_2"], p41, out=o4)
+        if p6_early:
+            t3 = t3 if t3 is not None else self.conv(C[f + "P3_1"], c3, name="t3")
+            p31 = self._upsample_add(t3, p41, "p31")
+            p3 = self.conv(C[f + "P3_2"], p31, out=o3, name="p3")
+            self._join_side()
+            return [p3, p4, p5, p6, p7, p8]
         # (P3_1 / top-down add / the large P3_2 are lowered BEHIND the P6 -> P7 -> P8 chain: a side-stream launch waits for the main-stream
         # work enqueued before it, so in program order behind P3_2 the chain only started when P3_2 had finished and the head's first
         # convolution waited ~90 us for it; here it runs under P3_1 / P3_2)
@@ -1289,6 +1317,38 @@ class _Plan:
             p3 = lower_p3()
         self._join_side()
         return [p3, p4, p5, p6, p7, p8]
+
+    def _lower_p6_chain(self, c5: Act, o6: Act, o7: Act, o8: Act):
+        """P6 -> ReLU -> P7_2 -> global average pool (fpn_resnet.py:175-178 + mdl.py's P8) on the side stream"""
+        net, B = self.net, self.B
+        C = net.convs
+        f = "backbone.fpn."
+        with self.on_side_stream():
+            p6 = self.conv(C[f + "P6"], c5, out=o6)
+            r6 = self.act("r6", B, p6.levels[0].H, p6.levels[0].W, 256)
+            n6 = r6.buf.numel()
+            self.fwd.add(lib.zsg_relu_fwd, self.base(p6), n6, r6.buf, what="relu(p6)", lane=self._lane)
+
+            def relu_back():
+                if r6.grad is None:
+                    return
+                g = self.grad_of(p6)
+                self.bwd.add(lib.zsg_relu_bwd, self.base(r6.grad), self.base(p6), n6, self.base(g), int(g.gfilled), what="relu_bwd(p6)")
+                g.gfilled = True
+            self.tape.append(relu_back)
+            p7 = self.conv(C[f + "P7_2"], r6, out=o7)
+            l7 = p7.levels[0]
+            p8 = o8
+            self.fwd.add(lib.zsg_avgpool_fwd, self.base(p7), B, l7.H * l7.W, 256, self.base(p8), what="avgpool", lane=self._lane)
+
+            def avg_back():
+                if p8.grad is None:
+                    return
+                g = self.grad_of(p7)
+                self.bwd.add(lib.zsg_avgpool_bwd, self.base(p8.grad), B, l7.H * l7.W, 256, self.base(g), int(g.gfilled), what="avgpool_bwd")
+                g.gfilled = True
+            self.tape.append(avg_back)
+        return p6, p7, p8
 
     def _upsample_add(self, a: Act, p: Act, name: str, join: bool = False) -> Act:
         la, lp = a.levels[0], p.levels[0]
@@ -1458,9 +1518,10 @@ class _Plan:
                 dg = fwd_desc(gridmap, G, 4, 256, 3, 1, 1, 1, wC=cp, wc0=Cf + Cw)
                 self.fwd.add(lib.zsg_conv_igemm, dg, gridmap.buf, self.P(W0n), G.buf, None, None, None, None, what=prefix + "0.G", lane=side)
             lmap = self.packed(prefix + ".lmap", B, sizes, 256)
-            for i, (h, w) in enumerate(sizes):
-                self.fwd.add(lib.zsg_head_lang_map, V.buf, self.base(G.lvl(i)) if G is not None else None, B, h, w, 256,
-                             self.base(lmap.lvl(i)), what=f"lmap{i}", lane=side)
+            # every level in one launch (G and lmap are packed level-major with the same level list)
+            hw = torch.tensor([v for hw_ in sizes for v in hw_], dtype=torch.int32)
+            self.fwd.add(lib.zsg_head_lang_map_packed, V.buf, G.buf if G is not None else None, B, len(sizes), hw, 256, lmap.buf,
+                         what="lmap", lane=side)
             if side:
                 self._hoist.append((i0, len(self.fwd.calls)))
                 self._join_side()
@@ -1572,24 +1633,48 @@ class _Plan:
         if not u8 and img.dtype != torch.float32:
             img = img.float()
         T = qvec.shape[1]
-        qbuf = self.in_qvec.view(B, self.T, net.emb_dim)
-        qbuf[:, :T].copy_(qvec, non_blocking=True)
-        if T < self.T:
-            qbuf[:, T:].zero_()
-        self.in_qlens.copy_(qlens.reshape(B), non_blocking=True)
         nd = 2 if net.bid else 1
-        if h0.device.type == "cpu" and c0.device.type == "cpu":     # lstm_init_hidden's two host draws: one transfer
-            self.in_hc.view(2, nd, B, net.lstm_dim).copy_(torch.stack([h0.float(), c0.float()]), non_blocking=True)
+        host_hc = h0.device.type == "cpu" and c0.device.type == "cpu"
+        staged = (STAGE_INPUTS and host_hc and qvec.is_cuda and qvec.dtype == torch.float32 and qlens.is_cuda and qlens.dtype == torch.int64
+                  and qlens.numel() == B)
+        if staged:
+            # ONE launch for the whole input staging (qvec into the zero-padded token bucket, qlens, the host-drawn h0 | c0 read straight
+            # from a pinned ring slot, the BatchNorm counters): five torch operations with 5-20 us between them before (rocprofv3: 45 us
+            # at the head of every forward).  A ring slot is rewritten only after the launch that read it has finished.
+            if self._hc_pin is None:
+                self._hc_pin = torch.empty(8, 2, nd, B, net.lstm_dim).pin_memory()
+                self._hc_ev = [None] * 8
+            k = self.fwd_id % 8
+            if self._hc_ev[k] is not None:
+                self._hc_ev[k].synchronize()
+            torch.stack([h0.float(), c0.float()], out=self._hc_pin[k])
+            qv, ql = qvec.contiguous(), qlens.reshape(B).contiguous()
+            n_nbt = net._nbt.numel() if self.training else 0
+            check(lib.zsg_stage_inputs(qv.data_ptr(), B, T, net.emb_dim, self.T, self.in_qvec.data_ptr(), ql.data_ptr(), self.in_qlens.data_ptr(),
+                                       self._hc_pin[k].data_ptr(), self.in_hc.numel(), self.in_hc.data_ptr(),
+                                       net._nbt.data_ptr() if n_nbt else None, n_nbt, stream_ptr()), "stage_inputs")
+            if self._hc_ev[k] is None:
+                self._hc_ev[k] = torch.cuda.Event()
+            self._hc_ev[k].record(torch.cuda.current_stream())
+            self._in_keepalive = (qv, ql)
         else:
-            self.in_h0.view(nd, B, net.lstm_dim).copy_(h0, non_blocking=True)
-            self.in_c0.view(nd, B, net.lstm_dim).copy_(c0, non_blocking=True)
+            qbuf = self.in_qvec.view(B, self.T, net.emb_dim)
+            qbuf[:, :T].copy_(qvec, non_blocking=True)
+            if T < self.T:
+                qbuf[:, T:].zero_()
+            self.in_qlens.copy_(qlens.reshape(B), non_blocking=True)
+            if host_hc:     # lstm_init_hidden's two host draws: one transfer
+                self.in_hc.view(2, nd, B, net.lstm_dim).copy_(torch.stack([h0.float(), c0.float()]), non_blocking=True)
+            else:
+                self.in_h0.view(nd, B, net.lstm_dim).copy_(h0, non_blocking=True)
+                self.in_c0.view(nd, B, net.lstm_dim).copy_(c0, non_blocking=True)
         # patch the one dynamic pointer (the caller's image tensor)
         fn, args, what = self.fwd.calls[self.img_slot]
         import ctypes as C_
         self.fwd.calls[self.img_slot] = (fn, (C_.c_void_p(img.data_ptr()),) + args[1:], what)
         self._img_keepalive = img
         self.fwd_id += 1
-        if self.training:
+        if self.training and not staged:
             net._nbt.add_(1)
         assert self.img_slot == 0
         if not self.training and self.fold_jobs:       # the weights may have changed since the last eval forward: refold (one launch)

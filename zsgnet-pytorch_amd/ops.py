@@ -724,10 +724,15 @@ def pw_cands(d: ConvDesc) -> list:
     """tile hints (BM = 32, BN = unit width) of the filter-resident streaming kernel (csrc/pw.hip) for a 1x1 / stride-1 convolution
     whose filter — whole, or cut into 2 / 4 / 8 panels of output channels — fits a CU's LDS next to the eight wave buffers; the
     library decides (zsg_conv_igemm_partial_rows returns -1 where the kernel does not apply)."""
-    if d.nseg != 1 or d.merge_x or d.C % 64:
+    keep = d.tile_hint
+    if d.merge_x:       # the network's first convolution: the streaming kernel of csrc/mx.hip behind the same BM = 32 hint
+        d.tile_hint = tile_hint(32, 64, 1)
+        ok = d.nseg == 1 and lib.zsg_conv_igemm_partial_rows(C.byref(d)) > 0
+        d.tile_hint = keep
+        return [tile_hint(32, 64, 1)] if ok else []
+    if d.nseg != 1 or d.C % 64:
         return []
     out = []
-    keep = d.tile_hint
     for uw in (32, 64, 128):
         if d.N % uw == 0:
             d.tile_hint = tile_hint(32, uw, 1)
@@ -767,7 +772,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
                          mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
-                         os.environ.get("ZSG_PW", "1") != "0"))
+                         os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0")))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -785,8 +790,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                 cands.append(tile_hint(bm, bn, 1, 1))          # 8-wave workgroup (64x64: two K groups)
         if not d.merge_x and d.C % 64 == 0 and os.environ.get("ZSG_K64", "1") != "0":
             cands += [tile_hint(bm, bn, 1, w8) | K64_FLAG for bm, bn in tiles for w8 in (0, 1) if not (bm == 128 and bn == 128 and not w8)]
-        if fn is lib.zsg_conv_igemm and os.environ.get("ZSG_PW", "1") != "0":
-            cands += pw_cands(d)
+        if fn is lib.zsg_conv_igemm and os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"):
+            cands += pw_cands(d)          # (ZSG_MX=0: A/B switch for the streaming first-layer kernel alone)
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
         if dense and blocks64 < 1024 and not deterministic():
