@@ -162,6 +162,17 @@ int32_t zsg_conv_igemm_partial_rows(const zsg_conv_desc* d);
  * tickets must be ZERO at entry and are zero again when the launch ends (the caller allocates them zeroed once; one set per call
  * site, never shared between launches that may be in flight together). */
 int32_t zsg_conv_bn_tail_tickets(const zsg_conv_desc* d, int32_t is_wino);
+/* The 1x1 / stride-1 convolution that consumes a train-mode BatchNorm + residual + ReLU — the next bottleneck's conv1 behind bn3
+ * (fpn_resnet.py:86-100: `out = relu(bn3(conv3(..)) + residual)` ... `conv1(out)`) — applies that BatchNorm in its operand loader
+ * (round 5): `x` is the RAW conv3 output [rows][C]; the loader stages relu((x - pre_mean) * pre_invstd * pre_gamma + pre_beta +
+ * pre_residual), zsg_bn_apply's own arithmetic, and the first column tile's workgroups also write that activation to pre_y and its
+ * packed ReLU bits to pre_relu_mask (NULL: no bits) — the separate zsg_bn_apply launch and the second read of the activation
+ * disappear.  64x64 / 128x64 tiles with 32-deep K tiles only (tile_hint), C % 32 == 0, dense source.  bn_partials (optional): this
+ * convolution's own fused statistics; tickets != NULL: finalised in-kernel exactly as zsg_conv_igemm_bnstat does. */
+int zsg_conv_igemm_bnpre(const zsg_conv_desc* d, const float* x, const float* wt, float* out, float* bn_partials, uint32_t* tickets,
+                         float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
+                         const float* pre_mean, const float* pre_invstd, const float* pre_gamma, const float* pre_beta,
+                         const float* pre_residual, float* pre_y, uint8_t* pre_relu_mask, void* stream);
 /* zsg_conv_igemm / zsg_conv_wino with bn_partials (plain, bias-free convolution feeding a train-mode BatchNorm, fpn_resnet.py:86-97)
  * + in-kernel finalize: mean / invstd (and running statistics, momentum as torch.nn.BatchNorm2d; NULL to skip) are valid when the
  * launch ends; zsg_bn_apply follows directly. */
@@ -332,8 +343,8 @@ int zsg_head_lang_map(const float* V, const float* G, int32_t B, int32_t h, int3
 /* Per-forward input staging in one launch (round 5): what `batch[k].to(device)` of the trainer (utils.py:403-405), the zero padding of
  * the query bucket, lstm_init_hidden's host draws (mdl.py:279-294: hc_src = h0 | c0, hc_n floats, may be PINNED HOST memory) and the
  * BatchNorm layers' num_batches_tracked += 1 (n_nbt int64 counters; 0 in eval mode) do at the head of ZSGNet.forward.
- * qvec [B][T][E] device fp32 -> qbuf [B][Tplan][E] (zeros behind T); qlens int64 [B] -> qlens_dst float [B]. */
-int zsg_stage_inputs(const float* qvec, int32_t B, int32_t T, int32_t E, int32_t Tplan, float* qbuf, const int64_t* qlens, float* qlens_dst,
+ * qvec [B][T][E] device fp32 -> qbuf [B][Tplan][E] (zeros behind T); qlens [B] (int64, or fp32 when qlens_f32) -> qlens_dst float [B]. */
+int zsg_stage_inputs(const float* qvec, int32_t B, int32_t T, int32_t E, int32_t Tplan, float* qbuf, const void* qlens, int32_t qlens_f32, float* qlens_dst,
                      const float* hc_src, int32_t hc_n, float* hc_dst, int64_t* nbt, int32_t n_nbt, void* stream);
 /* the same map for ALL pyramid levels in one launch (round 5): `out` [B][h_i*w_i][N] per level, levels packed level-major (level i
  * starts at B * N * sum_{j<i} h_j w_j); G (or NULL) packed the same way with B = 1; hw = {h_0, w_0, h_1, w_1, ...} (host memory,

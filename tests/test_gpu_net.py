@@ -377,3 +377,38 @@ def test_query_length_buckets_share_one_plan(Z):
         long["h0"], long["c0"] = h0, c0
         o37 = net(long)["att_bbx_out"]
     assert len(net._plans) == 2 and float((o37 - outs[0]).abs().max()) < tol
+
+
+def test_one_launch_input_staging_equals_torch_copies(Z, monkeypatch):
+    """run_forward's one-launch input staging (zsg_stage_inputs: qvec into the zero-padded token bucket, qlens int64 / float, the
+    host-drawn h0 | c0 from a pinned ring slot, num_batches_tracked += 1) stages exactly what the separate torch copies of rounds 1-4
+    staged: staged buffers, BatchNorm counters and network outputs bit-identical, for T below the bucket size, across more forwards
+    than the ring has slots."""
+    config, evaluator, loss, mdl, optim = Z
+    cfg, net, sd, lf, ev = build(Z, arch="resnet18", seed=5)
+    net.train()
+    bt = O.synthetic_batch(3, 96, 96, seed=12, tmax=13)
+    T = int(bt["qlens"].max())
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(mdl, "STAGE_INPUTS", mode)
+        net.load_state_dict(sd)
+        outs = []
+        torch.manual_seed(3)
+        for it in range(11):
+            inp = to_dev({**bt, "qvec": bt["qvec"][:, :T].contiguous()})
+            if it % 2:
+                inp["qlens"] = inp["qlens"].long()
+            h0, c0 = net.lstm_init_hidden(3)          # the reference's two host draws (mdl.py:279-294)
+            inp["h0"], inp["c0"] = h0, c0
+            with torch.no_grad():
+                o = net(inp)["att_bbx_out"].clone()
+            plan = next(iter(net._plans.values()))
+            outs.append((o, plan.in_qvec.clone(), plan.in_qlens.clone(), plan.in_hc.clone(), h0, c0))
+        res[mode] = (outs, net._nbt.clone())
+    assert int(res[True][1][0]) == int(res[False][1][0]) and torch.equal(res[True][1], res[False][1]), "num_batches_tracked"
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]), "same host draws in both modes"
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), "staged qvec / qlens / h0|c0"
+        assert torch.equal(a[3].cpu().view(2, -1), torch.stack([a[4], a[5]]).view(2, -1))
+        assert float((a[0] - b[0]).abs().max()) <= 1e-5 * float(b[0].abs().max())

@@ -408,6 +408,79 @@ def test_conv_mx_streaming(Z, case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", [(2, 256, 64, 19, 19), (3, 512, 128, 10, 13), (16, 256, 64, 75, 75), (2, 1024, 256, 19, 19)], ids=["l1", "l2", "l1bench", "l3"])
+def test_conv_igemm_bnpre(Z, case):
+    """zsg_conv_igemm_bnpre — the next bottleneck's conv1 applying the previous block's bn3 + residual + ReLU in its operand loader and
+    materialising the activation itself — against the unfused pair zsg_bn_apply -> zsg_conv_igemm on the same operands: the
+    materialised activation and its packed ReLU bits must be zsg_bn_apply's (same arithmetic: equal to 1 ulp of fp32 contraction),
+    the convolution output and its fused statistics equal to summation-order accuracy, for every tile the entry accepts, with and
+    without the in-kernel finalize; and against torch-CPU fp32 for the whole chain."""
+    L, ops = Z
+    B, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(31 + Ci + H)
+    rows = B * H * W
+    x = torch.randn(rows, Ci, generator=g) * 2 + 0.3
+    res = torch.randn(rows, Ci, generator=g)
+    gam, bet = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.2
+    mean = x.mean(0)
+    invstd = 1 / torch.sqrt(x.var(0, unbiased=False) + 1e-5)
+    w = torch.randn(Co, Ci, generator=g) / Ci ** 0.5
+    y_t = torch.relu((x - mean) * (invstd * gam) + bet + res)
+    o_t = y_t @ w.t()
+    st = L.stream_ptr()
+    xd, rd, gd, bd, md, isd, wd = dev(x), dev(res), dev(gam), dev(bet), dev(mean), dev(invstd), dev(w.view(Co, 1, 1, Ci))
+    y0 = torch.full((rows, Ci), float("nan"), device="cuda")
+    m0 = torch.zeros(rows * Ci // 4, dtype=torch.uint8, device="cuda")
+    L.check(L.lib.zsg_bn_apply(xd.data_ptr(), rows, Ci, md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rd.data_ptr(), 1, y0.data_ptr(),
+                               m0.data_ptr(), st), "bn_apply")
+    assert_close(y0, y_t, 1e-5, 1e-5, "bn_apply vs torch")
+    src0 = view_of(ops, y0, B, H, W, Ci)
+    o0 = torch.full((rows, Co), float("nan"), device="cuda")
+    d0 = ops.fwd_desc(src0, view_of(ops, o0, B, H, W, Co), Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=ops.tile_hint(64, 64, 1))
+    L.check(L.lib.zsg_conv_igemm(C.byref(d0), y0.data_ptr(), wd.data_ptr(), o0.data_ptr(), None, None, None, None, st), "plain conv")
+    assert_close(o0, o_t, 2e-4, 2e-4 * float(o_t.abs().max()), "unfused chain vs torch")
+    of = o0.double()
+    for bm, bn_, w8 in ((64, 64, 0), (64, 64, 1), (128, 64, 0), (128, 64, 1), (128, 128, 0), (128, 128, 1)):
+        if bn_ == 128 and Co < 128:
+            continue
+        hint = ops.tile_hint(bm, bn_, 1, w8)
+        for tail in (False, True):
+            y1 = torch.full((rows, Ci), float("nan"), device="cuda")
+            m1 = torch.full((rows * Ci // 4,), 0xAA, dtype=torch.uint8, device="cuda")
+            o1 = torch.full((rows, Co), float("nan"), device="cuda")
+            d1 = ops.fwd_desc(view_of(ops, xd, B, H, W, Ci), view_of(ops, o1, B, H, W, Co), Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=hint)
+            chunks = ops.igemm_partial_rows(d1)
+            part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
+            tk = torch.zeros(64, dtype=torch.int32, device="cuda")
+            mo, io = torch.full((Co,), float("nan"), device="cuda"), torch.full((Co,), float("nan"), device="cuda")
+            ntk = int(L.lib.zsg_conv_bn_tail_tickets(C.byref(d1), 0))
+            use_tail = tail and ntk > 0
+            if tail and not use_tail:
+                continue
+            L.check(L.lib.zsg_conv_igemm_bnpre(C.byref(d1), xd.data_ptr(), wd.data_ptr(), o1.data_ptr(), part.data_ptr(),
+                                               tk.data_ptr() if use_tail else None, mo.data_ptr(), io.data_ptr(), None, None, 0.1, 1e-5,
+                                               md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y1.data_ptr(), m1.data_ptr(), st),
+                    f"bnpre {bm}x{bn_} w8={w8} tail={tail}")
+            what = f"{bm}x{bn_} w8={w8} tail={use_tail}"
+            assert not torch.isnan(y1).any() and not torch.isnan(o1).any()
+            assert_close(y1, y0, 2e-7, 2e-7, "materialised activation " + what)
+            flips = int((m1 != m0).sum())
+            assert flips <= rows * Ci // 4 // 100000 + 2, f"ReLU bits {what}: {flips} bytes differ"      # (a value within an ulp of 0)
+            assert_close(o1, o0, 1e-5, 1e-5 * float(o0.abs().max()), "convolution output " + what)
+            assert_close(part[:, 0].double().sum(0), of.sum(0), 1e-4, 1e-4 * float(of.abs().sum(0).max()), "fused sums " + what)
+            assert_close(part[:, 1].double().sum(0), (of * of).sum(0), 1e-4, 1e-6, "fused sums of squares " + what)
+            if use_tail:
+                assert_close(mo, of.mean(0), 1e-4, 1e-5, "in-kernel mean " + what)
+                assert_close(io, 1 / torch.sqrt(of.var(0, unbiased=False) + 1e-5), 2e-4, 0, "in-kernel invstd " + what)
+                assert int(tk.abs().sum()) == 0, "tickets must be zero again"
+    # refused configurations fail loudly
+    dbad = ops.fwd_desc(view_of(ops, xd, B, H, W, Ci), view_of(ops, o0, B, H, W, Co), Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=ops.tile_hint(64, 64, 1) | (1 << 27))      # (64-deep K tiles)
+    rc = L.lib.zsg_conv_igemm_bnpre(C.byref(dbad), xd.data_ptr(), wd.data_ptr(), o0.data_ptr(), None, None, None, None, None, None, 0.1, 1e-5,
+                                    md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y0.data_ptr(), None, st)
+    assert rc != 0
+    torch.cuda.synchronize()
+
+
 def test_conv_multilevel_shared_weights(Z):
     """grouped launch over pyramid levels (shared head), output scattered into the [B, A, 5]-style buffer"""
     L, ops = Z

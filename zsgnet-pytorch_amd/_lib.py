@@ -64,6 +64,7 @@ SIGNATURES = {
     "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
     "zsg_conv_igemm_partial_rows": (I32, [DP]),
     "zsg_conv_bn_tail_tickets": (I32, [DP, I32]),
+    "zsg_conv_igemm_bnpre": (I32, [DP, P, P, P, P, P, P, P, P, P, F32, F32, P, P, P, P, P, P, P, P]),
     "zsg_conv_igemm_bnstat": (I32, [DP, P, P, P, P, P, P, P, P, P, F32, F32, P]),
     "zsg_conv_wino_bnstat": (I32, [DP, P, P, P, P, P, P, P, P, P, F32, F32, P]),
     "zsg_conv_igemm_bnb_tail": (I32, [DP, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P]),
@@ -107,7 +108,7 @@ SIGNATURES = {
     "zsg_interleave": (I32, [P, I64, I32, I32, P, I32, I32, I32, P]),
     "zsg_head_lang_map": (I32, [P, P, I32, I32, I32, I32, P, P]),
     "zsg_head_lang_map_packed": (I32, [P, P, I32, I32, P, I32, P, P]),
-    "zsg_stage_inputs": (I32, [P, I32, I32, I32, I32, P, P, P, P, I32, P, P, I32, P]),
+    "zsg_stage_inputs": (I32, [P, I32, I32, I32, I32, P, P, I32, P, P, I32, P, P, I32, P]),
     "zsg_head_border_sums": (I32, [P, I32, I32, I32, I32, P, P]),
     "zsg_head_border_finalize": (I32, [P, I32, I32, P, P, P, P]),
     "zsg_batch_sum": (I32, [P, I32, I64, P, P]),

@@ -33,6 +33,21 @@ struct IgSegDev {
     zsg_taps ty, tx;
 };
 
+// The producer BatchNorm applied by the operand loader (round 5, template flag PRE): `src` is the RAW output x of the previous block's last
+// convolution; the loader stages relu((x - mean) * invstd * gamma + beta + residual) — exactly what zsg_bn_apply writes — and the
+// blocks of the first column tile also write that activation (y) and its packed ReLU bits out, so that the separate apply launch
+// (read x + residual, write y: 280 MB at layer1's size, then y read again by this convolution) disappears.  1x1 / stride-1 dense
+// convolutions only: a source element belongs to exactly one row of the GEMM.
+struct IgPre {
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* residual;      // same [rows][C] layout as src
+    float* y;                   // the materialised activation (same layout) — the residual of the next block, the weight gradient's input
+    unsigned char* mask;        // 4 ReLU bits per 16-byte group, as zsg_bn_apply writes them (or nullptr)
+};
+
 struct IgParams {
     const float* src;
     const float* wt;
@@ -51,6 +66,7 @@ struct IgParams {
     int add_is_out;   // add_src aliases out (accumulate): with split-K the existing values are simply added to
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     BnTail tail;      // tail.tickets != nullptr: the last-arriving tile of a column block finalises the statistics (bn_tail.h)
+    IgPre pre;        // PRE kernels only
     IgSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -67,8 +83,9 @@ struct IgParams {
 // __launch_bounds__' second argument (two waves per SIMD = at most 256 registers per lane): without it hipcc parks the accumulators
 // of the 4-wave tiles in AGPRs and copies one tile in and out of them every K step (32 v_accvgpr moves per 16 MFMAs — VALU-class
 // instructions that are paid in full next to fp32 MFMAs).  The 64-deep 128x128 4-wave tile needs more than 256 registers.
-template <int BM, int BN, int NW, bool MERGE_X, int KS = 1, int BK = IG_BK>
+template <int BM, int BN, int NW, bool MERGE_X, int KS = 1, int BK = IG_BK, bool PRE = false>
 __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && NW * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
+    static_assert(!PRE || !MERGE_X, "the BatchNorm-applying loader is for 1x1 convolutions");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per K group");
     constexpr int WM = (NW == 8 && BN == 64) ? 4 : 2, WN = NW / WM;     // the wave grid over the tile
     constexpr int NB = 2;                    // LDS tile buffers
@@ -111,6 +128,8 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
 
     // ---- per-row gather state (fixed for the whole K loop) --------------------------------------------------
     int a_by[RA], a_bx[RA], a_off[RA];   // a_off: element offset of the row's tap (0, 0) pixel — a tap adds a WAVE-UNIFORM offset
+    constexpr int RPRE = PRE ? RA : 1;
+    unsigned pre_off[RPRE];              // PRE: byte offset of the row's channel 0 in src / residual / y (out of range for dead rows)
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int m = m0 + r0 + RP * j;
@@ -124,6 +143,7 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
         a_by[j] = ok ? (y * sg.sy + sg.ty.d0) : -(1 << 28);      // invalid rows fail the bounds test for every tap
         a_bx[j] = x * sg.sx + sg.tx.d0;
         a_off[j] = ok ? sg.src_off + b * sg.src_bstride + (a_by[j] * sg.src_W + a_bx[j]) * p.src_ld : 0;
+        if constexpr (PRE) pre_off[j] = ok ? 4u * (unsigned)a_off[j] : ZSG_OOB;
         if (g == 0)
             rowout[r0 + RP * j] =
                 ok ? sg.out_off + b * sg.out_bstride + ((y * sg.osy + sg.opy) * sg.out_W + (x * sg.osx + sg.opx)) * p.out_ld
@@ -152,6 +172,11 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     // igemm_model.py) and the step lost 1.6 % to the registers (14.32 -> 14.55 ms): not what the K loop waits for.
     constexpr int NS = 2;
     f32x4 ra[NS][RA], rb[NS][RB];
+    f32x4 rres[NS][RPRE], pvec[NS][3];   // PRE: the residual rows of a stage; (mean, invstd * gamma, beta) of its four channels
+    int pch[NS];                         // PRE: the stage's first channel (bytes), or -1 past the last K tile
+    const rsrc_t rsrc_res = make_rsrc(PRE ? (const void*)p.pre.residual : (const void*)p.src);
+    const rsrc_t rsrc_y = make_rsrc(PRE ? (const void*)p.pre.y : (const void*)p.src);
+    const rsrc_t rsrc_pm = make_rsrc(PRE && p.pre.mask ? (const void*)p.pre.mask : (const void*)p.src);
     const rsrc_t rsrc_a = make_rsrc(p.src);
     const rsrc_t rsrc_b = make_rsrc(p.wt);
     // K-iteration counters of the NEXT tile to load (wave-uniform)
@@ -166,7 +191,7 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
     // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
     // outstanding loads exactly (a branch made it wait for ALL of them, vmcnt(0), before parking the previous tile).
-    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], bool live) {
+    auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], bool live, int stg = 0) {
         if ((IG_ABL & 2) && in_loop) return;
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
@@ -213,6 +238,17 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
             for (int j = 0; j < RA; ++j) ra[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_vo[j], so_a, 0));
 #pragma unroll
             for (int j = 0; j < RB; ++j) rb[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_vo[j], so_b, 0));
+            if constexpr (PRE) {          // (1x1: the K tile's channels are so_a / 4 + 4 g .. + 3)
+                pch[stg] = live ? so_a + 16 * g : -1;
+#pragma unroll
+                for (int j = 0; j < RA; ++j)
+                    rres[stg][j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_res, (int)(live ? pre_off[j] + 16u * (unsigned)g : ZSG_OOB), so_a, 0));
+                const int c = (so_a >> 2) + 4 * g;
+                const int cs = live ? c : 0;
+                pvec[stg][0] = *(const f32x4*)(p.pre.mean + cs);
+                pvec[stg][1] = *(const f32x4*)(p.pre.invstd + cs) * *(const f32x4*)(p.pre.gamma + cs);
+                pvec[stg][2] = *(const f32x4*)(p.pre.beta + cs);
+            }
             so_a += 4 * BK;
             so_b += 4 * BK;
         } else {                          // (the 7x7x4 stem: one K tile per filter row, nothing to carry between tiles)
@@ -237,10 +273,42 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
             }
         }
     };
-    auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB], int stg = 0) {
         if ((IG_ABL & 4) && in_loop) return;
         float* a = As + buf * BM * LDR;
         float* b = Bs + buf * BN * LDR;
+        if constexpr (PRE) {
+            // the producer BatchNorm + residual + ReLU, in zsg_bn_apply's own arithmetic; dead rows / dead tiles stage exact zeros (the
+            // fused statistics of THIS convolution rely on it).  Column tile 0 materialises the activation and its ReLU bits.
+            const bool tlive = pch[stg] >= 0;
+            const bool wr = tlive & (nt == 0);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                f32x4 v = (ra[j] - pvec[stg][0]) * pvec[stg][1] + pvec[stg][2];
+                v += rres[stg][j];
+                const unsigned bits = (unsigned)(v[0] > 0.f) | ((unsigned)(v[1] > 0.f) << 1) | ((unsigned)(v[2] > 0.f) << 2) | ((unsigned)(v[3] > 0.f) << 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                const bool ok = tlive & (pre_off[j] != ZSG_OOB);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+                const unsigned off = (wr & ok) ? pre_off[j] + (unsigned)pch[stg] : ZSG_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, (int)off, 0, 0);
+                if (p.pre.mask) {
+                    // the KG = 8 threads of a tile row hold 8 consecutive mask bytes: gathered into one 8-byte store by the row's first thread
+                    static_assert(KG == 8, "mask packing assumes 8 16-byte groups per K tile row");
+                    unsigned lo = bits << (8 * (g & 3)), hi;
+                    lo |= __shfl_xor(lo, 1, 64);
+                    lo |= __shfl_xor(lo, 2, 64);
+                    hi = __shfl_xor(lo, 4, 64);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 pk = {lo, hi};
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, rsrc_pm, (int)((off == ZSG_OOB || g != 0) ? ZSG_OOB : off >> 4), 0, 0);
+                }
+                *(f32x4*)(a + (r0 + RP * j) * LDR + 4 * g) = v;
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < RA; ++j) *(f32x4*)(a + (r0 + RP * j) * LDR + 4 * g) = ra[j];
 #pragma unroll
@@ -257,10 +325,10 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
 
     in_loop = false;
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
-        load_tile(ra[0], rb[0], true);
-        store_tile(0, ra[0], rb[0]);
+        load_tile(ra[0], rb[0], true, 0);
+        store_tile(0, ra[0], rb[0], 0);
 #pragma unroll
-        for (int st = 0; st < NS - 1; ++st) load_tile(ra[st], rb[st], n_it > st + 1);      // tiles 1 .. NS-1 stay in flight
+        for (int st = 0; st < NS - 1; ++st) load_tile(ra[st], rb[st], n_it > st + 1, st);      // tiles 1 .. NS-1 stay in flight
     }
     __syncthreads();
 
@@ -270,8 +338,8 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
 
     // one K tile: prefetch tile it+NS into `nxt` (the stage tile `it` has left), MFMA on LDS[it&1], then park tile it+1 (in `cur`,
     // requested NS-1 steps ago) in the other LDS buffer.
-    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB]) {
-        load_tile(nxt_a, nxt_b, it + NS < n_it);
+    auto k_step = [&](int it, f32x4 (&cur_a)[RA], f32x4 (&cur_b)[RB], f32x4 (&nxt_a)[RA], f32x4 (&nxt_b)[RB], int cur_s, int nxt_s) {
+        load_tile(nxt_a, nxt_b, it + NS < n_it, nxt_s);
         const float* a = As + (it & 1) * BM * LDR + a_row * LDR + 4 * lh;
         const float* b = Bs + (it & 1) * BN * LDR + b_row * LDR + 4 * lh;
 #pragma unroll
@@ -304,14 +372,14 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
                     for (int j = 0; j < TN; ++j) acc[i][j][0] += fa[i][0] * fb[j][0];      // (keeps the fragment reads alive)
             }
         }
-        store_tile((it + 1) & 1, cur_a, cur_b);      // (after the last tile: zeros into the idle buffer)
+        store_tile((it + 1) & 1, cur_a, cur_b, cur_s);      // (after the last tile: zeros into the idle buffer)
         if (!(IG_ABL & 16)) __syncthreads();
     };
     in_loop = true;
     for (int it = 0; it < n_it; it += NS) {
 #pragma unroll
         for (int st = 0; st < NS; ++st)
-            if (it + st < n_it) k_step(it + st, ra[st], rb[st], ra[(st + NS - 1) % NS], rb[(st + NS - 1) % NS]);
+            if (it + st < n_it) k_step(it + st, ra[st], rb[st], ra[(st + NS - 1) % NS], rb[(st + NS - 1) % NS], st, (st + NS - 1) % NS);
     }
 
     // ---- K groups: sum the accumulators into group 0 (fixed order) -----------------------------------------------------------
@@ -593,7 +661,7 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int NW, bool MX, int KS, int BK>
+template <int BM, int BN, int NW, bool MX, int KS, int BK, bool PRE = false>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + BM * sizeof(int);
     static bool attr_done[ZSG_MAX_DEV] = {};      // per device; idempotent (a benign race sets it twice)
@@ -601,18 +669,25 @@ static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const ch
     (void)hipGetDevice(&dev);
     ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "igemm: device %d", dev);
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, MX, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, MX, KS, BK, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, p.alg_bytes);
-    ZSG_LAUNCH((igemm_kernel<BM, BN, NW, MX, KS, BK>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * NW * KS), lds, st, p);
+    ZSG_LAUNCH((igemm_kernel<BM, BN, NW, MX, KS, BK, PRE>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * NW * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
 }
 // p.bk64 selects the 64-deep K tile (profile name = kname + "+k64")
 template <int BM, int BN, int NW, bool MX, int KS = 1>
 static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const char* kname) {
+    if constexpr (!MX) {
+        if (p.pre.y) {                   // the BatchNorm-applying loader (32-deep K tiles; profile name = kname + "+pre")
+            static char nm[96];
+            snprintf(nm, sizeof(nm), "%s+pre", kname);
+            return launch_cfg1<BM, BN, NW, MX, KS, IG_BK, true>(p, st, flops, nm);
+        }
+    }
     if constexpr (!MX) {
         if (p.bk64) {
             static char nm[96];
@@ -657,12 +732,24 @@ static void pick_tile(const zsg_conv_desc* d, int* BM, int* BN, int* splits, int
 
 static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias,
                            const float* add_src, const float* mask_src, float* bn_partials, const BnbDev* bnb, void* stream,
-                           const BnTail* tail = nullptr) {
+                           const BnTail* tail = nullptr, const IgPre* pre = nullptr) {
     ZSG_REQUIRE(d && src && wt && out, "conv_igemm: null argument");
     int BM = 64, BN = 64, splits = 1, w8 = 0;
     pick_tile(d, &BM, &BN, &splits, &w8);
     if (d->merge_x && BN == 128) BN = 64;
     if (d->merge_x) w8 = 0;
+    if (pre) {
+        const zsg_seg& s0 = d->seg[0];
+        ZSG_REQUIRE(pre->mean && pre->invstd && pre->gamma && pre->beta && pre->residual && pre->y, "conv_igemm_bnpre: null argument");
+        ZSG_REQUIRE(d->nseg == 1 && !d->merge_x && s0.ty.n == 1 && s0.tx.n == 1 && s0.ty.d0 == 0 && s0.tx.d0 == 0 && s0.sy == 1 && s0.sx == 1 &&
+                        s0.src_H == s0.rows_y && s0.src_W == s0.rows_x && d->src_ld == d->C && s0.src_off == 0 &&
+                        s0.src_bstride == (int64_t)s0.src_H * s0.src_W * d->src_ld && d->wc0 == 0 && d->wC == d->C && (d->C % IG_BK) == 0,
+                    "conv_igemm_bnpre: a 1x1 / stride-1 convolution over a dense [rows][C] source with C %% 32 == 0");
+        ZSG_REQUIRE(BM != 32 && splits <= 1 && !((d->tile_hint >> 27) & 1) && !bnb && !bias && !add_src && !mask_src && !d->relu,
+                    "conv_igemm_bnpre: implicit-GEMM tiles with 32-deep K tiles, no split-K, plain epilogue");
+        const uintptr_t al = (uintptr_t)pre->mean | (uintptr_t)pre->invstd | (uintptr_t)pre->gamma | (uintptr_t)pre->beta | (uintptr_t)pre->residual | (uintptr_t)pre->y;
+        ZSG_REQUIRE((al & 15) == 0, "conv_igemm_bnpre: operands not 16-byte aligned");
+    }
     if (BM == 32 && d->merge_x) {                 // the filter-resident streaming kernel of the network's first convolution (mx.hip)
         ZSG_REQUIRE(splits <= 1 && !tail && !bnb, "conv_igemm: the streaming first-layer kernel has no split-K / in-kernel finalize / bnb variant");
         return zsg_conv_mx_launch(d, src, wt, out, bias, add_src, mask_src, bn_partials, (hipStream_t)stream);
@@ -683,6 +770,10 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     p.stats = bn_partials;
     p.alg_bytes = zsg_conv_alg_bytes(d, add_src != nullptr);
     p.bk64 = ((d->tile_hint >> 27) & 1) && !d->merge_x;
+    if (pre) {
+        p.pre = *pre;
+        p.alg_bytes += 4.0 * 2.0 * (double)d->B * d->seg[0].src_H * d->seg[0].src_W * d->C;      // + the residual read and the activation written
+    }
 
     {
         bool v = (d->out_ld % 4) == 0 && (d->N % 4) == 0;
@@ -750,6 +841,26 @@ extern "C" int zsg_conv_igemm_bnb(const zsg_conv_desc* d, const float* src, cons
                                   float* partials, void* stream) {
     BnbDev b = {bn_x, bn_mean, bn_invstd, bn_relu_mask};
     return conv_igemm_impl(d, src, wt, out, nullptr, add_src, nullptr, partials, &b, stream);
+}
+
+// The 1x1 convolution that CONSUMES a train-mode BatchNorm + residual + ReLU (the next bottleneck's conv1 behind bn3, fpn_resnet.py:
+// 86-100) applies it in its operand loader and materialises the activation itself (IgPre): `x` is the previous block's raw conv3
+// output.  Optional fused statistics of THIS convolution's output: bn_partials, and (tickets != NULL) their in-kernel finalize
+// exactly as zsg_conv_igemm_bnstat.
+extern "C" int zsg_conv_igemm_bnpre(const zsg_conv_desc* d, const float* x, const float* wt, float* out, float* bn_partials, uint32_t* tickets,
+                                    float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
+                                    const float* pre_mean, const float* pre_invstd, const float* pre_gamma, const float* pre_beta,
+                                    const float* pre_residual, float* pre_y, uint8_t* pre_relu_mask, void* stream) {
+    IgPre pre = {pre_mean, pre_invstd, pre_gamma, pre_beta, pre_residual, pre_y, pre_relu_mask};
+    if (tickets) {
+        ZSG_REQUIRE(mean && invstd && bn_partials, "conv_igemm_bnpre: null argument");
+        BnTail t;
+        memset(&t, 0, sizeof(t));
+        t.tickets = tickets; t.mean = mean; t.invstd = invstd; t.rmean = running_mean; t.rvar = running_var;
+        t.momentum = momentum; t.eps = eps; t.mode = 0;
+        return conv_igemm_impl(d, x, wt, out, nullptr, nullptr, nullptr, bn_partials, nullptr, stream, &t, &pre);
+    }
+    return conv_igemm_impl(d, x, wt, out, nullptr, nullptr, nullptr, bn_partials, nullptr, stream, nullptr, &pre);
 }
 
 // ---- in-kernel BatchNorm finalize (bn_tail.h) ---------------------------------------------------------------------------------

@@ -724,10 +724,10 @@ extern "C" int zsg_head_lang_map(const float* V, const float* G, int32_t B, int3
 // The per-forward input staging of ZSGNet.forward in ONE launch (round 5): the reference moves qvec / qlens to the device and draws the
 // LSTM's initial state on the host every forward (utils.py:403-405, mdl.py:279-294); as separate torch copies + the BatchNorm counters'
 // `add_` these were five ~5 us operations with 5-20 us between them at the head of every forward (rocprofv3: 45 us).  One kernel:
-//   qbuf[b][t][:] = t < T ? qvec[b][t][:] : 0   (the plan's zero-padded token bucket);   qlens (int64) -> float;
+//   qbuf[b][t][:] = t < T ? qvec[b][t][:] : 0   (the plan's zero-padded token bucket);   qlens (int64 or float) -> float;
 //   hc_dst = hc_src (h0 | c0; hc_src may be PINNED HOST memory: read over the bus by this kernel, no copy engine);   nbt[i] += 1.
 __global__ void stage_inputs_kernel(const float* __restrict__ qvec, int B, int T, int E, int Tplan, float* __restrict__ qbuf,
-                                    const long long* __restrict__ qlens, float* __restrict__ qlens_dst, const float* __restrict__ hc_src, int hc_n,
+                                    const void* __restrict__ qlens, int qlens_f32, float* __restrict__ qlens_dst, const float* __restrict__ hc_src, int hc_n,
                                     float* __restrict__ hc_dst, long long* __restrict__ nbt, int n_nbt) {
     const int64_t nq = (int64_t)B * Tplan * E;
     const int64_t total = nq + B + hc_n + n_nbt;
@@ -738,7 +738,7 @@ __global__ void stage_inputs_kernel(const float* __restrict__ qvec, int B, int T
             const int b = (int)(i / ((int64_t)E * Tplan));
             qbuf[i] = t < T ? qvec[((int64_t)b * T + t) * E + e] : 0.f;
         } else if (i < nq + B) {
-            qlens_dst[i - nq] = (float)qlens[i - nq];
+            qlens_dst[i - nq] = qlens_f32 ? ((const float*)qlens)[i - nq] : (float)((const long long*)qlens)[i - nq];
         } else if (i < nq + B + hc_n) {
             hc_dst[i - nq - B] = hc_src[i - nq - B];
         } else {
@@ -746,14 +746,14 @@ __global__ void stage_inputs_kernel(const float* __restrict__ qvec, int B, int T
         }
     }
 }
-extern "C" int zsg_stage_inputs(const float* qvec, int32_t B, int32_t T, int32_t E, int32_t Tplan, float* qbuf, const int64_t* qlens, float* qlens_dst,
+extern "C" int zsg_stage_inputs(const float* qvec, int32_t B, int32_t T, int32_t E, int32_t Tplan, float* qbuf, const void* qlens, int32_t qlens_f32, float* qlens_dst,
                                 const float* hc_src, int32_t hc_n, float* hc_dst, int64_t* nbt, int32_t n_nbt, void* stream) {
     ZSG_REQUIRE(qvec && qbuf && qlens && qlens_dst && B > 0 && T > 0 && T <= Tplan && E > 0 && hc_n >= 0 && n_nbt >= 0 && (!hc_n || (hc_src && hc_dst)) &&
                     (!n_nbt || nbt), "stage_inputs: bad argument");
     const int64_t total = (int64_t)B * Tplan * E + B + hc_n + n_nbt;
     hipStream_t st = (hipStream_t)stream;
     ZSG_PROF("stage_inputs", st, 0, 8.0 * total);
-    ZSG_LAUNCH(stage_inputs_kernel, dim3(grid_for(total)), dim3(256), 0, st, qvec, B, T, E, Tplan, qbuf, (const long long*)qlens, qlens_dst, hc_src, hc_n, hc_dst,
+    ZSG_LAUNCH(stage_inputs_kernel, dim3(grid_for(total)), dim3(256), 0, st, qvec, B, T, E, Tplan, qbuf, qlens, qlens_f32, qlens_dst, hc_src, hc_n, hc_dst,
                (long long*)nbt, n_nbt);
     ZSG_CHECK_LAUNCH("stage_inputs");
     return 0;

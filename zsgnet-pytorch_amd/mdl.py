@@ -72,6 +72,9 @@ BNB_FUSE = os.environ.get("ZSG_BNB_FUSE", "1") != "0"     # BatchNorm-backward s
 # finalize launch, no re-reduction in the apply pass, wherever the launch has <= 128 partial rows per column block ("0": rounds 1-4's
 # separate finalize / inline apply; "fwd" / "bwd": one direction only — A/B switches)
 FPN_ORDER_DEFAULT = "p6m"
+# bn3 + residual + ReLU of a bottleneck applied by the NEXT block's conv1 (zsg_conv_igemm_bnpre) instead of a zsg_bn_apply launch, where the
+# activation is at least this large (MB; 0 = never): the apply pass is HBM-bound there and the consumer would read its output again
+BN_PRE_MIN_MB = float(os.environ.get("ZSG_BN_PRE_MIN_MB", "40"))
 STAGE_INPUTS = os.environ.get("ZSG_STAGE_INPUTS", "1") != "0"      # (A/B: 0 = the separate torch copies of rounds 1-4)
 BN_TAIL = os.environ.get("ZSG_BN_TAIL", "1")
 BN_TAIL_MIN_ROWS = int(os.environ.get("ZSG_BN_TAIL_MIN_ROWS", "0"))      # (A/B: only launches with more partial rows than this finalise in-kernel)
@@ -646,6 +649,9 @@ class _Plan:
         if bn_fuse is not None and self.training and not L.bias and not relu:
             pen = 0.008 + out.rows() * L.cout * 4 / 4e9
         wt = self.P(L.name + ".weight")
+        pend = getattr(src, "pending", None)
+        if pend is not None:
+            return self._conv_bnpre(L, src, out, d, wt, pend, bn_fuse)
         wargs = None
         if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
             U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
@@ -707,6 +713,48 @@ class _Plan:
         out.needs_mask = relu
         # the first consumer lowered is the LAST to add to src's gradient in the backward: if src is a train-mode BatchNorm's
         # output, that data gradient completes the BatchNorm's dout and can carry its backward sums (see bn())
+        completes = self.training and getattr(src, "bn_out", False) and not getattr(src, "_consumed", False)
+        src._consumed = True
+        self.tape.append(lambda: self._conv_bwd(L, src, out, completes_bn=completes))
+        return out
+
+    def _conv_bnpre(self, L: ConvL, src: Act, out: Act, d, wt, pend, bn_fuse: Optional[BnL]) -> Act:
+        """conv() for a source whose closing BatchNorm + residual + ReLU is still pending (bn(defer=True)): this 1x1 convolution applies
+        it in its operand loader and writes the activation (src.buf) and its ReLU bits itself — zsg_conv_igemm_bnpre.  Everything
+        behind the launch (this convolution's own fused statistics, the tape) is conv()'s."""
+        assert self.training and L.k == 1 and L.stride == 1 and L.pad == 0 and not L.bias and bn_fuse is not None and len(src.levels) == 1, \
+            "a deferred BatchNorm apply needs a plain 1x1 consumer in front of a BatchNorm"
+        x = pend["x"]
+        fn = lib.zsg_conv_igemm_bnpre
+        pre = (pend["mean"], pend["invstd"], pend["gam"], pend["bet"], pend["residual"].buf, src.buf, pend["rmask"])
+        autotune_conv("igemm", fn, d, (x.buf, wt, out.buf, None, None, None, None, None, None, 0.1, 1e-5) + pre, stream_ptr())
+        assert d.tile_hint and ((d.tile_hint >> 16) & 0xff) <= 1, "no tile of the BatchNorm-applying loader fits this convolution"
+        lane = 2 if pend["join"] else self._lane
+        chunks = igemm_partial_rows(d)
+        assert chunks * 2 * L.cout * 4 <= self.ws_bytes
+        partials, out.bn_chunks = self._ws_now(), chunks
+        tail_n = -1
+        if BN_TAIL in ("1", "fwd") and chunks > BN_TAIL_MIN_ROWS:
+            tail_n = int(lib.zsg_conv_bn_tail_tickets(_ct.byref(d), 0))
+        Lb = bn_fuse
+        rm, rv = self.net._rm[Lb.index:Lb.index + Lb.c], self.net._rv[Lb.index:Lb.index + Lb.c]
+        out.bn_inline = None
+        what = L.name + "+bnpre(" + pend["name"] + ")"
+        if tail_n > 0:
+            tk = self._buf(tail_n, dtype=torch.int32)
+            out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
+            self.fwd.add(fn, d, x.buf, wt, out.buf, partials, tk, out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5, *pre, what=what + "+bnstat", lane=lane)
+        else:
+            self.fwd.add(fn, d, x.buf, wt, out.buf, partials, None, None, None, None, None, 0.1, 1e-5, *pre, what=what, lane=lane)
+            out.bn_mean, out.bn_invstd = self._buf(Lb.c), self._buf(Lb.c)
+            if out.bn_chunks <= lib.zsg_bn_inline_max_chunks():
+                out.bn_inline = partials
+            else:
+                rows = src.B * d.seg[0].rows_y * d.seg[0].rows_x
+                self.fwd.add(lib.zsg_bn_stats_from_partials, partials, out.bn_chunks, rows, Lb.c, out.bn_mean, out.bn_invstd, rm, rv, 0.1, 1e-5,
+                             what="stats:" + Lb.name, lane=self._lane)
+        src.pending = None
+        out.needs_mask = False
         completes = self.training and getattr(src, "bn_out", False) and not getattr(src, "_consumed", False)
         src._consumed = True
         self.tape.append(lambda: self._conv_bwd(L, src, out, completes_bn=completes))
@@ -854,8 +902,10 @@ class _Plan:
         covers_all = not d.zero_fill and mask is None and ((d.tile_hint >> 16) & 0xff) <= 1 and d.tile_hint and dx.ld == n and n % 4 == 0
         dx.last_writer = (len(self.bwd.calls) - 1, d, wargs if d.use_wino else args, "dgrad:" + L.name) if covers_all else None
 
-    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False) -> Act:
-        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2)."""
+    def bn(self, L: BnL, x: Act, relu: bool, residual: Optional[Act] = None, name=None, join: bool = False, defer: bool = False) -> Act:
+        """join: an operand (the residual) was produced on the side stream — the apply launch first joins it (lane 2).
+        defer: no apply launch — the one consumer lowered next (a 1x1 convolution, conv()) applies this BatchNorm in its operand loader
+        and materialises the activation (out.pending describes it)."""
         net = self.net
         lv = x.levels[0]
         out = self.act(name or L.name, x.B, lv.H, lv.W, L.c)
@@ -874,7 +924,12 @@ class _Plan:
         rmask = self._buf((rows * L.c // 4 + 3) // 4) if (relu and self.training) else None     # 4 mask bits per byte
         lane = 2 if (join and self.training) else self._lane
         inl = getattr(x, "bn_inline", None) if fused else None
-        if inl is not None:
+        defer = defer and self.training and relu and residual is not None and rmask is not None and rows * L.c * 4 >= BN_PRE_MIN_MB * 1e6
+        if defer:
+            if inl is not None:       # the statistics were left to the apply launch: finalise them now (the very next launch: workspace intact)
+                self.fwd.add(lib.zsg_bn_stats_from_partials, inl, x.bn_chunks, rows, L.c, mean, invstd, rm, rv, 0.1, 1e-5, what="stats:" + L.name, lane=lane)
+            out.pending = dict(x=x, mean=mean, invstd=invstd, gam=gam, bet=bet, residual=residual, rmask=rmask, join=join, name=L.name)
+        elif inl is not None:
             self.fwd.add(lib.zsg_bn_apply_from_partials, x.buf, rows, L.c, inl, x.bn_chunks, gam, bet, residual.buf if residual is not None else None,
                          int(relu), out.buf, rmask, mean, invstd, rm, rv, 0.1, 1e-5, what=L.name, lane=lane)
         else:
@@ -999,7 +1054,10 @@ class _Plan:
             taps, lat = {}, {}
             early = self.training and os.environ.get("ZSG_FPN_LATERAL_EARLY", "1") != "0"
             for blk in net.blocks:
-                x = self._lower_block(blk, x)
+                # (a block that is not the last of its stage has ONE first reader, the next block's conv1: that convolution applies this block's
+                # closing BatchNorm + residual + ReLU itself where the activation is large, see BN_PRE_MIN_MB)
+                big = BN_PRE_MIN_MB > 0 and net.block_kind == "bottleneck" and self.training and not blk["last"]
+                x = self._lower_block(blk, x, defer_out=big)
                 if blk["last"]:
                     taps[blk["layer"]] = x
                     if early and blk["layer"] in (2, 3):
@@ -1182,7 +1240,7 @@ class _Plan:
         outs = [self.conv(C[f"{e}fproj{i + 1}"], sources[i], name=f"fproj{i + 1}", out=dest[i]) for i in range(3)] + sources[3:]
         return outs[1:] if net.six_hundred else outs
 
-    def _lower_block(self, blk, x: Act) -> Act:
+    def _lower_block(self, blk, x: Act, defer_out: bool = False) -> Act:
         """fpn_resnet.py:26-58 (BasicBlock), :61-100 (Bottleneck).  Training: a projection shortcut (downsample conv +
         BatchNorm) only depends on the block input, so it is lowered FIRST, on the side stream, and runs concurrently with
         the block's main branch; the last BatchNorm (which adds it) joins."""
@@ -1198,7 +1256,7 @@ class _Plan:
             a2 = self.conv_bn(C[q + "conv2"], BN[q + "bn2"], a1, True, name=q + "a2", yname=q + "y2")
             if self.training:
                 y3 = self.conv(C[q + "conv3"], a2, name=q + "y3", bn_fuse=BN[q + "bn3"])
-                return self.bn(BN[q + "bn3"], y3, True, residual=rd, name=q + "out", join=join)
+                return self.bn(BN[q + "bn3"], y3, True, residual=rd, name=q + "out", join=join, defer=defer_out)
             return self.conv_bn(C[q + "conv3"], BN[q + "bn3"], a2, True, residual=rd, name=q + "out", yname=q + "y3")
         a1 = self.conv_bn(C[q + "conv1"], BN[q + "bn1"], x, True, name=q + "a1", yname=q + "y1")
         if self.training:
@@ -1635,8 +1693,8 @@ class _Plan:
         T = qvec.shape[1]
         nd = 2 if net.bid else 1
         host_hc = h0.device.type == "cpu" and c0.device.type == "cpu"
-        staged = (STAGE_INPUTS and host_hc and qvec.is_cuda and qvec.dtype == torch.float32 and qlens.is_cuda and qlens.dtype == torch.int64
-                  and qlens.numel() == B)
+        staged = (STAGE_INPUTS and host_hc and qvec.is_cuda and qvec.dtype == torch.float32 and qlens.is_cuda
+                  and qlens.dtype in (torch.int64, torch.float32) and qlens.numel() == B)
         if staged:
             # ONE launch for the whole input staging (qvec into the zero-padded token bucket, qlens, the host-drawn h0 | c0 read straight
             # from a pinned ring slot, the BatchNorm counters): five torch operations with 5-20 us between them before (rocprofv3: 45 us
@@ -1650,7 +1708,8 @@ class _Plan:
             torch.stack([h0.float(), c0.float()], out=self._hc_pin[k])
             qv, ql = qvec.contiguous(), qlens.reshape(B).contiguous()
             n_nbt = net._nbt.numel() if self.training else 0
-            check(lib.zsg_stage_inputs(qv.data_ptr(), B, T, net.emb_dim, self.T, self.in_qvec.data_ptr(), ql.data_ptr(), self.in_qlens.data_ptr(),
+            check(lib.zsg_stage_inputs(qv.data_ptr(), B, T, net.emb_dim, self.T, self.in_qvec.data_ptr(), ql.data_ptr(),
+                                       int(ql.dtype == torch.float32), self.in_qlens.data_ptr(),
                                        self._hc_pin[k].data_ptr(), self.in_hc.numel(), self.in_hc.data_ptr(),
                                        net._nbt.data_ptr() if n_nbt else None, n_nbt, stream_ptr()), "stage_inputs")
             if self._hc_ev[k] is None:
