@@ -2,9 +2,9 @@
 # Round-end measurement cycle on ONE GPU box, kernel sources frozen (any csrc edit invalidates the table's stamp):
 #   tools/final_round.sh A   tuning table -> reproducibility runs -> full bench.py -> the other configurations
 #   tools/final_round.sh B   rocprofv3 stats + HBM traffic (tools/rocprof_round.sh) -> bench.py with the fresh traffic file -> PMC
-#                            counters (tools/pmc_round4.sh) -> co-issue micro-benchmark -> loader rate
-# Everything lands under gpurun_out/r04final/; the builder copies what is judged into profiles/r04_*.
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04final; mkdir -p $O; cd $R
+#                            counters (tools/pmc_round5.sh) -> co-issue micro-benchmark -> loader rate
+# Everything lands under gpurun_out/r05final/; the builder copies what is judged into profiles/r05_*.
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05final; mkdir -p $O; cd $R
 Q="--no-cpu-baseline --no-roofline"
 if [ "$1" = "A" ]; then
   python tools/make_tuning_table.py r50 r18 ssd r101 > $O/make_table.log 2>&1
@@ -15,15 +15,15 @@ if [ "$1" = "A" ]; then
     for i in 1 2 3; do ZSG_SHIPPED_TUNE=0 python bench.py --steps 100 --warmup 20 $Q 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"tuning": {[^}]*}' | tr '\n' ' '; echo; done
   } > $O/tuning_repro.txt 2>&1
   python bench.py > $O/bench_default.log 2>$O/bench_default.err
-  python bench.py --backbone ssd_vgg --bs 32 --no-cpu-baseline > $O/bench_ssd_vgg_b32.log 2>&1
-  python bench.py --arch resnet101 --img 600 --bs 32 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_r101_600_b32.log 2>&1
-  python bench.py --arch resnet18 --no-cpu-baseline > $O/bench_r18.log 2>&1
-  python bench.py --force-ddp --no-cpu-baseline > $O/bench_force_ddp.log 2>&1
-  ZSG_COMM=native python bench.py --force-ddp --no-cpu-baseline > $O/bench_force_ddp_native.log 2>&1
+  python bench.py --backbone ssd_vgg --bs 32 --no-cpu-baseline --other-configs off > $O/bench_ssd_vgg_b32.log 2>&1
+  python bench.py --arch resnet101 --img 600 --bs 32 --steps 30 --warmup 5 --no-cpu-baseline --other-configs off > $O/bench_r101_600_b32.log 2>&1
+  python bench.py --arch resnet18 --no-cpu-baseline --other-configs off > $O/bench_r18.log 2>&1
+  python bench.py --force-ddp --no-cpu-baseline --other-configs off > $O/bench_force_ddp.log 2>&1
+  ZSG_COMM=native python bench.py --force-ddp --no-cpu-baseline --other-configs off > $O/bench_force_ddp_native.log 2>&1
 else
-  USE_SHIPPED=1 bash tools/rocprof_round.sh r04 > $O/rocprof_round.log 2>&1
+  USE_SHIPPED=1 bash tools/rocprof_round.sh r05 > $O/rocprof_round.log 2>&1
   python bench.py > $O/bench_final.log 2>$O/bench_final.err
-  bash tools/pmc_round4.sh > $O/pmc.log 2>&1
+  bash tools/pmc_round5.sh > $O/pmc.log 2>&1
   [ -x tools/ubench/build/mfma_coissue ] && timeout 600 tools/ubench/build/mfma_coissue > $O/mfma_coissue.txt 2>&1
   timeout 900 python tools/loader_rate.py > $O/loader_rate.txt 2>&1
 fi
