@@ -998,6 +998,38 @@ def test_wgrad_256_column_tile(Z, case):
     assert_close(dw[..., :Ci].permute(0, 3, 1, 2), ref, 5e-4, 5e-4 * float(ref.abs().max()), "wgrad, 256-column tile")
 
 
+@pytest.mark.parametrize("B,Ci,Co,sizes", [(2, 64, 96, [(19, 19)]), (3, 256, 64, [(7, 5), (3, 3), (1, 1)]), (16, 128, 512, [(5, 5)]), (1, 36, 20, [(1, 1)]),
+                                           (2, 64, 256, [(38, 38), (19, 19), (10, 10)])], ids=["one", "levels", "wide", "tiny", "pyramid"])
+def test_wgrad_dense_1x1_loader(Z, B, Ci, Co, sizes):
+    """1x1 / stride-1 weight gradient over batch-dense tensors = the DENSE loader of wgrad_kernel (descriptor-base addressing, the level's
+    ragged last K tile and the dead prefetch cut by num_records): every tile / wave / K-depth variant and split count, ragged row counts
+    (361 * B, 35 * B, 1), ragged channel counts (Co = 20 in a 4-padded row), several levels in one launch, accumulate on / off."""
+    L, ops = Z
+    g = torch.Generator().manual_seed(7 + Ci + Co)
+    xs = [torch.randn(B, Ci, h, w, generator=g) for h, w in sizes]
+    gys = [torch.randn(B, Co, h, w, generator=g) for h, w in sizes]
+    ref = sum(torch.einsum("bohw,bihw->oi", gy.double(), x.double()) for gy, x in zip(gys, xs)).float()
+    Cop = pad4(Co)
+    packed_x = torch.cat([nhwc(x).reshape(-1) for x in xs]).cuda()
+    packed_g = torch.cat([nhwc(gy, Cop).reshape(-1) for gy in gys]).cuda()
+    lv_x, lv_g, ox, og = [], [], 0, 0
+    for h, w in sizes:
+        lv_x.append(ops.Level(ox, h, w, h * w * Ci))
+        lv_g.append(ops.Level(og, h, w, h * w * Cop))
+        ox += B * h * w * Ci
+        og += B * h * w * Cop
+    src, dyv = ops.TView(packed_x, B, Ci, Ci, lv_x), ops.TView(packed_g, B, Cop, Cop, lv_g)
+    st = L.stream_ptr()
+    hints = [0] + [ops.tile_hint(bm, bn, sp, w8, k32) for bm, bn in ((64, 64), (128, 64), (64, 128), (128, 128)) for sp in (1, 3, 16)
+                   for w8 in ((0, 1) if (bm, bn) == (128, 128) else (0,)) for k32 in (0, 1)]
+    for i, hint in enumerate(hints):
+        acc = i & 1
+        dw = torch.full((Co, 1, 1, Ci), 1.0, device="cuda")
+        d = ops.fwd_desc(src, dyv, Ci, Co, 1, 1, 0, 1, wC=Ci, tile_hint=hint)
+        L.check(L.lib.zsg_conv_wgrad(C.byref(d), packed_x.data_ptr(), packed_g.data_ptr(), dw.data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, st), "wgrad dense")
+        assert_close(dw.view(Co, Ci).cpu() - (1.0 if acc else 0.0), ref, 5e-4, 5e-4 * float(ref.abs().max()), f"dense 1x1 wgrad hint {hint:x} acc={acc}")
+
+
 @pytest.mark.parametrize("case", [(2, 32, 16, 520, 520, 3, 1, 1, (128, 128, 24)), (2, 8, 32, 520, 520, 1, 1, 0, (64, 64, 64)), (2, 32, 16, 520, 520, 3, 1, 1, (0, 0, 0))],
                          ids=["src_wide", "dy_wide", "heuristic"])
 def test_wgrad_image_stride_beyond_2p23(Z, case):

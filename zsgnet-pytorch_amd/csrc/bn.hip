@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ relu_out, const uint8_t* __restrict__ relu_mask,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          int64_t rows, int C, int lanes, int rpb, float* __restrict__ part) {
+    ZSG_SET_MAIN_PRIO();
     __shared__ f32x4 red[2][256];
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
@@ -166,6 +167,7 @@ template <int FW>
 __global__ __launch_bounds__(64 * FW) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
                                                                     float* mean, float* invstd, float* rmean, float* rvar,
                                                                     float momentum, float eps) {
+    ZSG_SET_MAIN_PRIO();
     const int c = blockIdx.x * 4;
     double se, sse;
     bn_reduce_partials<FW>(part, chunks, C, c, se, sse);
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ residual, int relu,
                                                        float* __restrict__ out, uint8_t* __restrict__ relu_mask, int lanes, int rpb) {
+    ZSG_SET_MAIN_PRIO();
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     const int c = (blockIdx.y * lanes + l) * 4;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // coef[0][c] = sum g / n ; coef[1][c] = sum g*xhat / n ; dgamma/dbeta written or accumulated.
 __global__ __launch_bounds__(64 * BN_FW) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, int64_t rows,
                                                                      float* coef, float* dgamma, float* dbeta, int accumulate) {
+    ZSG_SET_MAIN_PRIO();
     const int c = blockIdx.x * 4;
     double se, sse;
     bn_reduce_partials<BN_FW>(part, chunks, C, c, se, sse);
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ coef,
                                                            float* __restrict__ dx, float* __restrict__ g_out, int lanes, int rpb) {
+    ZSG_SET_MAIN_PRIO();
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     const int c = (blockIdx.y * lanes + l) * 4;
@@ -291,6 +296,7 @@ __global__ __launch_bounds__(256) void bn_apply_inl_kernel(const float* __restri
                                                            uint8_t* __restrict__ relu_mask, float* __restrict__ mean_out,
                                                            float* __restrict__ invstd_out, float* rmean, float* rvar, float momentum,
                                                            float eps, int lanes, int rpb) {
+    ZSG_SET_MAIN_PRIO();
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     const int c = (blockIdx.y * lanes + l) * 4;

@@ -32,6 +32,13 @@ int zsg_conv_mx_groups(const zsg_conv_desc* d);
 int zsg_conv_mx_launch(const zsg_conv_desc* d, const float* src, const float* wt, float* out, const float* bias, const float* add_src,
                        const float* mask_src, float* bn_partials, hipStream_t st);
 
+// Wave priority of the kernels of the step's dependent (main-stream) chain: convolutions, BatchNorm passes.  The weight-gradient kernels
+// (side stream) stay at 0, so where a CU holds blocks of both streams the SIMD's arbiter serves the critical chain first.
+#ifndef ZSG_MAIN_PRIO
+#define ZSG_MAIN_PRIO 3
+#endif
+#define ZSG_SET_MAIN_PRIO() do { if (ZSG_MAIN_PRIO) __builtin_amdgcn_s_setprio(ZSG_MAIN_PRIO); } while (0)
+
 #define ZSG_WAVE 64
 #define ZSG_NUM_CU 256
 #define ZSG_NUM_XCD 8
@@ -111,6 +118,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ rsrc_t make_rsrc_n(const void* base, unsigned bytes) {     // a window of `bytes` bytes: lanes beyond it read zeros
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned byte_off) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -85,6 +85,7 @@ struct IgParams {
 // instructions that are paid in full next to fp32 MFMAs).  The 64-deep 128x128 4-wave tile needs more than 256 registers.
 template <int BM, int BN, int NW, bool MERGE_X, int KS = 1, int BK = IG_BK, bool PRE = false>
 __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && NW * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
+    ZSG_SET_MAIN_PRIO();
     static_assert(!PRE || !MERGE_X, "the BatchNorm-applying loader is for 1x1 convolutions");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per K group");
     constexpr int WM = (NW == 8 && BN == 64) ? 4 : 2, WN = NW / WM;     // the wave grid over the tile

@@ -94,6 +94,7 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, unsigned byte_off, f32x4 v)
 // unit lost ~1 us per unit).  PF = 2 register stages where a step is short (NJ <= 2: 32 / 64 MFMAs), 1 for NJ = 4 (128 MFMAs).
 template <int NJ, int MODE>
 __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
+    ZSG_SET_MAIN_PRIO();
     constexpr int UW = 32 * NJ;             // unit width (output channels)
     constexpr int NP = (NJ + 1) / 2;        // epilogue passes of 64 columns
     constexpr int PF = NJ <= 2 ? 2 : 1;     // register stages

@@ -81,7 +81,12 @@ int wg_reduce_launch(const WgReduceJob& j, hipStream_t st) {
 // WIDE: an image stride (src_bstride / out_bstride) does not fit mul24's 24 signed bits (an activation of >= 2^23 elements per image:
 // the stem / layer1 maps of inputs beyond ~724x724): the batch-index x image-stride products use the 32-bit multiply.  Only the
 // 64x64 tile is instantiated that way (the host maps every tile hint onto it): a correct fallback, not a tuned path.
-template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true, bool WIDE = false>
+// DENSE: a 1x1 / stride-1 / unpadded convolution over batch-dense tensors (every bottleneck conv1 / conv3, the FPN laterals): pixel
+// row r of a level is row r of both operands, so a K tile is 16 (32) CONSECUTIVE rows.  The loader then has no per-lane address
+// arithmetic at all: every lane's byte offset inside a tile is a kernel-lifetime constant, the tile's position travels in the
+// buffer descriptor's base (scalar adds) and its num_records bound cuts the level's last, ragged tile (and a dead prefetch) to
+// zeros — 0 VALU per K tile instead of ~25 per load next to fp32 MFMAs that nothing co-issues with (tools/ubench/mfma_coissue.hip).
+template <int TM, int TN, int WG_BK, int WM, int WN, bool AVEC = true, bool WIDE = false, bool DENSE = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -137,6 +142,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p
     // register stages: the global loads run NS K tiles ahead
     constexpr int NS = 2;            // (4 stages measured together with igemm.hip's: no gain, see there)
     f32x4 ra[NS][NA], rb[NS][NB];
+    unsigned a_vo[NA], b_vo[NB];     // DENSE: this lane's byte offsets inside a K tile
+    if (DENSE) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a_vo[j] = a_colok ? 4u * (unsigned)((ka + PA * j) * p.out_ld + na) : ZSG_OOB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b_vo[j] = b_colok ? 4u * (unsigned)((kb + PB * j) * p.src_ld + b_c) : ZSG_OOB;
+    }
     // live == false (past this block's last K tile): every lane gets an out-of-range offset — the loads still issue and
     // return zeros without touching memory, so the K loop has no branch around them and the compiler counts the
     // outstanding loads exactly (with a branch it waited for ALL of them, vmcnt(0), before parking the previous tile).
@@ -146,6 +158,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p
             sg = p.seg[si];
         }
         const int rbase = (kt_next - sg.kt0) * WG_BK;
+        if (DENSE) {
+            const unsigned left = live ? (unsigned)(sg.rows - rbase) : 0u;          // rows of the level from this tile on (wave-uniform)
+            const rsrc_t ta = make_rsrc_n(p.dy + sg.out_off + rbase * p.out_ld, 4u * left * (unsigned)p.out_ld);
+            const rsrc_t tb = make_rsrc_n(p.src + sg.src_off + rbase * p.src_ld, 4u * left * (unsigned)p.src_ld);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) ra[j] = buf_load4(ta, a_vo[j]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) rb[j] = buf_load4(tb, b_vo[j]);
+            ++kt_next;
+            return;
+        }
         const int per = sg.rows_y * sg.rows_x;
 #if defined(WG_ABL) && (WG_ABL & 1)       // timing experiment only (wrong results): the loads without the pixel decode
         {
@@ -298,6 +321,9 @@ extern "C" size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d) {
     return (size_t)splits * d->N * ncols * sizeof(float);
 }
 
+// A/B switch for the DENSE loader (ZSG_WG_DENSE=0: every launch takes the decoding loader), read once
+static const int g_zsg_wg_no_dense = [] { const char* e = getenv("ZSG_WG_DENSE"); return (e && e[0] == '0') ? 1 : 0; }();
+
 static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                            size_t ws_bytes, void* stream) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad: null argument");
@@ -347,6 +373,14 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
         rows_all += (double)rows;
     }
     p.kt_total = kt;
+    // 1x1 / stride 1 / no padding over batch-dense tensors: pixel row r of a level is row r of both operands (the DENSE loader)
+    bool dense = avec && !wide && p.ty.n == 1 && p.tx.n == 1 && p.ty.d0 == 0 && p.tx.d0 == 0 && !g_zsg_wg_no_dense;
+    for (int s = 0; s < d->nseg && dense; ++s) {
+        const zsg_seg& a = d->seg[s];
+        dense = a.sy == 1 && a.sx == 1 && a.osy == 1 && a.osx == 1 && a.opy == 0 && a.opx == 0 && a.rows_y == a.src_H && a.rows_x == a.src_W &&
+                a.out_W == a.rows_x && a.src_bstride == (int64_t)a.src_H * a.src_W * d->src_ld &&
+                a.out_bstride == (int64_t)a.rows_y * a.rows_x * d->out_ld;
+    }
     // tile_hint = BM | (BN << 8) | (splits << 16) (BM over output channels, BN over weight columns); 0 = heuristic
     int TM = (d->N > 64) ? 2 : 1;
     int TN = (p.ncols > 64) ? 2 : 1;
@@ -382,20 +416,25 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
     const double wg_flops = 2.0 * rows_all * d->N * p.ncols;
     const double wg_bytes = zsg_conv_alg_bytes(d, accumulate != 0);      // (dw takes the filter's place, dy the output's: same count)
     dim3 grid(nmn * p.splits);
-#define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_) WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, true)
+#define WG_LAUNCH(TM_, TN_, BK_, WM_, WN_)                                                     \
+    do {                                                                                       \
+        if (dense) WG_LAUNCH_D(TM_, TN_, BK_, WM_, WN_, true, false, true, ", true, false, true"); \
+        else WG_LAUNCH_D(TM_, TN_, BK_, WM_, WN_, true, false, false, "");                       \
+    } while (0)
 #define WG_LAUNCH_A(TM_, TN_, BK_, WM_, WN_, AV_) WG_LAUNCH_W(TM_, TN_, BK_, WM_, WN_, AV_, false)
-#define WG_LAUNCH_W(TM_, TN_, BK_, WM_, WN_, AV_, WD_)                                                                          \
+#define WG_LAUNCH_W(TM_, TN_, BK_, WM_, WN_, AV_, WD_) WG_LAUNCH_D(TM_, TN_, BK_, WM_, WN_, AV_, WD_, false, "")
+#define WG_LAUNCH_D(TM_, TN_, BK_, WM_, WN_, AV_, WD_, DN_, SFX_)                                                              \
     do {                                                                                                                   \
         const size_t lds = (size_t)2 * BK_ * ((32 * TM_ * WM_ + WG_PAD) + (32 * TN_ * WN_ + WG_PAD)) * sizeof(float);       \
         static bool attr_done[ZSG_MAX_DEV] = {};                                                                           \
         if (!attr_done[dev]) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_, WD_>,                   \
+            hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_, WD_, DN_>,              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
             if (e != hipSuccess) ZSG_FAIL(-3, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
             attr_done[dev] = true;                                                                                         \
         }                                                                                                                  \
-        ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ ">", st, wg_flops, wg_bytes);                     \
-        ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_, WD_>), grid, dim3(64 * WM_ * WN_), lds, st, p);          \
+        ZSG_PROF("wgrad_kernel<" #TM_ ", " #TN_ ", " #BK_ ", " #WM_ ", " #WN_ SFX_ ">", st, wg_flops, wg_bytes);                \
+        ZSG_LAUNCH((wgrad_kernel<TM_, TN_, BK_, WM_, WN_, AV_, WD_, DN_>), grid, dim3(64 * WM_ * WN_), lds, st, p);     \
     } while (0)
     if (wide) {                                       // an image stride >= 2^23 elements: 32-bit batch-offset multiplies
         if (avec) WG_LAUNCH_W(1, 1, 16, 2, 2, true, true);
@@ -420,6 +459,7 @@ static int conv_wgrad_impl(const zsg_conv_desc* d, const float* src, const float
 #undef WG_LAUNCH
 #undef WG_LAUNCH_A
 #undef WG_LAUNCH_W
+#undef WG_LAUNCH_D
     if (p.splits > 1) {
         WgReduceJob j;
         wg_reduce_job_fill(j, d, p.ws, dw, p.accumulate, p.splits);

@@ -66,6 +66,7 @@ __device__ __forceinline__ float quad_other(float v) {
 // i = ph (PS = 4).  PS = 4 doubles the waves per SIMD for the same tile (64 instead of 128 accumulator registers each).
 template <int TM, int TN, int PS>
 __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnParams p) {
+    ZSG_SET_MAIN_PRIO();
     constexpr int NT = 64 * PS * TM * TN;        // PS position groups x TM x TN waves
     constexpr int NP = 16 / PS;                  // positions (accumulator tiles) per wave
     constexpr int TB = 32 * TM, BN = 32 * TN;
