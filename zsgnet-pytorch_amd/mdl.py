@@ -492,7 +492,7 @@ class _Plan:
         self.expect_backward = False
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
-        self.bwd.side_defer = 0 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_DEFER, measured)
+        self.bwd.side_defer = 1      # (ops.SIDE_DEFER; round 5, with the main chain at wave priority 3: 1 wins at every size)
         self.tape = []
         self.acts: Dict[str, Act] = {}
         self.bytes = 0

@@ -207,8 +207,9 @@ GRAPH_WARMUP = 2                                             # eager replays of 
 # layer's data gradient.  Round 2 (markers on every release, slower weight gradients): 1 won, 15.27 -> 15.12 ms.  Round 4, one
 # box each, tools/ab_env.sh (4 interleaved runs): configs[1] 13.64 -> 13.54 ms with 0 (+ the early laterals, mdl.py), ResNet-18
 # 7.61 -> 7.46, SSD-VGG B=32 38.32 -> 38.16; ResNet-101 @600^2 B=32 (launches of several hundred us, every one fills the chip)
-# 105.2 -> 107.3 with 0 — hence the plan picks 0 for small launches and 1 for large ones (Program.side_defer) unless
-# ZSG_SIDE_DEFER says otherwise.
+# 105.2 -> 107.3 with 0.  Round 5: with the main chain's kernels at wave priority 3 (common.h ZSG_MAIN_PRIO) and the faster dense
+# 1x1 weight gradients, 1 wins again on configs[1] (two boxes: 13.32 -> 13.24, 13.46 -> 13.40 ms; 2 = 1, 3 slower;
+# profiles/r05_release_policy_prio.txt), so every plan uses 1 (Program.side_defer) unless ZSG_SIDE_DEFER says otherwise.
 SIDE_DEFER = int(os.environ.get("ZSG_SIDE_DEFER", "-1"))
 # ... and only at every n-th main-stream convolution: every release costs the main stream an event record, i.e. a marker packet
 # the next kernel has to wait for (~4 us each: doubling the ~70 records of a ResNet-50 backward costs 0.28 ms).  Measured on
