@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* _
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int k, int s,
                                                                   int p, int Ho, int Wo, float* __restrict__ out, uint8_t* __restrict__ idx) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* _
                                                                   int Wo, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
                                                                   int lanes, int rpb, float* __restrict__ part) {
+    ZSG_SET_MAIN_PRIO();
     __shared__ f32x4 red[2][256];
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ coef, int64_t rows, float* __restrict__ dx, int lanes,
                                                                 int rpb) {
+    ZSG_SET_MAIN_PRIO();
     const int rowlanes = 256 / lanes;
     const int l = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     const int c = (blockIdx.y * lanes + l) * 4;

@@ -12,6 +12,7 @@ static inline int grid_for(int64_t n_items, int block = 256, int cap = ZSG_NUM_C
 // ---- max pool -------------------------------------------------------------------------------------------------
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C4, int k, int s, int p, int Ho, int Wo,
                                    float* __restrict__ out, uint8_t* __restrict__ idx) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -47,6 +48,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, in
 
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx, int B, int H, int W, int C4, int k,
                                    int s, int p, int Ho, int Wo, float* __restrict__ dx) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * H * W * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -111,6 +113,7 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
 
 __global__ void upsample_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ p, int B, int Hs, int Ws, int Hd, int Wd,
                                         int C4, float sh, float sw, float* __restrict__ out) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * Hd * Wd * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -127,6 +130,7 @@ __global__ void upsample_add_fwd_kernel(const float* __restrict__ a, const float
 
 __global__ void upsample_add_bwd_kernel(const float* __restrict__ dout, int B, int Hs, int Ws, int Hd, int Wd, int C4, float sh, float sw,
                                         float* __restrict__ dp, int accumulate) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * Hs * Ws * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -185,6 +189,7 @@ __global__ void relu_fwd_kernel(const float* __restrict__ x, int64_t n4, float* 
     }
 }
 __global__ void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int64_t n4, float* __restrict__ dx, int accumulate) {
+    ZSG_SET_MAIN_PRIO();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v = *(const f32x4*)(x + i * 4);
         f32x4 g = *(const f32x4*)(dout + i * 4);
@@ -217,6 +222,7 @@ __global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int HW, i
     out[i] = s / (float)HW;
 }
 __global__ void avgpool_bwd_kernel(const float* __restrict__ dout, int B, int HW, int C, float* __restrict__ dx, int accumulate) {
+    ZSG_SET_MAIN_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * HW * C) return;
     const int c = i % C, b = i / (HW * C);
@@ -239,6 +245,7 @@ extern "C" int zsg_avgpool_bwd(const float* dout, int32_t B, int32_t HW, int32_t
 
 // ---- channel L2 norm (one wave per pixel row) ----------------------------------------------------------------------
 __global__ void l2norm_fwd_kernel(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ out, float* __restrict__ norm) {
+    ZSG_SET_MAIN_PRIO();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -254,6 +261,7 @@ __global__ void l2norm_fwd_kernel(const float* __restrict__ x, int64_t rows, int
 }
 __global__ void l2norm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ norm,
                                   int64_t rows, int C, float* __restrict__ dx) {
+    ZSG_SET_MAIN_PRIO();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -278,6 +286,7 @@ extern "C" int zsg_l2norm_bwd(const float* dout, const float* out, const float* 
 
 // ---- image NCHW -> NHWC4 ---------------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ img, int B, int C, int HW, float* __restrict__ out) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW, px = i % HW;
@@ -637,6 +646,7 @@ extern "C" int zsg_colsum(const float* x, int32_t groups, int64_t gstride, int32
 
 // ---- dst[r][0:dst_ld] = [src[r][0:C] | 0]  (e.g. the 45-channel head gradient -> 48-channel GEMM operand) -------------
 __global__ void pad_rows_kernel(const float* __restrict__ src, int64_t rows, int C, int src_ld, float* __restrict__ dst, int dst_ld) {
+    ZSG_SET_MAIN_PRIO();
     const int64_t total = rows * dst_ld;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / dst_ld;

@@ -74,6 +74,7 @@ struct MxAddr {
 // R: tap rows; KQ: pairs of taps per row that exist (ceil(taps / 2): 4 for the 7-tap stem, 2 for a 3-tap row)
 template <int R, int KQ>
 __global__ __launch_bounds__(64 * MX_WAVES) void mx_kernel(const MxParams p) {
+    ZSG_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* Ws = smem;                                              // [R][64][MX_LDW]
