@@ -7,10 +7,12 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; P=$R/zsgnet-pytorch_amd; OUT=$P/build/abl; mkdir -p $OUT
 LIST=${ABLS:-0 1 2 3 4 8 16 32 48 52 60}
 if [ "$1" = "build" ]; then
-  FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -I$R/include -I$P/csrc -I/opt/rocm/include -Wno-unused-result -Wno-unused-value -Wno-array-bounds"
+  FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -I$R/include -I$P/csrc -I$P/build -I/opt/rocm/include -Wno-unused-result -Wno-unused-value -Wno-array-bounds"
   OBJS=$(ls $P/build/*.o | grep -v wino.hip.o)
+  # the product source carries no experiment switches: they live in tools/ablation/wino_abl.patch and are applied to a COPY here
+  cp $P/csrc/wino.hip $OUT/wino_ablsrc.hip && patch -s $OUT/wino_ablsrc.hip $R/tools/ablation/wino_abl.patch || { echo "tools/ablation/wino_abl.patch no longer applies to csrc/wino.hip"; exit 1; }
   for n in $LIST; do
-    ( /opt/rocm/bin/hipcc $FLAGS -DWN_ABL=$n -c $P/csrc/wino.hip -o $OUT/wino_abl$n.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libzsg_wabl$n.so $OUT/wino_abl$n.o $OBJS -ldl && rm $OUT/wino_abl$n.o ) &
+    ( /opt/rocm/bin/hipcc $FLAGS -DWN_ABL=$n -c $OUT/wino_ablsrc.hip -o $OUT/wino_abl$n.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libzsg_wabl$n.so $OUT/wino_abl$n.o $OBJS -ldl && rm $OUT/wino_abl$n.o ) &
   done
   wait
   ls $OUT

@@ -16,12 +16,6 @@
 #include "bn_tail.h"
 
 #define IG_BK 32
-// IG_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong; 32 = no output stores in the plain
-// vectorised epilogue) — 1 no MFMAs, 2 no global loads
-// in the K loop, 4 no LDS stores, 8 no fragment reads, 16 no barrier.  tools/igemm_ablation.sh builds one library per value.
-#ifndef IG_ABL
-#define IG_ABL 0
-#endif
 #define IG_LDK 36
 
 struct IgSegDev {
@@ -188,12 +182,10 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     unsigned a_vo[RA], b_vo[RB];       // per-lane byte offsets of the current tap's tile rows (see load_tile)
     int so_a = 0, so_b = 0, skip = 0;  // the tile's channel offset in both operands (bytes, SGPRs); tiles until the offsets are recomputed
     const bool c_tail = (Cdim % BK) != 0;
-    bool in_loop = false;
     // live == false (past the last K tile): every lane gets an out-of-range offset, i.e. the loads still issue — and
     // return zeros without touching memory — so the K loop has no branch around them and the compiler can count the
     // outstanding loads exactly (a branch made it wait for ALL of them, vmcnt(0), before parking the previous tile).
     auto load_tile = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB], bool live, int stg = 0) {
-        if ((IG_ABL & 2) && in_loop) return;
         const int wr = sg.ty.w0 + jy * sg.ty.wstep;
         const int dyy = jy * sg.ty.dstep;
         int ws_, dxx, koff;
@@ -275,7 +267,6 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
         }
     };
     auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB], int stg = 0) {
-        if ((IG_ABL & 4) && in_loop) return;
         float* a = As + buf * BM * LDR;
         float* b = Bs + buf * BN * LDR;
         if constexpr (PRE) {
@@ -324,7 +315,6 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    in_loop = false;
     if (n_it > 0) {                      // a parity class of a strided dgrad may have no contributing tap at all
         load_tile(ra[0], rb[0], true, 0);
         store_tile(0, ra[0], rb[0], 0);
@@ -347,36 +337,21 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
         for (int kk = 0; kk < BK / 8 / KS; ++kk) {
             const int kq = kg * (BK / 8 / KS) + kk;
             f32x4 fa[TM], fb[TN];
-            if (!(IG_ABL & 8)) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a + i * 32 * LDR + kq * 8);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
-            } else {
+            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(b + j * 32 * LDR + kq * 8);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = acc[i][0].xyzw;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = acc[0][j].xyzw;
-            }
-            if (!(IG_ABL & 1)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-            } else {
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j][0] += fa[i][0] * fb[j][0];      // (keeps the fragment reads alive)
-            }
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
         store_tile((it + 1) & 1, cur_a, cur_b, cur_s);      // (after the last tile: zeros into the idle buffer)
-        if (!(IG_ABL & 16)) __syncthreads();
+        __syncthreads();
     };
-    in_loop = true;
     for (int it = 0; it < n_it; it += NS) {
 #pragma unroll
         for (int st = 0; st < NS; ++st)
@@ -539,7 +514,6 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                 }
-                if ((IG_ABL & 32) && v[0] != 12345.678f) continue;      // (ablation: no output stores)
                 *(f32x4*)(p.out + o) = v;
             }
         }

@@ -28,12 +28,6 @@
 // MFMA phase (19.3 us) that ADDS to the 7.6 us of loads + stores of the SIMD's other wave instead of hiding them.
 #include "common.h"
 
-// PW_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong) — 1 no MFMAs, 2 no output stores,
-// 4 no fragment reads, 8 no source loads in the streaming loop, 16 no partial-row reduction at the end, 32 no per-row statistics.
-// tools/pw_ablation.sh builds one library per value.
-#ifndef PW_ABL
-#define PW_ABL 0
-#endif
 #define PW_TB 68          // floats per row of a wave's tile buffer: 64 + 4 = 17 x 16 B (odd: conflict-free b128 rows)
 #define PW_WAVES 8
 #define PW_LDS_MAX (160 * 1024)
@@ -67,16 +61,8 @@ __device__ __forceinline__ void pw_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#if PW_ABL & 1
-#define PW_MFMA(c, a, b) (c)[0] += (a) * (b)
-#else
 #define PW_MFMA(c, a, b) (c) = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#endif
-#if PW_ABL & 4
-#define PW_FRAG(ptr) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
-#else
 #define PW_FRAG(ptr) (*(const f32x4*)(ptr))
-#endif
 
 __device__ __forceinline__ void buf_store4(rsrc_t r, unsigned byte_off, f32x4 v) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -150,7 +136,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + rr + 4 * i;
             const bool ok = live & (m < M);
-            r[i] = buf_load4(rs, (ok && !((PW_ABL & 8) && ru >= 8)) ? 4u * (unsigned)(p.src_off + m * p.src_ld + rk * 64 + 4 * cg) : ZSG_OOB);
+            r[i] = buf_load4(rs, ok ? 4u * (unsigned)(p.src_off + m * p.src_ld + rk * 64 + 4 * cg) : ZSG_OOB);
         }
     };
 #define PW_ADVANCE()           \
@@ -345,7 +331,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
                         s2[jp] += g * ((xb[i] - mu) * is);
                     }
                 } else {
-                    if (MODE == 0 && p.stats && !(PW_ABL & 32)) {          // (plain convolution: the host excludes bias / add / ReLU here)
+                    if (MODE == 0 && p.stats) {          // (plain convolution: the host excludes bias / add / ReLU here)
 #pragma unroll
                         for (int i = 0; i < RH; ++i) {    // (dead rows hold exact zeros, dead columns are never written out: no test)
                             s1[jp] += v[i];
@@ -367,7 +353,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < RH; ++i) buf_store4(rs_out, ((PW_ABL & 2) && v[i][0] != 12345.678f) ? ZSG_OOB : off[i], v[i]);
+                for (int i = 0; i < RH; ++i) buf_store4(rs_out, off[i], v[i]);
             }
         }
         kc = 0;
@@ -377,7 +363,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
 #undef PW_ADVANCE
 
     // ---- one partial row per workgroup: lanes of a column group, then the waves of a column split, in a fixed order ------------
-    if (p.stats && !(PW_ABL & 16)) {
+    if (p.stats) {
         __syncthreads();                    // every wave has left the streaming loop: the filter panel is no longer needed
         float* red = smem;                  // [PW_WAVES][2][UW]
 #pragma unroll

@@ -170,17 +170,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p
             return;
         }
         const int per = sg.rows_y * sg.rows_x;
-#if defined(WG_ABL) && (WG_ABL & 1)       // timing experiment only (wrong results): the loads without the pixel decode
-        {
-            const unsigned base = live ? (4u * (unsigned)(rbase * 64) & 0x3FFFFu) : ZSG_OOB;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) ra[j] = buf_load4(rs_a, live ? ((base + 4u * (unsigned)(tid * 4 + j * 1024)) & 0xFF0u) : ZSG_OOB);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) rb[j] = buf_load4(rs_b, live ? ((base + 4u * (unsigned)(tid * 4 + j * 1024)) & 0xFF0u) : ZSG_OOB);
-            ++kt_next;
-            return;
-        }
-#endif
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int r = rbase + ka + PA * j;
@@ -259,12 +248,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_kernel(const WgParams p
             for (int i = 0; i < TM; ++i) fa[i] = As[buf][k][am + i];
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][k][bn + j];
-#if defined(WG_ABL) && (WG_ABL & 2)       // timing experiment: no fragment reads
-#pragma unroll
-            for (int i = 0; i < TM; ++i) { fa[i] = (float)(kk + i); asm volatile("" : "+v"(fa[i])); }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) { fb[j] = (float)(kk - j); asm volatile("" : "+v"(fb[j])); }
-#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -25,12 +25,6 @@
 #include "bn_tail.h"
 
 #define WN_CK 8
-// WN_ABL (compile-time, default 0): ablation bits for timing experiments ONLY (results are wrong): 1 = every patch load of a lane hits
-// one cache line, 2 = the filter chunk is always chunk 0 (L2-resident), 4 = no MFMAs, 8 = no fragment reads, 16 = no patch loads /
-// transform, 32 = no filter DMA.  tools/wino_ablation.sh builds one library per value.
-#ifndef WN_ABL
-#define WN_ABL 0
-#endif
 
 struct WnSegDev {
     int tiles_y, tiles_x, tiles;   // tile grid per image; tiles = B * tiles_y * tiles_x
@@ -128,7 +122,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const bool pok = rok & ((unsigned)(x0 + c) < (unsigned)sg.W);
-            a_voff[ia][c] = pok ? 4u * (unsigned)((WN_ABL & 1) ? 4 * (tid & 7) : base + c * src_ld) : ZSG_OOB;
+            a_voff[ia][c] = pok ? 4u * (unsigned)(base + c * src_ld) : ZSG_OOB;
             a_voff_t[ia][c] = (pok && !(c_tail && g)) ? a_voff[ia][c] : ZSG_OOB;
         }
         a_lds[ia] = q * SA + t * 8 + 4 * (g ^ ((t >> 3) & 1));
@@ -166,8 +160,8 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     f32x4 ra[IA][4];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto load_a = [&](int c, bool live) {          // c, live: wave-uniform
-        if (!a_thr || !live || (WN_ABL & 16)) return;      // (a dead prefetch leaves ra as it is: it is stored into the idle buffer, never read)
-        const int so = (WN_ABL & 1) ? 0 : c * (WN_CK * 4); // bytes, SGPR
+        if (!a_thr || !live) return;      // (a dead prefetch leaves ra as it is: it is stored into the idle buffer, never read)
+        const int so = c * (WN_CK * 4);      // bytes, SGPR
         if (!(c_tail && c == p.chunks - 1)) {
 #pragma unroll
             for (int ia = 0; ia < IA; ++ia)
@@ -185,8 +179,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     auto load_b = [&](int c, int buf) {              // straight into LDS, no registers
 #if __HIP_DEVICE_COMPILE__      // (the host pass of hipcc cannot type-check the LDS address-space cast; it never runs this body)
         lds_f32* b = (lds_f32*)(Bs + buf * 16 * SB);
-        const int so = (WN_ABL & 2) ? 0 : c * (ustep * 4);   // bytes, SGPR
-        if (WN_ABL & 32) return;
+        const int so = c * (ustep * 4);   // bytes, SGPR
 #pragma unroll
         for (int ib = 0; ib < IB; ++ib)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, b + b_dst[ib], 16, (int)b_voff[ib], so, 0, 0);
@@ -197,7 +190,7 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     // ONE cross-lane operand, i.e. one v_fmac_f32 with a DPP source per value.
     const float sgn = (q == 1) ? 1.f : -1.f;
     auto store_a = [&](int buf) {
-        if (!a_thr || (WN_ABL & 16)) return;
+        if (!a_thr) return;
         float* a = As + buf * 16 * SA;
 #pragma unroll
         for (int ia = 0; ia < IA; ++ia) {
@@ -236,15 +229,8 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     const int frag_b = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + pbase * SB;
     auto mfma_pos = [&](const float* a, const float* b, int pl) {       // position p = j*4 + i: PS 2: pl = j*2 + il, i = 2ph + il; PS 4: pl = j, i = ph
         const int po = (PS == 2) ? (pl >> 1) * 4 + (pl & 1) : pl * 4;
-        f32x4 fa = {1.f, 1.f, 1.f, 1.f}, fb = {1.f, 1.f, 1.f, 1.f};
-        if (!(WN_ABL & 8)) {
-            fa = *(const f32x4*)(a + po * SA);
-            fb = *(const f32x4*)(b + po * SB);
-        }
-        if (WN_ABL & 4) {
-            acc[pl][0] += fa[0] + fb[1];
-            return;
-        }
+        const f32x4 fa = *(const f32x4*)(a + po * SA);
+        const f32x4 fb = *(const f32x4*)(b + po * SB);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[pl], 0, 0, 0);
     };
