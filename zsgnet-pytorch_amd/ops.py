@@ -648,12 +648,11 @@ def _time_launch(fn, args, stream, reps=6):
 TUNE_ROUNDS = int(os.environ.get("ZSG_TUNE_ROUNDS", "5"))
 
 
-def _pick_best(trials, set_hint, stream, penalty, scale=None):
+def _pick_best(trials, set_hint, stream, penalty):
     """Median of TUNE_ROUNDS INTERLEAVED samples per candidate (round r times every surviving candidate once before round r + 1
     starts, so clock / thermal drift and a noisy neighbour hit all candidates alike; one batch of 10 launches per candidate picked
     tiles that differed from process to process and moved the step by +-1 %).  Candidates more than 25 % behind the leader after
-    the first round are dropped.  trials: [(fn, marshalled args, hint, flag)]; returns hint | flag of the winner.
-    scale(hint, flag): factor on the measured time (the weight gradients' CU-time criterion, autotune_conv)."""
+    the first round are dropped.  trials: [(fn, marshalled args, hint, flag)]; returns hint | flag of the winner."""
     live, samples = [], []
     for f, conv, h, flag in trials:
         set_hint(h)
@@ -667,7 +666,7 @@ def _pick_best(trials, set_hint, stream, penalty, scale=None):
             if samples[i] is None:
                 continue
             set_hint(h)
-            samples[i].append(_time_launch(f, conv, stream) * (scale(h, flag) if scale else 1.0) + penalty(h))
+            samples[i].append(_time_launch(f, conv, stream) + penalty(h))
         if r == 0 and live:
             lead = min(s[0] for s in samples if s)
             for i, s_ in enumerate(samples):
@@ -682,9 +681,6 @@ def _pick_best(trials, set_hint, stream, penalty, scale=None):
     return best
 
 
-# ZSG_WG_CUTIME=1: the autotuner ranks weight-gradient candidates by occupied CU-time instead of latency (see autotune_conv)
-WG_CUTIME = os.environ.get("ZSG_WG_CUTIME", "0") == "1"
-WG_CUTIME_FLOOR = float(os.environ.get("ZSG_WG_CUTIME_FLOOR", "0.25"))
 WINO_FLAG = 1 << 30          # tuner result: the Winograd kernel won (its own tile hint in the low bits)
 
 
@@ -777,8 +773,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
                          mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
-                         os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"))
-                + (("cutime",) if (kind == "wgrad" and WG_CUTIME) else ()))
+                         os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0")))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -815,7 +810,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             for bn in (((64, 128) if ncols > 64 else (64,)) + ((255,) if (bm == 64 and d.N <= 64 and 128 < ncols <= 256 and d.out_ld % 4 == 0) else ())):
                 nmn = ((d.N + bm - 1) // bm) * ((ncols + (256 if bn == 255 else bn) - 1) // (256 if bn == 255 else bn))
                 seen = set()
-                for target in ((96, 128, 192) if WG_CUTIME else ()) + (256, 384, 512, 768, 1024, 2048):
+                for target in (256, 384, 512, 768, 1024, 2048):
                     sp = max(1, min(target // nmn, rows // 64, 255))
                     if sp not in seen and sp * d.N * ncols * 4 <= ws_bytes:
                         seen.add(sp)
@@ -834,7 +829,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
         nmn = ((d.N + 63) // 64) * ((d.C + 63) // 64)
         seen = set()
-        for target in ((64, 96) if WG_CUTIME else ()) + (128, 192, 256, 384, 512, 768):
+        for target in (128, 192, 256, 384, 512, 768):
             sp = max(1, min(target // nmn, tiles // 16, 255))
             if sp not in seen and sp * d.N * 9 * d.C * 4 <= ws_bytes:
                 seen.add(sp)
@@ -842,22 +837,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     def set_hint(h):
         d.tile_hint = h
 
-    scale = None
-    if kind == "wgrad" and WG_CUTIME:
-        # Weight gradients run on the side stream under the chain's kernels, which have wave priority (csrc/common.h): what they cost the
-        # step is the CU-time they occupy, not their latency.  A launch that fills only part of the chip (blocks x waves < 256 CUs x 8
-        # waves) is charged that part of its measured time, so a few fat K slices can beat many thin ones that finish sooner.
-        ncols_ = d.seg[0].ty.n * d.seg[0].tx.n * d.C
-
-        def scale(h, flag):
-            sp = max(1, (h >> 16) & 0xff)
-            if flag & WINO_FLAG:
-                blocks, waves = ((d.N + 63) // 64) * ((d.C + 63) // 64) * sp, 8
-            else:
-                bm, bn = (128 if (h & 0xff) >= 128 else 64), (256 if ((h >> 8) & 0xff) == 255 else (128 if ((h >> 8) & 0xff) >= 128 else 64))
-                blocks, waves = ((d.N + bm - 1) // bm) * ((ncols_ + bn - 1) // bn) * sp, (8 if (h >> 24) & 1 else 4)
-            return max(WG_CUTIME_FLOOR, min(1.0, blocks * waves / 2048.0))
-    best = _pick_best(trials, set_hint, stream, lambda h: split_penalty_ms if (kind == "igemm" and ((h >> 16) & 0xff) > 1) else 0.0, scale)
+    best = _pick_best(trials, set_hint, stream, lambda h: split_penalty_ms if (kind == "igemm" and ((h >> 16) & 0xff) > 1) else 0.0)
     d.tile_hint, d.use_wino = best & ~WINO_FLAG, bool(best & WINO_FLAG)
     _TUNE_CACHE[key] = best
     global _TUNE_DIRTY
