@@ -27,6 +27,8 @@ run wino_l3conv2_bnstat      fwd "backbone.encoder.layer3.1.conv2"         "wino
 run igemm_l3conv1_bnstat     fwd "backbone.encoder.layer3.1.conv1"         "igemm_kernel"
 run igemm_l3conv3_bnstat     fwd "backbone.encoder.layer3.1.conv3"         "igemm_kernel"
 run igemm_l3conv1_dgrad_bnb  bwd "dgrad:backbone.encoder.layer3.1.conv1"   "igemm_kernel"
+run mx_stem_fwd              fwd "backbone.encoder.conv1"                  "mx_kernel"
+run igemm_l1conv1_bnpre      fwd "backbone.encoder.layer1.1.conv1"         "igemm_kernel"
 run pw_l1conv3_fwd           fwd "backbone.encoder.layer1.1.conv3"         "pw_kernel"
 run pw_l1conv1_dgrad         bwd "dgrad:backbone.encoder.layer1.1.conv1"   "pw_kernel"
 run bn_apply_l1bn3           fwd "backbone.encoder.layer1.1.bn3"           "bn_apply_kernel"
