@@ -104,7 +104,11 @@ int zsg_conv_igemm(const zsg_conv_desc* d, const float* src, const float* wt, fl
 /* Weight gradient.  dw[n][(r*wS+s)*wC + wc0 + c] (+)= sum_rows dy[row][n] * src[gather(row, r, s)][c]
  * The descriptor is the FORWARD descriptor of the convolution (src = forward input, "out" geometry = dy); all
  * segments (pyramid levels of the shared head) are reduced in the one launch.  The pixel dimension is split over
- * tile_hint's split_k blocks whose partial tiles go to the workspace and are summed in a fixed order (deterministic). */
+ * tile_hint's split_k blocks whose partial tiles go to the workspace and are summed in a fixed order (deterministic).
+ * Limits (error -1 otherwise): every tensor within a 2^29-element window, fewer than 2^24 pixel rows per segment, row pitches and
+ * per-image pixel counts below 2^23; an IMAGE STRIDE of 2^23 elements or more (stem / layer1 maps of inputs beyond ~724x724) is
+ * served by a 32-bit-multiply variant of the 64x64 tile (correct, not tuned).  1x1 / stride-1 / unpadded convolutions over
+ * batch-dense tensors (src_bstride = H*W*src_ld, out_bstride = rows*out_ld) take the address-arithmetic-free DENSE loader. */
 size_t zsg_conv_wgrad_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                    size_t ws_bytes, void* stream);
