@@ -206,7 +206,7 @@ int zsg_wino_weights(const void* jobs, int32_t njobs, int32_t total_blocks, void
 
 /* Winograd F(3x3,2x2) weight gradient of a 3x3 / stride 1 / pad 1 convolution: same contract as zsg_conv_wgrad (forward
  * descriptor, accumulate flag, split-K workspace [splits][N][9*C] with the deterministic slab reduction), 16 instead of
- * 36 multiply-adds per 2x2 output tile.  tile_hint: split_k << 16 (0: heuristic). */
+ * 36 multiply-adds per 2x2 output tile.  tile_hint: split_k << 16 (0: heuristic), bit 24: block order "whole K slices per XCD". */
 size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                         size_t ws_bytes, void* stream);

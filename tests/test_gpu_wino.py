@@ -179,12 +179,18 @@ def test_wino_wgrad(Z, case):
     cp, Cop = pad4(Ci), pad4(Co)
     xd, dyd = dev(nhwc(x)), dev(nhwc(gy, Cop))
     src, dyv = view_of(ops, xd, B, H, W, cp), view_of(ops, dyd, B, H, W, Cop)
-    d = ops.fwd_desc(src, dyv, cp, Co, 3, 1, 1, 1, wC=cp, tile_hint=ops.tile_hint(64, 64, splits))
-    dw = torch.full((Co, 3, 3, cp), float(acc), device="cuda")
-    L.check(L.lib.zsg_conv_wgrad_wino(C.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad_wino")
-    assert_close(dw[..., :Ci].permute(0, 3, 1, 2) - acc, w.grad, 5e-4, 5e-4 * float(w.grad.abs().max()), "wino wgrad")
-    if cp > Ci:
-        assert float((dw[..., Ci:] - acc).abs().max()) == 0.0
+    first = None
+    for xmap in (0, 1):       # tile_hint bit 24: block order "whole K slices per XCD" — the same sums in the same order
+        d = ops.fwd_desc(src, dyv, cp, Co, 3, 1, 1, 1, wC=cp, tile_hint=ops.tile_hint(64, 64, splits, xmap))
+        dw = torch.full((Co, 3, 3, cp), float(acc), device="cuda")
+        L.check(L.lib.zsg_conv_wgrad_wino(C.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad_wino")
+        assert_close(dw[..., :Ci].permute(0, 3, 1, 2) - acc, w.grad, 5e-4, 5e-4 * float(w.grad.abs().max()), "wino wgrad")
+        if cp > Ci:
+            assert float((dw[..., Ci:] - acc).abs().max()) == 0.0
+        if first is None:
+            first = dw.clone()
+        else:
+            assert torch.equal(first, dw), "block order must not change the result"
 
 
 def test_wino_wgrad_multilevel_window(Z):

@@ -34,10 +34,13 @@ struct WwParams {
     float* ws;
     int accumulate;
     int C, N, src_ld, dy_ld, wC, wc0, wt_ld, nseg;
-    int m_tiles, n_tiles, splits, st_total, st_chunk;
+    int m_tiles, n_tiles, splits, st_total, st_chunk, xmap;
     WwSegDev seg[ZSG_MAX_SEG];
 };
 
+__device__ __forceinline__ float buf_load1_s(rsrc_t r, unsigned byte_off, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, soff, 0));
+}
 __device__ __forceinline__ float ww_quad_other(float v) {      // quad_perm [2,2,1,1]
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
 }
@@ -54,8 +57,11 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int nmn = p.m_tiles * p.n_tiles;
-    const int split = blockIdx.x / nmn;
-    const int mn = xcd_remap(blockIdx.x % nmn, nmn);
+    // xmap: an XCD owns WHOLE K slices (all (n, c) blocks of a slice on one L2: the slice's rows of dY / X are fetched into one L2
+    // instead of eight); else the (n, c) blocks of every slice are spread over the XCDs
+    const int lb = p.xmap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int split = lb / nmn;
+    const int mn = p.xmap ? lb % nmn : xcd_remap(lb % nmn, nmn);
     const int mt = mn / p.n_tiles, nt = mn % p.n_tiles;
     const int m0 = mt * 64, n0 = nt * 64;
     const int st_begin = split * p.st_chunk;
@@ -211,7 +217,11 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
 
     // ---- output transform dW = G^T M G, this wave's rows i of M; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] ----------------
     // z[il][v] = sum_j M[i][j] G[j][v];  partial dW[u][v] = sum_il G[2ph+il][u] z[il][v]
-    float* xch = ww_smem;                           // [4 sub-blocks][48][64 lanes] exchange buffer (3 taps x 16 elements)
+    // Both position halves finish HALF of the elements each: half ph hands the other one the 8 accumulator rows it does not finish
+    // (3 taps x 8 elements per lane and round) through LDS, all reads of a round are issued together, and the stores are branch-free
+    // raw-buffer stores (out-of-range offset where the row / column is past N / C).  The per-element form this replaces (LDS read ->
+    // wait -> conditional store, 144 times in half of the waves) cost 10 us per launch: 18 % of the 13-stage launches.
+    float* xch = ww_smem;                           // [2 rounds in flight][2 directions][4 sub-blocks][24][64 lanes]
     const int sub = wave & 3;
     float* dst = p.ws ? p.ws + (size_t)split * p.N * (9 * p.C) : p.dw;
     const int ld = p.ws ? 9 * p.C : p.wt_ld;
@@ -219,6 +229,15 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     const int c = n0 + wn * 32 + li;
     const bool cok = c < p.C;
     const int col0 = p.ws ? c : (p.wc0 + c);
+    const rsrc_t rs_o = make_rsrc(dst);
+    const int nrow0 = m0 + wm * 32 + 4 * lh + 16 * ph;                  // this lane's first finished row: e = 8 ph + (e & 7)
+    unsigned vo[8];                                                       // byte offsets of its 8 rows at tap 0 (level constants)
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) {
+        const int n = nrow0 + (e8 & 3) + 8 * (e8 >> 2);
+        vo[e8] = (cok && n < p.N) ? 4u * (unsigned)(n * ld + col0) : ZSG_OOB;
+    }
+    const bool rmw = !p.ws && p.accumulate;                              // wave-uniform
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         float part[3][16];
@@ -243,27 +262,35 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
                 part[v][e] = y;
             }
         }
-        if (ph == 1) {
+        // hand over the half this wave does not finish: ph 0 gives e = 8..15, ph 1 gives e = 0..7
+        float* give = xch + ((((u & 1) * 2 + ph) * 4 + sub) * 24) * 64 + lane;
+        const float* take = xch + ((((u & 1) * 2 + (ph ^ 1)) * 4 + sub) * 24) * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) give[(v * 8 + e8) * 64] = ph ? part[v][e8] : part[v][8 + e8];
+        __syncthreads();     // (one barrier per round: round u + 2 rewrites this region only after every wave has passed round u + 1's barrier, i.e. read it)
+        float got[3][8];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) got[v][e8] = take[(v * 8 + e8) * 64];
+        float old[3][8];
+        if (rmw) {
 #pragma unroll
             for (int v = 0; v < 3; ++v)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) xch[(sub * 48 + v * 16 + e) * 64 + lane] = part[v][e];
+                for (int e8 = 0; e8 < 8; ++e8) old[v][e8] = buf_load1_s(rs_o, vo[e8], 4 * (u * 3 + v) * tap_ld);
         }
-        __syncthreads();
-        if (ph == 0) {
 #pragma unroll
-            for (int v = 0; v < 3; ++v)
+        for (int v = 0; v < 3; ++v)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int n = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float val = part[v][e] + xch[(sub * 48 + v * 16 + e) * 64 + lane];
-                    if (cok && n < p.N) {
-                        float* o = dst + (size_t)n * ld + (u * 3 + v) * tap_ld + col0;
-                        *o = (!p.ws && p.accumulate) ? *o + val : val;
-                    }
-                }
-        }
-        __syncthreads();
+            for (int e8 = 0; e8 < 8; ++e8) {
+                // the same sum as ever: (rows i = 0, 1 half) + (rows i = 2, 3 half)
+                float val = ph ? got[v][e8] + part[v][8 + e8] : part[v][e8] + got[v][e8];
+                if (rmw) val = old[v][e8] + val;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_o, (int)vo[e8], 4 * (u * 3 + v) * tap_ld, 0);
+            }
     }
 }
 
@@ -289,7 +316,7 @@ extern "C" size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d) {
 }
 
 // Same contract as zsg_conv_wgrad (forward descriptor, dy in the "out" geometry, accumulate flag, split-K workspace,
-// deterministic slab reduction); 3x3 / stride 1 / pad 1 only.  tile_hint: split_k << 16 (0: heuristic).
+// deterministic slab reduction); 3x3 / stride 1 / pad 1 only.  tile_hint: split_k << 16 (0: heuristic), bit 24: block order "whole K slices per XCD".
 static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                                 size_t ws_bytes, void* stream) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad_wino: null argument");
@@ -338,6 +365,7 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
         if (!ws || ws_bytes < need) ZSG_FAIL(-2, "conv_wgrad_wino: workspace too small (%zu < %zu bytes)", ws_bytes, need);
         p.ws = (float*)ws;
     }
+    p.xmap = (d->tile_hint >> 24) & 1;      // tile_hint bit 24: whole K slices per XCD (a tuner candidate: the large launches gain 1-2 %, the 13-stage ones lose 5 %)
     hipStream_t stq = (hipStream_t)stream;
     const size_t lds = (size_t)4 * 16 * WW_SP * sizeof(float);
     static bool attr_done[ZSG_MAX_DEV] = {};

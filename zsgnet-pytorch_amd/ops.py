@@ -834,6 +834,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             if sp not in seen and sp * d.N * 9 * d.C * 4 <= ws_bytes:
                 seen.add(sp)
                 trials.append((lib.zsg_conv_wgrad_wino, wconv, tile_hint(64, 64, sp), WINO_FLAG))
+                if sp > 1 and nmn * sp >= 128:        # block order "whole K slices per XCD" (csrc/winowg.hip: xmap)
+                    trials.append((lib.zsg_conv_wgrad_wino, wconv, tile_hint(64, 64, sp, 1), WINO_FLAG))
     def set_hint(h):
         d.tile_hint = h
 
