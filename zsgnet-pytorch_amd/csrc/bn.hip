@@ -516,22 +516,35 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* _
     if (cok) {
         const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
         const f32x4 sc = is * *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
-        for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-            const int wo = (int)(r % Wo);
-            const int64_t t = r / Wo;
-            const int ho = (int)(t % Ho);
-            const int64_t b = t / Ho;
+        // pooled pixel cursor (b, ho, wo) advanced by rowlanes per trip (one 64-bit division per thread instead of two per trip), window
+        // code / k by a 16-bit reciprocal (exact for code < 256, k <= 15)
+        int64_t r = r_begin + rl;
+        int wo = (int)(r % Wo);
+        int64_t t0 = r / Wo;
+        int ho = (int)(t0 % Ho);
+        int64_t b = t0 / Ho;
+        const unsigned kmag = 65536u / (unsigned)k + 1u;
+        for (; r < r_end; r += rowlanes) {
             const uchar4 u = *(const uchar4*)(idx + r * C + c);
             const f32x4 g = *(const f32x4*)(dout + r * C + c);
             const unsigned code[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int hi = ho * s - p + (int)(code[e] / k), wi = wo * s - p + (int)(code[e] % k);
+                const int cr = (int)((code[e] * kmag) >> 16), cq = (int)code[e] - cr * k;
+                const int hi = ho * s - p + cr, wi = wo * s - p + cq;
                 const float xv = x[((b * H + hi) * W + wi) * C + c + e];
                 const float v = fmaxf(fmaf(xv - mu[e], sc[e], be[e]), 0.f);
                 const float ge = v > 0.f ? g[e] : 0.f;
                 s0[e] += ge;
                 s1[e] += ge * ((xv - mu[e]) * is[e]);
+            }
+            wo += rowlanes;
+            while (wo >= Wo) {
+                wo -= Wo;
+                if (++ho == Ho) {
+                    ho = 0;
+                    ++b;
+                }
             }
         }
     }
@@ -566,24 +579,30 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
     const f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + C + c);
     const int64_t r_begin = (int64_t)blockIdx.x * rpb;
     const int64_t r_end = min(rows, r_begin + (int64_t)rpb);
-    for (int64_t r = r_begin + rl; r < r_end; r += rowlanes) {
-        const int wi = (int)(r % W);
-        const int64_t t = r / W;
-        const int hi = (int)(t % H);
-        const int64_t b = t / H;
+    // input pixel cursor (b, hi, wi) advanced by rowlanes per trip; the windows that contain a pixel are ho in [ceil((hi + p - k + 1) / s),
+    // floor((hi + p) / s)] (two divisions per pixel — shifts for the stem's stride 2 — instead of two per window tap), visited in the
+    // order of the tap loop this replaces (tap row ascending = ho descending): the same sum, bit for bit
+    int64_t r = r_begin + rl;
+    int wi = (int)(r % W);
+    int64_t t0 = r / W;
+    int hi = (int)(t0 % H);
+    int64_t b = t0 / H;
+    const bool s2 = s == 2;
+    for (; r < r_end; r += rowlanes) {
         const f32x4 xv = *(const f32x4*)(x + r * C + c);
         const f32x4 v = bn_pool_val(xv, mu, sc, be);
         f32x4 g = {0, 0, 0, 0};
-        for (int rr = 0; rr < k; ++rr) {
-            const int hn = hi + p - rr;
-            if (hn < 0 || (hn % s) != 0 || hn / s >= Ho) continue;
-            for (int q = 0; q < k; ++q) {
-                const int wn = wi + p - q;
-                if (wn < 0 || (wn % s) != 0 || wn / s >= Wo) continue;
-                const int64_t o = ((b * Ho + hn / s) * Wo + wn / s) * C + c;
+        const int hn0 = hi + p, wn0 = wi + p;
+        const int ho_hi = min(s2 ? (hn0 >> 1) : hn0 / s, Ho - 1), wo_hi = min(s2 ? (wn0 >> 1) : wn0 / s, Wo - 1);
+        const int hlo = hn0 - k + s, wlo = wn0 - k + s;          // ceil((n - k + 1) / s) = floor((n - k + s) / s) for n - k + 1 > 0
+        const int ho_lo = (hn0 - k + 1 <= 0) ? 0 : (s2 ? (hlo >> 1) : hlo / s), wo_lo = (wn0 - k + 1 <= 0) ? 0 : (s2 ? (wlo >> 1) : wlo / s);
+        for (int ho = ho_hi; ho >= ho_lo; --ho) {
+            const int rr = hn0 - ho * s;
+            for (int wo = wo_hi; wo >= wo_lo; --wo) {
+                const int64_t o = ((b * Ho + ho) * Wo + wo) * C + c;
                 const uchar4 u = *(const uchar4*)(idx + o);
                 const f32x4 d = *(const f32x4*)(dout + o);
-                const unsigned code = rr * k + q;
+                const unsigned code = rr * k + (wn0 - wo * s);
                 g[0] += (u.x == code) ? d[0] : 0.f;
                 g[1] += (u.y == code) ? d[1] : 0.f;
                 g[2] += (u.z == code) ? d[2] : 0.f;
@@ -594,6 +613,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
         for (int e = 0; e < 4; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
         const f32x4 xh = (xv - mu) * is;
         *(f32x4*)(dx + r * C + c) = sc * (g - c1 - xh * c2);
+        wi += rowlanes;
+        while (wi >= W) {
+            wi -= W;
+            if (++hi == H) {
+                hi = 0;
+                ++b;
+            }
+        }
     }
 }
 

@@ -29,7 +29,8 @@ class _LossFn(torch.autograd.Function):
         ctx.save_for_backward(grad5)
         ctx.g5_buf = getattr(out5, "_zsg_g5", None)      # the network plan's incoming-gradient buffer, when out5 came from ZSGNet
         mod._last_losses = losses
-        return losses[0].clone()
+        # (a view of the 3-float result, not a copy: one dependent launch less between the loss kernels and the backward)
+        return losses.narrow(0, 0, 1).view(())
 
     @staticmethod
     def backward(ctx, g):
