@@ -467,12 +467,21 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* _
     ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t t = i / C4;
-        const int wo = (int)(t % Wo);
-        t /= Wo;
-        const int ho = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+        int c4, wo, ho, b;
+        if (total < (1ll << 32)) {            // (32-bit divisions: a 64-bit one is ~4x the instructions, and there are three per element)
+            const unsigned iu = (unsigned)i, t1 = iu / (unsigned)C4, t2 = t1 / (unsigned)Wo;
+            c4 = (int)(iu - t1 * (unsigned)C4);
+            wo = (int)(t1 - t2 * (unsigned)Wo);
+            b = (int)(t2 / (unsigned)Ho);
+            ho = (int)(t2 - (unsigned)b * (unsigned)Ho);
+        } else {
+            c4 = (int)(i % C4);
+            int64_t t = i / C4;
+            wo = (int)(t % Wo);
+            t /= Wo;
+            ho = (int)(t % Ho);
+            b = (int)(t / Ho);
+        }
         const f32x4 mu = *(const f32x4*)(mean + 4 * c4);
         const f32x4 sc = *(const f32x4*)(invstd + 4 * c4) * *(const f32x4*)(gamma + 4 * c4);
         const f32x4 be = *(const f32x4*)(beta + 4 * c4);

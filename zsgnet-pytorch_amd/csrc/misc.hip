@@ -9,18 +9,40 @@ static inline int grid_for(int64_t n_items, int block = 256, int cap = ZSG_NUM_C
     return (int)(b > cap ? cap : b);
 }
 
+// i -> (c4, x, y, b) of a [B][Y][X][C4] index space: 32-bit divisions when the space allows (a 64-bit division is ~4x the instructions,
+// and these element-wise kernels are otherwise a load and a store)
+__device__ __forceinline__ void decomp4(int64_t i, int64_t total, int C4, int X, int Y, int& c4, int& x, int& y, int& b) {
+    if (total < (1ll << 32)) {
+        const unsigned iu = (unsigned)i, t1 = iu / (unsigned)C4, t2 = t1 / (unsigned)X;
+        c4 = (int)(iu - t1 * (unsigned)C4);
+        x = (int)(t1 - t2 * (unsigned)X);
+        b = (int)(t2 / (unsigned)Y);
+        y = (int)(t2 - (unsigned)b * (unsigned)Y);
+    } else {
+        c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        x = (int)(t % X);
+        t /= X;
+        y = (int)(t % Y);
+        b = (int)(t / Y);
+    }
+}
+// windows of a k / stride s / pad p pooling that contain input coordinate n: o in [lo, hi] (empty when lo > hi); tap index = n + p - o*s
+__device__ __forceinline__ void pool_windows(int n, int k, int s, int p, int On, int& lo, int& hi) {
+    const int np = n + p;
+    hi = min(s == 2 ? (np >> 1) : (s == 1 ? np : np / s), On - 1);
+    const int num = np - k + 1;
+    lo = num <= 0 ? 0 : (s == 2 ? ((num + 1) >> 1) : (s == 1 ? num : (num + s - 1) / s));
+}
+
 // ---- max pool -------------------------------------------------------------------------------------------------
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C4, int k, int s, int p, int Ho, int Wo,
                                    float* __restrict__ out, uint8_t* __restrict__ idx) {
     ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t t = i / C4;
-        const int wo = (int)(t % Wo);
-        t /= Wo;
-        const int ho = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+        int c4, wo, ho, b;
+        decomp4(i, total, C4, Wo, Ho, c4, wo, ho, b);
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {0, 0, 0, 0};
         for (int r = 0; r < k; ++r) {
@@ -51,28 +73,20 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t
     ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * H * W * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t t = i / C4;
-        const int wi = (int)(t % W);
-        t /= W;
-        const int hi = (int)(t % H);
-        const int b = (int)(t / H);
+        int c4, wi, hi, b;
+        decomp4(i, total, C4, W, H, c4, wi, hi, b);
         f32x4 acc = {0, 0, 0, 0};
-        // windows (ho, r) with ho*s - p + r == hi
-        for (int r = 0; r < k; ++r) {
-            const int hn = hi + p - r;
-            if (hn < 0 || (hn % s) != 0) continue;
-            const int ho = hn / s;
-            if (ho >= Ho) continue;
-            for (int q = 0; q < k; ++q) {
-                const int wn = wi + p - q;
-                if (wn < 0 || (wn % s) != 0) continue;
-                const int wo = wn / s;
-                if (wo >= Wo) continue;
+        // windows (ho, r) with ho*s - p + r == hi, in the order of the tap loop r = 0 .. k-1 (ho descending): the same sum, bit for bit
+        int ho_lo, ho_hi, wo_lo, wo_hi;
+        pool_windows(hi, k, s, p, Ho, ho_lo, ho_hi);
+        pool_windows(wi, k, s, p, Wo, wo_lo, wo_hi);
+        for (int ho = ho_hi; ho >= ho_lo; --ho) {
+            const int r = hi + p - ho * s;
+            for (int wo = wo_hi; wo >= wo_lo; --wo) {
                 const int64_t o = ((((int64_t)b * Ho + ho) * Wo + wo) * C4 + c4) * 4;
                 const uchar4 u = *(const uchar4*)(idx + o);
                 const f32x4 g = *(const f32x4*)(dout + o);
-                const int code = r * k + q;
+                const int code = r * k + (wi + p - wo * s);
                 acc[0] += (u.x == code) ? g[0] : 0.f;
                 acc[1] += (u.y == code) ? g[1] : 0.f;
                 acc[2] += (u.z == code) ? g[2] : 0.f;
