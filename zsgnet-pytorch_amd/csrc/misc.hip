@@ -303,7 +303,15 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ img, int B, int C
     ZSG_SET_MAIN_PRIO();
     const int64_t total = (int64_t)B * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / HW, px = i % HW;
+        int64_t b, px;
+        if (total < (1ll << 32)) {            // (one 32-bit division instead of two 64-bit ones per pixel)
+            const unsigned bu = (unsigned)i / (unsigned)HW;
+            b = bu;
+            px = (unsigned)i - bu * (unsigned)HW;
+        } else {
+            b = i / HW;
+            px = i % HW;
+        }
         f32x4 v = {0, 0, 0, 0};
         for (int c = 0; c < C && c < 4; ++c) v[c] = img[(b * C + c) * HW + px];
         *(f32x4*)(out + i * 4) = v;
