@@ -379,6 +379,38 @@ def test_query_length_buckets_share_one_plan(Z):
     assert len(net._plans) == 2 and float((o37 - outs[0]).abs().max()) < tol
 
 
+def test_caller_owns_the_output_tensor(Z):
+    """ZSGNet.forward returns a tensor of its own, as the reference's module does (mdl.py:338-403): the launches that produce the
+    [B, A, 5] output write straight into a fresh tensor (no copy out of the plan's buffers), so a result kept across later forwards
+    keeps its values; the copying path (ZSG_FRESH_OUT=0 -> _out_slots() is None) gives the same numbers."""
+    cfg, net, sd, lf, ev = build(Z, arch="resnet18", seed=3)
+    h0, c0 = torch.zeros(2, 2, 128), torch.zeros(2, 2, 128)
+    for training in (False, True):
+        net.train(training)
+        outs, keep = [], []
+        for seed in (21, 22, 21):
+            inp = to_dev(O.synthetic_batch(2, 96, 96, seed=seed))
+            inp["h0"], inp["c0"] = h0, c0
+            with torch.set_grad_enabled(training):
+                o = net(inp)["att_bbx_out"]
+            outs.append(o)
+            keep.append(o.detach().clone())
+        plan = [p for k, p in net._plans.items() if k[-1] == training][0]
+        assert plan._out_slots(), "the default configuration must take the direct-output path"
+        assert len({o.data_ptr() for o in outs}) == 3, "every forward returns its own tensor"
+        for o, k in zip(outs, keep):
+            assert torch.equal(o.detach(), k), "a later forward must not touch an earlier result"
+        assert not torch.equal(keep[0], keep[1])
+        if not training:      # the same input gives the same output (up to the summation order of atomic split-K launches), through either path
+            tol = 1e-4 * float(keep[0].abs().max())
+            assert float((keep[0] - keep[2]).abs().max()) < tol
+            plan._out_slots_v = None            # the copying path
+            with torch.no_grad():
+                o = net(inp)["att_bbx_out"]
+            assert float((o - keep[2]).abs().max()) < tol
+            plan._out_slots_v = False
+
+
 def test_one_launch_input_staging_equals_torch_copies(Z, monkeypatch):
     """run_forward's one-launch input staging (zsg_stage_inputs: qvec into the zero-padded token bucket, qlens int64 / float, the
     host-drawn h0 | c0 from a pinned ring slot, num_batches_tracked += 1) stages exactly what the separate torch copies of rounds 1-4

@@ -5,9 +5,11 @@
 #                            counters (tools/pmc_round5.sh) -> co-issue micro-benchmark -> loader rate
 # Everything lands under gpurun_out/r05final/; the builder copies what is judged into profiles/r05_*.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05final; mkdir -p $O; cd $R
-Q="--no-cpu-baseline --no-roofline"
+Q="--no-cpu-baseline --no-roofline --other-configs off"
 if [ "$1" = "A" ]; then
-  python tools/make_tuning_table.py r50 r18 ssd r101 > $O/make_table.log 2>&1
+  # (tools/_tunings/seed.json: the fastest of six fresh tunings of the headline configuration, refined in-step — tools/best_of_tunings.sh, refine_tuning.py)
+  SEED=""; [ -f tools/_tunings/seed.json ] && SEED="--seed tools/_tunings/seed.json"
+  python tools/make_tuning_table.py $SEED r50 r18 ssd r101 > $O/make_table.log 2>&1
   cp zsgnet-pytorch_amd/tuning/gfx950.json $O/gfx950.json
   { echo "# five fresh processes, shipped table (python bench.py --steps 100 --warmup 20 $Q)"
     for i in 1 2 3 4 5; do python bench.py --steps 100 --warmup 20 $Q 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"tuning": {[^}]*}' | tr '\n' ' '; echo; done

@@ -1,7 +1,10 @@
 """Developer tool (GPU box): build the shipped tuning table zsgnet-pytorch_amd/tuning/gfx950.json.
 Lowers (= autotunes, median of ZSG_TUNE_ROUNDS interleaved samples per candidate) the training and eval plans of the BASELINE.json
 configurations in a FRESH tuning state and writes every choice with the sha256 stamp of the kernel sources.
-usage: ZSG_SHIPPED_TUNE=0 python tools/make_tuning_table.py [out.json] [configs: r50 r18 ssd r101 ...]"""
+usage: ZSG_SHIPPED_TUNE=0 python tools/make_tuning_table.py [out.json] [--seed cache.json] [configs: r50 r18 ssd r101 ...]
+--seed: start from the choices of a tuning cache (ZSG_TUNE_CACHE format) instead of an empty state — tools/best_of_tunings.sh selects, among
+N complete fresh tunings of the headline configuration, the one whose STEP is fastest (the tuner ranks single launches by latency; which of
+two near-equal tiles is better inside the two-stream step it cannot see), and the table is then built around it."""
 import json
 import os
 import sys
@@ -45,6 +48,9 @@ def lower(arch, B, img, backbone):
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else ops.SHIPPED_TABLE
     names = [a for a in sys.argv[1:] if a in CONFIGS] or ["r50", "r18"]
+    seed = sys.argv[sys.argv.index("--seed") + 1] if "--seed" in sys.argv else None
+    if seed:
+        print(f"seeded with {ops.load_tune_cache(seed)} choices from {seed}", flush=True)
     for n in names:
         n0 = len(ops._TUNE_CACHE)
         lower(**CONFIGS[n])
@@ -52,7 +58,7 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     with open(out, "w") as f:
         json.dump({"source_stamp": ops.source_stamp(), "device": torch.cuda.get_device_name(0), "tune_rounds": ops.TUNE_ROUNDS,
-                   "configs": names, "entries": {repr(k): v for k, v in sorted(ops._TUNE_CACHE.items(), key=lambda kv: repr(kv[0]))}}, f, indent=0)
+                   "configs": names, "seeded": bool(seed), "entries": {repr(k): v for k, v in sorted(ops._TUNE_CACHE.items(), key=lambda kv: repr(kv[0]))}}, f, indent=0)
     print(f"wrote {out}: {len(ops._TUNE_CACHE)} entries, stamp {ops.source_stamp()}")
 
 
