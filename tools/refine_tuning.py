@@ -3,6 +3,7 @@
 on which the given caches disagree, every alternative choice is tried on top of the current best cache and kept when the step gets faster by
 more than the noise (two confirming runs).
 usage: python tools/refine_tuning.py <best.json> <other1.json> [...]   -> <best>.refined.json + a log on stdout
+       python tools/refine_tuning.py <best.json> --toggle-w8        ... every direct-kernel entry with the 8-wave workgroup bit flipped
        python tools/refine_tuning.py <best.json> --toggle24        the alternatives are every Winograd entry with tile_hint bit 24 flipped (forward /
                                                                    data gradient: four position groups <-> two; weight gradient: the block order)"""
 import json
@@ -27,6 +28,9 @@ def step_ms(cache: dict) -> float:
 
 best = json.load(open(sys.argv[1]))
 others = [json.load(open(p)) for p in sys.argv[2:] if not p.startswith("--")]
+if "--toggle-w8" in sys.argv:      # direct kernels: the 8-wave workgroup variants (implicit GEMM: every tile; weight gradient: the 128x128 tile)
+    others.append({k: v ^ (1 << 24) for k, v in best.items()
+                   if not (v & 0x40000000) and ((k.startswith("('igemm'") and (v & 0xff) in (64, 128)) or (k.startswith("('wgrad'") and (v & 0xffff) == 0x8080))})
 if "--toggle24" in sys.argv:
     others.append({k: v ^ (1 << 24) for k, v in best.items() if v & 0x40000000})
 base = min(step_ms(best), step_ms(best))
