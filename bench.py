@@ -167,6 +167,7 @@ def parse():
     ap.add_argument("--tokens", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--forward-leg", action="store_true", help="time the forward-only leg also under --no-roofline (tuning tools)")
     ap.add_argument("--no-bx", action="store_true", help="(accepted and ignored: the bf16x6 leg was removed in round 4)")
     ap.add_argument("--prof-out", default="")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in the RCCL data-parallel reducer even at world size 1 (smoke test)")
@@ -407,7 +408,7 @@ def main():
     # (the forward-only leg runs BEFORE the per-kernel profiled legs: bracketing every launch with timing events leaves the
     # process ~3 % slower afterwards)
     fwd = None
-    if not a.no_roofline:          # every rank (the training forward of a DDP model broadcasts the BatchNorm buffers)
+    if not a.no_roofline or a.forward_leg:          # every rank (the training forward of a DDP model broadcasts the BatchNorm buffers)
         # grad mode ON, as in a training step: the forward then also co-schedules the backward's weight preparation on the side
         # stream (mdl._Plan.run_forward), which a no_grad forward would leave out.  (The 21 forwards advance the BatchNorm running
         # statistics; nothing below depends on them.)

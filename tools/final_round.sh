@@ -28,5 +28,9 @@ else
   bash tools/pmc_round5.sh > $O/pmc.log 2>&1
   [ -x tools/ubench/build/mfma_coissue ] && timeout 600 tools/ubench/build/mfma_coissue > $O/mfma_coissue.txt 2>&1
   timeout 900 python tools/loader_rate.py > $O/loader_rate.txt 2>&1
+  # gpurun merges at most 64 MiB back: keep the summaries (gpurun_out/profiles_r05, pmc_r05/{summary.txt,counters.json,*.info}), drop the raw traces
+  rm -rf $R/gpurun_out/rp_r05/stats $R/gpurun_out/rp_r05/stats_serial $R/gpurun_out/rp_r05/fetch $R/gpurun_out/rp_r05/write
+  find $R/gpurun_out/pmc_r05 -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+  du -sh $R/gpurun_out
 fi
 ls -la $O
