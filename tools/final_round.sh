@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-end measurement cycle on ONE GPU box, kernel sources frozen (any csrc edit invalidates the table's stamp):
-#   tools/final_round.sh A   tuning table -> reproducibility runs -> full bench.py -> the other configurations
+#   (before A, once per source stamp: tools/best_of_tunings.sh 6 -> tools/refine_tuning.py best.json c*.json -> tools/_tunings/seed.json)
+#   tools/final_round.sh A   tuning table (seeded) -> reproducibility runs -> full bench.py -> the other configurations
 #   tools/final_round.sh B   rocprofv3 stats + HBM traffic (tools/rocprof_round.sh) -> bench.py with the fresh traffic file -> PMC
 #                            counters (tools/pmc_round5.sh) -> co-issue micro-benchmark -> loader rate
 # Everything lands under gpurun_out/r05final/; the builder copies what is judged into profiles/r05_*.
