@@ -9,7 +9,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05final; mkdir -p $O; cd $R
 Q="--no-cpu-baseline --no-roofline --other-configs off"
 if [ "$1" = "A" ]; then
   # (tools/_tunings/seed.json: the fastest of six fresh tunings of the headline configuration, refined in-step — tools/best_of_tunings.sh, refine_tuning.py)
-  SEED=""; [ -f tools/_tunings/seed.json ] && SEED="--seed tools/_tunings/seed.json"
+  # (used only for the sources it was made on: seed.stamp = the csrc stamp; after a kernel edit the tunings have to be made again)
+  CUR=$(python3 zsgnet-pytorch_amd/csrc/stamp.py | grep -o '"[0-9a-f]*"' | tr -d '"')
+  SEED=""; [ -f tools/_tunings/seed.json ] && [ "$(cat tools/_tunings/seed.stamp 2>/dev/null)" = "$CUR" ] && SEED="--seed tools/_tunings/seed.json"
+  echo "seed: ${SEED:-none (stamp $CUR)}" > $O/seed_used.txt
   python tools/make_tuning_table.py $SEED r50 r18 ssd r101 > $O/make_table.log 2>&1
   cp zsgnet-pytorch_amd/tuning/gfx950.json $O/gfx950.json
   { echo "# five fresh processes, shipped table (python bench.py --steps 100 --warmup 20 $Q)"
