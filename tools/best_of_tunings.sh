@@ -26,4 +26,5 @@ best = min(m, key=m.get)
 open("$O/summary.txt", "a").write("# mean ms/step: " + " ".join(f"{k}={v:.3f}" for k, v in sorted(m.items())) + f"\n# best: {best}\n")
 import shutil; shutil.copy("$O/" + best + ".json", "$O/best.json")
 PY
+python3 zsgnet-pytorch_amd/csrc/stamp.py | grep -o '"[0-9a-f]*"' | tr -d '"' > $O/best.stamp      # -> tools/_tunings/seed.stamp beside seed.json
 cat $O/summary.txt
