@@ -3,9 +3,10 @@
 # processes; the cache with the fastest step seeds the shipped table (tools/make_tuning_table.py --seed).  The tuner ranks the candidates of
 # ONE launch by latency (median of interleaved samples); fresh tunings of one build still differ by ~0.5 % of the step, because near-equal tiles
 # behave differently beside the other stream's kernels — that part is only visible in the step itself.
-#   tools/best_of_tunings.sh [N=6]  -> gpurun_out/tunings/{c<i>.json, summary.txt, best.json}
-R=${GRAFT_REPO_ROOT:-/root/repo}; N=${1:-6}; O=$R/gpurun_out/tunings; mkdir -p $O; cd $R
-B="python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --other-configs off"
+#   tools/best_of_tunings.sh [N=6] [tag] -> gpurun_out/tunings<tag>/{c<i>.json, summary.txt, best.json}     (AB_ARGS: another configuration, e.g.
+#   AB_ARGS="--backbone ssd_vgg --bs 32" tools/best_of_tunings.sh 4 _ssd)
+R=${GRAFT_REPO_ROOT:-/root/repo}; N=${1:-6}; O=$R/gpurun_out/tunings$2; mkdir -p $O; cd $R
+B="python bench.py --steps ${AB_STEPS:-100} --warmup 20 --no-cpu-baseline --no-roofline --other-configs off ${AB_ARGS:-}"
 G='"ms_per_step": [0-9.]*'
 : > $O/summary.txt
 for i in $(seq $N); do
