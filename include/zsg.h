@@ -88,7 +88,10 @@ typedef struct {
     int32_t nseg;
     int32_t tile_hint;    /* 0 heuristic, else BM | (BN << 8) | (split_k << 16) | variant bits; chosen by the host autotuner.
                            * bit 24: 8-wave workgroup (igemm, wgrad) / four position groups (wino); bit 25: 32-pixel K tiles
-                           * (wgrad); bit 27 (igemm): 64-deep K tiles                                                         */
+                           * (wgrad); bit 27 (igemm): 64-deep K tiles; bits 28-29 (igemm): stream-K with 1..3 workgroups per CU —
+                           * 256 x that many workgroups share the (tile, K step) units evenly, cut tiles are completed in a fixed
+                           * order (deterministic; needs zsg_set_stream_workspace, fewer tiles than workgroups, one segment,
+                           * split_k <= 1)                                                                                    */
     zsg_seg seg[ZSG_MAX_SEG];
 } zsg_conv_desc;
 
@@ -424,6 +427,15 @@ int zsg_adam_step_range(float* p, const float* g, float* m, float* v, int64_t n,
                         float weight_decay, float grad_scale, int32_t* step_count, int32_t publish, void* stream);
 
 int zsg_memset_f32(float* p, int64_t n, float value, void* stream);
+
+/* Scratch for the launches of one stream (round 6).  The reference has no counterpart: cuDNN / cuBLAS take their split-K workspace from
+ * PyTorch's caching allocator behind nn.Conv2d (mdl.py:149-156, fpn_resnet.py:86-100).  Here the caller owns it: `ws` (256-byte aligned,
+ * more than 16 KB; device memory of the current device) serves every later libzsg launch on `stream` that needs scratch — today the
+ * stream-K implicit GEMM (tile_hint bits 28-29: one partial accumulator tile per workgroup + hand-off flags).  Launches of one stream are
+ * ordered, so they share the buffer; two streams that run such launches concurrently register one buffer each.  The call clears the
+ * first 16 KB (the flags) on `stream`; launches leave them zero.  ws = NULL unregisters.  A launch that needs scratch on a stream
+ * without a registered buffer fails with -1, with a buffer that is too small with -2. */
+int zsg_set_stream_workspace(void* stream, void* ws, size_t bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Cross-stream ordering without marker packets (SURVEY 8b "Threading / streams": asynchronous launches on the passed stream, a

@@ -37,6 +37,10 @@ CASES = [
     # many partial rows (100 / 200)
     (4, 64, 64, 40, 40, 1, 1, False, True, "igemm", (64, 64, 0)),
     (4, 64, 32, 40, 40, 3, 1, True, True, "wino", (32, 64, 1)),
+    # stream-K launches (hint: bm, bn, w8, k64, workgroups per CU): sums and in-kernel finalize by the workgroups that finish the tiles
+    (16, 256, 1024, 19, 19, 1, 1, True, True, "igemm", (64, 64, 1, 1, 2)),     # layer3 conv3's data gradient (K = 1024) at the bench shape
+    (16, 512, 2048, 10, 10, 1, 1, False, True, "igemm", (128, 64, 1, 0, 1)),   # layer4 conv3's
+    (2, 64, 256, 19, 19, 1, 1, True, False, "igemm", (128, 128, 1, 0, 1)),
 ]
 
 
@@ -82,8 +86,8 @@ def test_dgrad_with_bn_backward_sums(Z, case):
         fn_plain, fn_bnb = L.lib.zsg_conv_wino, L.lib.zsg_conv_wino_bnb
         chunks = (B * ((H + 1) // 2) * ((W + 1) // 2) + tb - 1) // tb
     else:
-        bm, bn, w8 = hint3
-        hint = ops.tile_hint(bm, bn, 1, w8)
+        bm, bn, w8, k64, bpc = (tuple(hint3) + (0, 0))[:5]
+        hint = ops.tile_hint(bm, bn, 1, w8) | (k64 << 27) | (bpc << 28)
         wop = wt
         fn_plain, fn_bnb = L.lib.zsg_conv_igemm, L.lib.zsg_conv_igemm_bnb
 

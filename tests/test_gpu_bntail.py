@@ -28,6 +28,11 @@ CASES = [
     (16, 256, 256, 19, 19, 3, 1, "wino", (64, 64, 0)),          # wino_kernel<2,2,2>
     (16, 512, 512, 10, 10, 3, 1, "wino", (32, 32, 1)),          # layer4 conv2
     (2, 64, 64, 7, 9, 3, 1, "wino", (64, 32, 0)),
+    # stream-K launches (hint: bm, bn, w8, k64, workgroups per CU): the finishing workgroup of a cut tile writes the partial row and arrives
+    (16, 1024, 256, 19, 19, 1, 1, "igemm", (64, 64, 1, 1, 2)),   # layer3 conv1: 364 tiles over 512 workgroups
+    (16, 1024, 256, 19, 19, 1, 1, "igemm", (128, 128, 1, 0, 1)), # the same as 92 tiles of 128x128 over 256 workgroups
+    (16, 2048, 512, 10, 10, 1, 1, "igemm", (128, 64, 1, 0, 1)),  # layer4 conv1
+    (16, 2048, 512, 10, 10, 1, 1, "igemm", (64, 64, 0, 0, 1)),   # 200 tiles over 256 workgroups
 ]
 
 
@@ -53,8 +58,8 @@ def test_conv_with_in_kernel_bn_statistics(Z, case):
         fn_plain, fn_tail = L.lib.zsg_conv_wino, L.lib.zsg_conv_wino_bnstat
         chunks = (B * ((H + 1) // 2) * ((W + 1) // 2) + tb - 1) // tb
     else:
-        bm, bn, w8 = hint3
-        hint = ops.tile_hint(bm, bn, 1, w8)
+        bm, bn, w8, k64, bpc = (tuple(hint3) + (0, 0))[:5]
+        hint = ops.tile_hint(bm, bn, 1, w8) | (k64 << 27) | (bpc << 28)
         wop = wd
         fn_plain, fn_tail = L.lib.zsg_conv_igemm, L.lib.zsg_conv_igemm_bnstat
         chunks = (rows + bm - 1) // bm

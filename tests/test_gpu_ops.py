@@ -18,7 +18,20 @@ def Z():
         pytest.skip("no GPU")
     import zsgnet_pytorch_amd._lib as L
     import zsgnet_pytorch_amd.ops as ops
+    stream_scratch(L)
     return L, ops
+
+
+_SCRATCH = {}
+
+
+def stream_scratch(L, stream=None, mb=40):
+    """caller-owned scratch of the stream-K launches (zsg_set_stream_workspace), registered once per stream"""
+    key = L.stream_ptr() if stream is None else stream
+    if key not in _SCRATCH:
+        _SCRATCH[key] = torch.zeros(mb << 18, device="cuda")
+        L.check(L.lib.zsg_set_stream_workspace(C.c_void_p(key), _SCRATCH[key].data_ptr(), _SCRATCH[key].numel() * 4), "set_stream_workspace")
+    return _SCRATCH[key]
 
 
 def dev(t):
@@ -105,20 +118,20 @@ CONV_CASES = [
     (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 128 | (64 << 8) | (1 << 24) | (1 << 27)),
     (2, 256, 256, 9, 9, 1, 1, 0, 1, False, False, False, 128 | (128 << 8) | (1 << 24) | (1 << 27)),
     (3, 128, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 27)),
-    # staggered K groups (tile_hint bit 28, 64x64 8-wave tile): one K tile, odd / even tile counts, taps + padding + stride, epilogue terms
+    # stream-K (tile_hint bits 28-29 = workgroups per CU): one K tile, odd / even tile counts, taps + padding + stride, epilogue terms
     (2, 32, 64, 16, 16, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (2, 64, 256, 16, 16, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (2, 96, 128, 17, 15, 3, 1, 1, 1, True, True, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (1, 1024, 256, 19, 19, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
     (3, 160, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 28)),
-    # three-buffer ring (tile_hint bit 29): K of one / two / three / many tiles, every tile shape it exists for
-    (2, 32, 64, 16, 16, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 29)),
-    (2, 64, 256, 16, 16, 1, 1, 0, 1, True, True, False, 64 | (64 << 8) | (1 << 24) | (1 << 29)),
-    (2, 96, 128, 17, 15, 3, 1, 1, 1, True, True, False, 128 | (64 << 8) | (1 << 29)),
-    (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 128 | (64 << 8) | (1 << 24) | (1 << 29)),
-    (1, 1024, 256, 19, 19, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 24) | (1 << 29)),
-    (3, 160, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (1 << 29)),
+    # stream-K, two workgroups per CU: K of one / two / three / many tiles, every tile shape it exists for
+    (2, 32, 64, 16, 16, 1, 1, 0, 1, False, False, False, 64 | (64 << 8) | (2 << 28)),
+    (2, 64, 256, 16, 16, 1, 1, 0, 1, True, True, False, 64 | (64 << 8) | (1 << 24) | (1 << 27) | (2 << 28)),
+    (2, 96, 128, 17, 15, 3, 1, 1, 1, True, True, False, 128 | (64 << 8) | (1 << 24) | (2 << 28)),
+    (2, 64, 192, 21, 21, 3, 2, 1, 1, True, False, False, 128 | (128 << 8) | (1 << 24) | (2 << 28)),
+    (1, 1024, 256, 19, 19, 1, 1, 0, 1, False, False, False, 128 | (128 << 8) | (2 << 28)),
+    (3, 160, 64, 11, 13, 1, 2, 0, 1, False, False, False, 64 | (64 << 8) | (3 << 28)),
 ]
 
 

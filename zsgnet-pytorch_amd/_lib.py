@@ -123,6 +123,7 @@ SIGNATURES = {
     "zsg_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "zsg_adam_step_range": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, I32, P]),
     "zsg_memset_f32": (I32, [P, I64, F32, P]),
+    "zsg_set_stream_workspace": (I32, [P, P, SZ]),
     "zsg_event_create": (P, []),
     "zsg_event_destroy": (I32, [P]),
     "zsg_set_completion_event": (I32, [P]),

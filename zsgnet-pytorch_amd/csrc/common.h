@@ -78,6 +78,13 @@ extern thread_local int zsg_tls_completion_uses;
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                              \
     } while (0)
 
+// ---- per-stream scratch (api.cpp; zsg_set_stream_workspace) ----------------------------------------------------------------
+// The caller registers one scratch buffer per stream; launches of one stream are ordered, so they can share it.  The first
+// ZSG_SK_FLAG_BYTES are hand-off flags (zeroed at registration, left zero by every launch), the rest partial-tile slots.
+#define ZSG_SK_FLAG_BYTES 16384
+#define ZSG_SK_ERR_WORD (ZSG_SK_FLAG_BYTES / 4 - 1)      // the last flag word: set when a stream-K finisher gave up waiting (bounded poll)
+void* zsg_stream_workspace(hipStream_t st, size_t* bytes);
+
 // ---- per-launch profiling (prof.cpp) --------------------------------------------------------------------------
 struct ZsgProfScope {
     int slot;

@@ -61,6 +61,11 @@ struct IgParams {
     BnbDev bnb;       // bnb.x != nullptr: `stats` receives BatchNorm-BACKWARD partials of the stored values (see common.h)
     BnTail tail;      // tail.tickets != nullptr: the last-arriving tile of a column block finalises the statistics (bn_tail.h)
     IgPre pre;        // PRE kernels only
+    // stream-K (SK kernels only; tile_hint bits 28-29): sk_grid workgroups share the launch's (tile, K step) units evenly, sk_per
+    // consecutive units each; a tile cut between workgroups is completed by the one that holds its FIRST K step
+    int sk_grid, sk_per;
+    float* sk_ws;         // partial accumulator tiles, one BM x BN slot per workgroup (zsg_set_stream_workspace)
+    unsigned* sk_flags;   // one word per workgroup: "its partial tile is published"; zero at entry, zero at exit
     IgSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -74,13 +79,29 @@ struct IgParams {
 // that no MFMA overlaps (address arithmetic, load issue, fragment-read latency, the barrier: tools/igemm_model.py, profiles/
 // r03_igemm_model_*.txt), which at one or two resident blocks per CU is 25-45 % of a step — at twice the LDS per block.
 //
+// (SK: four waves per SIMD = 128 registers — inside the pass loop hipcc otherwise parks every hoisted constant in a register of its own,
+// 114 -> 244 registers, and a CU holds ONE stream-K workgroup where the launch counts on two.)
 // __launch_bounds__' second argument (two waves per SIMD = at most 256 registers per lane): without it hipcc parks the accumulators
 // of the 4-wave tiles in AGPRs and copies one tile in and out of them every K step (32 v_accvgpr moves per 16 MFMAs — VALU-class
 // instructions that are paid in full next to fp32 MFMAs).  The 64-deep 128x128 4-wave tile needs more than 256 registers.
-template <int BM, int BN, int NW, bool MERGE_X, int KS = 1, int BK = IG_BK, bool PRE = false>
-__global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && NW * KS <= 4) ? 1 : 2) void igemm_kernel(const IgParams p) {
+//
+// SK (stream-K, round 6; tile_hint bits 28-29 = workgroups per CU): the grids of layer3 / layer4's 1x1 convolutions are one to two rounds of tiles on 256 CUs (364 tiles of 64x64 =
+// two rounds at 71 %; 184 tiles of 128x64 = 72 idle CUs).  With SK the launch has a FIXED number of workgroups (256 x blocks-per-CU) and
+// the work is cut into (tile, K step) units dealt evenly: workgroup l owns units [l * per, (l + 1) * per) in tile-major order, i.e. the
+// tail of one tile (its last K steps) followed by the head of the next.  The workgroup that holds a tile's first K step FINISHES the tile:
+// it adds the partial accumulator tiles of the workgroups behind it in workgroup order (fixed order: deterministic) and runs the complete
+// epilogue (fused BatchNorm partials, in-kernel finalize and all) — nothing downstream changes.  A workgroup works through its range in
+// ascending order, so its producer segment (a tile's tail) always comes first and never waits: the finisher's poll cannot deadlock
+// whatever the dispatch order (producers only need to be dispatched, and a waiting finisher holds one workgroup slot).  Hand-off
+// (MI355X_MICROARCH.md, inter-workgroup visibility): partial tile by 16-byte write-through (sc1) stores -> every storing wave drains
+// (s_waitcnt vmcnt(0)) -> barrier -> one relaxed agent-scope flag store; the finisher polls the flag with relaxed agent-scope loads
+// (+ s_sleep), re-zeroes it, and reads the tile with sc1 loads.  No fences (an agent-scope release writes back the XCD's whole L2).
+template <int BM, int BN, int NW, bool MERGE_X, int KS = 1, int BK = IG_BK, bool PRE = false, bool SK = false>
+__global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && NW * KS <= 4) ? 1 : (SK && !(BM * BN >= 128 * 128 && NW * KS <= 4)) ? 4 : 2)
+void igemm_kernel(const IgParams p) {
     ZSG_SET_MAIN_PRIO();
     static_assert(!PRE || !MERGE_X, "the BatchNorm-applying loader is for 1x1 convolutions");
+    static_assert(!SK || (!PRE && !MERGE_X), "stream-K: plain single-segment convolutions");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per K group");
     constexpr int WM = (NW == 8 && BN == 64) ? 4 : 2, WN = NW / WM;     // the wave grid over the tile
     constexpr int NB = 2;                    // LDS tile buffers
@@ -99,6 +120,18 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     float* Bs = smem + NB * BM * LDR;                  // [NB][BN][LDR]
     int* rowout = (int*)(smem + NB * (BM + BN) * LDR); // [BM]
 
+
+    const int n_tiles_mn = p.m_tiles * p.n_tiles;
+    // SK: this workgroup's range of (tile, K step) units, [sk_u, sk_u1) in tile-major order; workgroups that land on one XCD own
+    // neighbouring ranges (the partial tiles they exchange and the operand rows they share stay in that XCD's neighbourhood)
+    int sk_l = 0, sk_u = 0, sk_u1 = 0, sk_nit = 1;
+    if constexpr (SK) {
+        sk_l = xcd_remap(blockIdx.x, p.sk_grid);
+        sk_nit = p.seg[0].ty.n * p.seg[0].tx.n * ((p.C + BK - 1) / BK);
+        sk_u = sk_l * p.sk_per;
+        sk_u1 = min(n_tiles_mn * sk_nit, sk_u + p.sk_per);
+        if (sk_u >= sk_u1) return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int kg = wave / (WM * WN);     // K group of this wave
@@ -106,12 +139,25 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     const int wm = wmn / WN, wn = wmn % WN;
     const int g = tid % KG;              // 16-byte k-group staged by this thread
     const int r0 = tid / KG;             // first staged row
-
-    const int n_tiles_mn = p.m_tiles * p.n_tiles;
-    const int split = blockIdx.x / n_tiles_mn;
-    const int bid0 = blockIdx.x - split * n_tiles_mn;
-    const int bid = p.remap ? xcd_remap(bid0, n_tiles_mn) : bid0;
-    const int mt = bid / p.n_tiles, nt = bid % p.n_tiles;
+    const int li = lane & 31, lh = lane >> 5;
+    // the tile of the current pass (what the epilogue behind the pass loop completes)
+    int mt = 0, nt = 0, n0 = 0, split = 0;
+    int sk_t = 0, sk_k0 = 0, sk_k1 = 0;  // SK: the tile of this pass and its K steps [sk_k0, sk_k1)
+    f32x16 acc[TM][TN];
+  // One pass, unless SK: then a workgroup's unit range is at most a tile's TAIL (K steps [k0, n): a producer pass — K loop, publish, next
+  // pass) followed by a tile's HEAD or a whole tile (the finishing pass, which leaves the loop for the epilogue).  The epilogue stays
+  // OUTSIDE the loop: inside it hipcc keeps the epilogue's per-thread state live across the next pass's K loop (96 -> 244 registers).
+  for (;;) {
+    if constexpr (SK) {
+        sk_t = sk_u / sk_nit;
+        sk_k0 = sk_u - sk_t * sk_nit;
+        sk_k1 = min(sk_nit, sk_k0 + (sk_u1 - sk_u));
+    } else
+        split = blockIdx.x / n_tiles_mn;
+    const int bid0 = SK ? sk_t : blockIdx.x - split * n_tiles_mn;
+    const int bid = (!SK && p.remap) ? xcd_remap(bid0, n_tiles_mn) : bid0;
+    mt = bid / p.n_tiles;
+    nt = bid % p.n_tiles;
     int si = 0;
 #pragma unroll
     for (int s = 1; s < ZSG_MAX_SEG; ++s)
@@ -119,7 +165,7 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     const IgSegDev sg = p.seg[si];       // by value: keeps the geometry in SGPRs for the whole K loop
     const int srcH = sg.src_H, srcW = sg.src_W, src_ld = p.src_ld, Cdim = p.C;
     const int m0 = (mt - sg.tile0) * BM;
-    const int n0 = nt * BN;
+    n0 = nt * BN;
 
     // ---- per-row gather state (fixed for the whole K loop) --------------------------------------------------
     int a_by[RA], a_bx[RA], a_off[RA];   // a_off: element offset of the row's tap (0, 0) pixel — a tap adds a WAVE-UNIFORM offset
@@ -159,6 +205,10 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
         const int per = (n_it_all + p.splits - 1) / p.splits;
         it0 = min(split * per, n_it_all);
         n_it = min(per, n_it_all - it0);
+    }
+    if constexpr (SK) {
+        it0 = sk_k0;
+        n_it = sk_k1 - sk_k0;
     }
 
     // Register stages: the global loads run NS K tiles ahead of the MFMAs.  NS = 2.  Deeper prefetch (4 stages where a stage is
@@ -307,7 +357,6 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
         for (int j = 0; j < RB; ++j) *(f32x4*)(b + (r0 + RP * j) * LDR + 4 * g) = rb[j];
     };
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -323,7 +372,6 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
     }
     __syncthreads();
 
-    const int li = lane & 31, lh = lane >> 5;
     const int a_row = wm * (BM / WM) + li;
     const int b_row = wn * (BN / WN) + li;
 
@@ -384,6 +432,70 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
         }
     }
 
+    // ---- stream-K hand-off, producer side: a tile's tail is published, then the next pass -----------------------------------------
+    if constexpr (!SK) break;
+    else {
+        if (sk_k0 == 0) break;                        // the head of a tile (or a whole tile): the finishing pass
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NT0 = 64 * WM * WN;             // threads of K group 0 (they hold the accumulators)
+        const int t0 = tid % NT0;                     // 16-byte unit q of thread t at ((q * NT0 + t) * 16) bytes of a slot
+        if (kg == 0) {
+            const rsrc_t rs = make_rsrc(p.sk_ws + (size_t)sk_l * (BM * BN));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, 16 * ((((i * TN + j) * 4 + q) * NT0) + t0), 0, 16);      // sc1: write-through
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its own stores ...
+        __syncthreads();                                      // ... before the one flag store (also: the staging area is free again)
+        if (tid == 0) __hip_atomic_store(p.sk_flags + sk_l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_u += sk_k1 - sk_k0;
+        if (sk_u >= sk_u1) return;                    // this workgroup's range ended inside the tile
+    }
+  }
+    // ---- stream-K hand-off, finisher side: the workgroups sk_l + 1 .. last hold the remaining K steps of this cut tile ------------------
+    if constexpr (SK) {
+        if (sk_k1 < sk_nit) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int NT0 = 64 * WM * WN;
+            constexpr int NQ = TM * TN * 4;
+            const int t0 = tid % NT0;
+            const int last = ((sk_t + 1) * sk_nit - 1) / p.sk_per;
+            if (tid == 0) {
+                for (int j = sk_l + 1; j <= last; ++j) {
+                    // bounded poll (~1 s): a producer that never arrives (a lost workgroup, a clobbered flag word) must not hang the step —
+                    // the finisher gives up, the tile is wrong, and the last flag word says so (ZSG_SK_ERR_WORD; nonzero = poisoned launch)
+                    int spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(4);
+                    if (spins >= (1 << 20)) __hip_atomic_store(p.sk_flags + ZSG_SK_ERR_WORD, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.sk_flags + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+                }
+            }
+            __syncthreads();
+            if (kg == 0) {
+                for (int j = sk_l + 1; j <= last; ++j) {          // fixed order: deterministic
+                    const rsrc_t rs = make_rsrc(p.sk_ws + (size_t)j * (BM * BN));
+                    constexpr int QB = NQ < 8 ? NQ : 8;           // 16-byte loads in flight per thread
+#pragma unroll
+                    for (int q0 = 0; q0 < NQ; q0 += QB) {
+                        f32x4 v[QB];
+#pragma unroll
+                        for (int q = 0; q < QB; ++q) v[q] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, 16 * ((q0 + q) * NT0 + t0), 0, 16));
+#pragma unroll
+                        for (int q = 0; q < QB; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[(q0 + q) / (4 * TN)][((q0 + q) / 4) % TN][4 * ((q0 + q) & 3) + e] += v[q][e];
+                    }
+                }
+            }
+        }
+    }
+  {
     // ---- fused BatchNorm statistics: per-column (sum, sum^2) over this tile's rows (dead rows hold exact zeros) -----
     const bool tail_on = p.tail.tickets != nullptr;       // (host: only with the vectorised epilogue, unsplit)
     if (p.stats && !p.bnb.x) {
@@ -556,9 +668,7 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
                 bn_tail_reduce<NT, BN>(p.tail, p.tail.tickets + nt, p.stats, p.m_tiles, p.N, n0, (double*)smem);
             }
         }
-        return;
-    }
-    if (kg != 0) return;
+    } else if (kg == 0) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + li;
@@ -591,6 +701,8 @@ __global__ __launch_bounds__(64 * NW * KS, (BK == 64 && BM * BN >= 128 * 128 && 
             }
         }
     }
+    }
+  }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -636,7 +748,7 @@ static int fill_params(const zsg_conv_desc* d, IgParams& p, int BM, int BN, doub
 }
 
 // kname: the kernel's name as rocprofv3 prints it, so the event-timed profile (zsg_prof_*) and the rocprof trace line up
-template <int BM, int BN, int NW, bool MX, int KS, int BK, bool PRE = false>
+template <int BM, int BN, int NW, bool MX, int KS, int BK, bool PRE = false, bool SK = false>
 static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + BM * sizeof(int);
     static bool attr_done[ZSG_MAX_DEV] = {};      // per device; idempotent (a benign race sets it twice)
@@ -644,14 +756,35 @@ static int launch_cfg1(const IgParams& p, hipStream_t st, double flops, const ch
     (void)hipGetDevice(&dev);
     ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "igemm: device %d", dev);
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, MX, KS, BK, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, MX, KS, BK, PRE, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, p.alg_bytes);
-    ZSG_LAUNCH((igemm_kernel<BM, BN, NW, MX, KS, BK, PRE>), dim3(p.m_tiles * p.n_tiles * p.splits), dim3(64 * NW * KS), lds, st, p);
+    ZSG_LAUNCH((igemm_kernel<BM, BN, NW, MX, KS, BK, PRE, SK>), dim3(SK ? p.sk_grid : p.m_tiles * p.n_tiles * p.splits), dim3(64 * NW * KS), lds, st, p);
     ZSG_CHECK_LAUNCH("igemm");
     return 0;
+}
+// stream-K launch of one tile configuration (profile name = kname + "+sk", + "+k64" for the 64-deep K tile): the workgroup count and
+// the units per workgroup follow from the tile; the partial-tile slots and flags come from the stream's workspace
+template <int BM, int BN, int NW, int KS, int BK>
+static int launch_sk(IgParams& p, hipStream_t st, double flops, const char* kname, int bpc) {
+    size_t ws_bytes = 0;
+    char* ws = (char*)zsg_stream_workspace(st, &ws_bytes);
+    ZSG_REQUIRE(ws, "conv_igemm: a stream-K tile hint needs zsg_set_stream_workspace() for this stream");
+    const int tiles = p.m_tiles * p.n_tiles;
+    const int grid = ZSG_NUM_CU * bpc;
+    const int nit = p.seg[0].ty.n * p.seg[0].tx.n * ((p.C + BK - 1) / BK);
+    ZSG_REQUIRE(tiles <= grid && grid < ZSG_SK_ERR_WORD, "conv_igemm: stream-K is for grids below one round (%d tiles, %d workgroups)", tiles, grid);
+    if ((size_t)ZSG_SK_FLAG_BYTES + (size_t)grid * BM * BN * sizeof(float) > ws_bytes)
+        ZSG_FAIL(-2, "conv_igemm: stream-K needs %zu bytes of stream workspace (%zu registered)", (size_t)ZSG_SK_FLAG_BYTES + (size_t)grid * BM * BN * sizeof(float), ws_bytes);
+    p.sk_grid = grid;
+    p.sk_per = cdiv((int64_t)tiles * nit, grid);
+    p.sk_flags = (unsigned*)ws;
+    p.sk_ws = (float*)(ws + ZSG_SK_FLAG_BYTES);
+    static char nm[96];
+    snprintf(nm, sizeof(nm), "%s+sk%s", kname, BK == 64 ? "+k64" : "");
+    return launch_cfg1<BM, BN, NW, false, KS, BK, false, true>(p, st, flops, nm);
 }
 // p.bk64 selects the 64-deep K tile (profile name = kname + "+k64")
 template <int BM, int BN, int NW, bool MX, int KS = 1>
@@ -713,6 +846,11 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
     pick_tile(d, &BM, &BN, &splits, &w8);
     if (d->merge_x && BN == 128) BN = 64;
     if (d->merge_x) w8 = 0;
+    const int sk_bpc = d->tile_hint ? (d->tile_hint >> 28) & 3 : 0;      // stream-K: workgroups per CU (tile_hint bits 28-29), 0 = off
+    const bool sk = sk_bpc > 0;
+    if (sk)
+        ZSG_REQUIRE(BM != 32 && !d->merge_x && !pre && d->nseg == 1 && splits <= 1,
+                    "conv_igemm: stream-K needs an implicit-GEMM tile, one segment, no split-K");
     if (pre) {
         const zsg_seg& s0 = d->seg[0];
         ZSG_REQUIRE(pre->mean && pre->invstd && pre->gamma && pre->beta && pre->residual && pre->y, "conv_igemm_bnpre: null argument");
@@ -784,6 +922,17 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
             hipError_t e = hipMemsetAsync(out + d->seg[0].out_off, 0, (size_t)d->B * d->seg[0].out_bstride * sizeof(float), st);
             if (e != hipSuccess) ZSG_FAIL(-3, "conv_igemm: memset: %s", hipGetErrorString(e));
         }
+    }
+    if (sk) {
+        ZSG_REQUIRE(p.vec, "conv_igemm: stream-K needs 16-byte addressable output rows");
+        const bool k64 = p.bk64;
+        if (BM == 64 && BN == 64 && !w8 && !k64) return launch_sk<64, 64, 4, 1, 32>(p, st, flops, "igemm_kernel<64, 64, 4, false>", sk_bpc);
+        if (BM == 64 && BN == 64 && w8 && !k64) return launch_sk<64, 64, 4, 2, 32>(p, st, flops, "igemm_kernel<64, 64, 4, false, 2>", sk_bpc);
+        if (BM == 64 && BN == 64 && w8 && k64) return launch_sk<64, 64, 4, 2, 64>(p, st, flops, "igemm_kernel<64, 64, 4, false, 2>", sk_bpc);
+        if (BM == 128 && BN == 64 && w8 && !k64) return launch_sk<128, 64, 8, 1, 32>(p, st, flops, "igemm_kernel<128, 64, 8, false>", sk_bpc);
+        if (BM == 128 && BN == 128 && w8 && !k64) return launch_sk<128, 128, 8, 1, 32>(p, st, flops, "igemm_kernel<128, 128, 8, false>", sk_bpc);
+        if (BM == 128 && BN == 128 && !w8 && !k64) return launch_sk<128, 128, 4, 1, 32>(p, st, flops, "igemm_kernel<128, 128, 4, false>", sk_bpc);
+        ZSG_FAIL(-1, "conv_igemm: no stream-K variant for tile %dx%d (w8 %d, k64 %d)", BM, BN, w8, (int)k64);
     }
     if (d->merge_x) {
         if (BM == 128) return launch_cfg<128, 64, 4, true>(p, st, flops, "igemm_kernel<128, 64, 4, true>");

@@ -28,7 +28,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
+from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, ensure_stream_scratch, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
                   shared_side_stream, wino_mode, wino_ok)
 from .params import ParamStore, pad4, register_named
 
@@ -1681,6 +1681,7 @@ class _Plan:
     def run_forward(self, img, qvec, qlens, h0, c0) -> torch.Tensor:
         net = self.net
         B = self.B
+        ensure_stream_scratch(stream_ptr())      # (stream-K launches take their scratch from the stream they run on)
         net.join_grads()
         rel = None
         if prep_release_top() and self._prep_stream is not None:
@@ -1831,6 +1832,7 @@ class _Plan:
         return self._prep_idx_v
 
     def run_backward(self, g5: torch.Tensor):
+        ensure_stream_scratch(stream_ptr())
         net = self.net
         if not self.training:
             raise RuntimeError("backward through an eval-mode plan")

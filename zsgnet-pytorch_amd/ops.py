@@ -239,11 +239,29 @@ def shared_side_stream():
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
         _SIDE[dev] = make_side_stream()
+        ensure_stream_scratch(_SIDE[dev].cuda_stream)
     return _SIDE[dev]
 
 
 def make_side_stream():
     return torch.cuda.Stream()
+
+
+# ---- per-stream scratch of the stream-K convolutions (zsg_set_stream_workspace) -----------------------------------------------------
+# 16 KB of hand-off flags + one partial accumulator tile per workgroup: 512 workgroups x 128 x 128 floats (the largest stream-K
+# candidate the tuner offers) = 32 MB.  One buffer per (device, stream) that ever replays a program, registered on first use.
+SCRATCH_BYTES = (16 << 10) + 512 * 128 * 128 * 4
+_SCRATCH = {}
+
+
+def ensure_stream_scratch(stream: int):
+    """Register this process's scratch buffer for `stream` (a hipStream_t as an integer) with the library, once."""
+    key = (torch.cuda.current_device(), int(stream or 0))
+    if key not in _SCRATCH:
+        buf = torch.zeros(SCRATCH_BYTES // 4, dtype=torch.float32, device="cuda")
+        check(lib.zsg_set_stream_workspace(C.c_void_p(stream), buf.data_ptr(), SCRATCH_BYTES), "set_stream_workspace")
+        _SCRATCH[key] = buf
+    return _SCRATCH[key]
 
 
 class Program:
@@ -691,6 +709,24 @@ def wino_mode() -> str:
 
 
 K64_FLAG = 1 << 27           # tile_hint bit (igemm): 64-deep K tiles — half the K steps (barriers) at twice the LDS per block
+SK_SHIFT = 28                # tile_hint bits 28-29 (igemm): stream-K with that many workgroups per CU (csrc/igemm.hip, template flag SK)
+
+
+def sk_cands(d: ConvDesc, rows: int) -> list:
+    """Stream-K candidates of an implicit-GEMM launch whose tile grid is below one round of (256 x workgroups-per-CU) workgroups —
+    layer3 / layer4's 1x1 convolutions, the strided 3x3 ones, the small pyramid levels.  The library refuses what it cannot run
+    (more tiles than workgroups, several segments): a refused candidate is simply not timed."""
+    if d.nseg != 1 or d.merge_x or os.environ.get("ZSG_SK", "1") == "0":
+        return []
+    out = []
+    for bm, bn, w8, k64 in ((64, 64, 0, 0), (64, 64, 1, 0), (64, 64, 1, 1), (128, 64, 1, 0), (128, 128, 1, 0), (128, 128, 0, 0)):
+        if (bn == 128 and d.N <= 64) or (k64 and d.C % 64):
+            continue
+        tiles = ((rows + bm - 1) // bm) * ((d.N + bn - 1) // bn)
+        for bpc in ((1, 2, 3) if bm == 64 else (1, 2)):
+            if tiles <= 256 * bpc and not (tiles <= 256 * (bpc - 1) and bpc > 2):
+                out.append(tile_hint(bm, bn, 1, w8) | (K64_FLAG if k64 else 0) | (bpc << SK_SHIFT))
+    return out
 
 
 def deterministic() -> bool:
@@ -773,7 +809,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     add_src, mask = (args[4], args[5]) if kind == "igemm" else (None, None)
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
                          mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
-                         os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0")))
+                         os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"),
+                         os.environ.get("ZSG_SK", "1") != "0"))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -793,6 +830,9 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands += [tile_hint(bm, bn, 1, w8) | K64_FLAG for bm, bn in tiles for w8 in (0, 1) if not (bm == 128 and bn == 128 and not w8)]
         if fn is lib.zsg_conv_igemm and os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"):
             cands += pw_cands(d)          # (ZSG_MX=0: A/B switch for the streaming first-layer kernel alone)
+        if fn is not lib.zsg_conv_igemm_bnpre:
+            ensure_stream_scratch(stream)
+            cands += sk_cands(d, rows)
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
         n_it = s0.ty.n * s0.tx.n * ((d.C + 31) // 32)
         if dense and blocks64 < 1024 and not deterministic():
