@@ -41,6 +41,8 @@ CASES = [
     (16, 256, 1024, 19, 19, 1, 1, True, True, "igemm", (64, 64, 1, 1, 2)),     # layer3 conv3's data gradient (K = 1024) at the bench shape
     (16, 512, 2048, 10, 10, 1, 1, False, True, "igemm", (128, 64, 1, 0, 1)),   # layer4 conv3's
     (2, 64, 256, 19, 19, 1, 1, True, False, "igemm", (128, 128, 1, 0, 1)),
+    (16, 256, 256, 19, 19, 3, 1, False, True, "wino", (32, 64, 1, 1)),          # layer3 conv2's data gradient as a Winograd stream-K launch
+    (4, 64, 96, 20, 20, 3, 1, True, True, "wino", (32, 64, 1, 1)),
 ]
 
 
@@ -80,8 +82,8 @@ def test_dgrad_with_bn_backward_sums(Z, case):
         maskb = dev((bb[:, 0] | (bb[:, 1] << 1) | (bb[:, 2] << 2) | (bb[:, 3] << 3)).contiguous())
     xd, md, isd, gd = dev(xbn), dev(mean), dev(invstd), dev(gamma)
     if kern == "wino":
-        tb, bn, ps4 = hint3
-        hint = tb | (bn << 8) | (1 << 16) | (ps4 << 24)
+        tb, bn, ps4, skw = (tuple(hint3) + (0,))[:4]
+        hint = tb | (bn << 8) | (1 << 16) | (ps4 << 24) | (skw << 28)
         wop = make_u(L, ops, wt, Ci, Cop, k * k * Cop, Cop, True)
         fn_plain, fn_bnb = L.lib.zsg_conv_wino, L.lib.zsg_conv_wino_bnb
         chunks = (B * ((H + 1) // 2) * ((W + 1) // 2) + tb - 1) // tb

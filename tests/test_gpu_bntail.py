@@ -33,6 +33,8 @@ CASES = [
     (16, 1024, 256, 19, 19, 1, 1, "igemm", (128, 128, 1, 0, 1)), # the same as 92 tiles of 128x128 over 256 workgroups
     (16, 2048, 512, 10, 10, 1, 1, "igemm", (128, 64, 1, 0, 1)),  # layer4 conv1
     (16, 2048, 512, 10, 10, 1, 1, "igemm", (64, 64, 0, 0, 1)),   # 200 tiles over 256 workgroups
+    (16, 256, 256, 19, 19, 3, 1, "wino", (32, 64, 1, 1)),        # layer3 conv2 as a Winograd stream-K launch (tb, bn, ps4, stream-K)
+    (16, 512, 512, 10, 10, 3, 1, "wino", (32, 64, 1, 1)),        # layer4 conv2
 ]
 
 
@@ -52,8 +54,8 @@ def test_conv_with_in_kernel_bn_statistics(Z, case):
     st = L.stream_ptr()
     rows = B * Ho * Wo
     if kern == "wino":
-        tb, bn, ps4 = hint3
-        hint = tb | (bn << 8) | (1 << 16) | (ps4 << 24)
+        tb, bn, ps4, skw = (tuple(hint3) + (0,))[:4]
+        hint = tb | (bn << 8) | (1 << 16) | (ps4 << 24) | (skw << 28)
         wop = make_u(L, ops, wd, Co, cp, k * k * cp, cp, False)
         fn_plain, fn_tail = L.lib.zsg_conv_wino, L.lib.zsg_conv_wino_bnstat
         chunks = (B * ((H + 1) // 2) * ((W + 1) // 2) + tb - 1) // tb

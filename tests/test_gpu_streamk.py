@@ -10,7 +10,9 @@ one holding its first K step, which adds the others' partial accumulator tiles i
   * determinism: repeated launches — alone and under a noisy neighbour stream — are bit-identical; the hand-off flags read zero after
     every launch;
   * refusals: no registered scratch (-1), scratch too small (-2), more tiles than workgroups, several segments, split-K — all loud.
-In-kernel BatchNorm finalize and the bnb-tail variant on stream-K launches: tests/test_gpu_bntail.py / test_gpu_bnb.py cases."""
+In-kernel BatchNorm finalize and the bnb-tail variant on stream-K launches: tests/test_gpu_bntail.py / test_gpu_bnb.py cases.
+The Winograd kernel's stream-K form (zsg_conv_wino, 32 tiles x 64 channels, four position groups; csrc/wino.hip) exchanges partial
+OUTPUT tiles: test_wino_stream_k below, same checks."""
 import ctypes as C
 
 import pytest
@@ -18,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from test_gpu_ops import Z, assert_close, dev, nhwc, ohwi, pad4, stream_scratch, view_of  # noqa: F401
+from test_gpu_wino import make_u  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -196,4 +199,89 @@ def test_stream_k_refusals(Z):
     dd = ops.dgrad_desc(view_of(ops, dy, B, 5, 5, Co), view_of(ops, dx, B, H, W, Ci), Co, Ci, 3, 2, 1, 1, tile_hint=hint)
     assert dd.nseg > 1
     assert L.lib.zsg_conv_igemm(C.byref(dd), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, None, None, st) == -1
+    torch.cuda.synchronize()
+
+
+WINO_SK = 32 | (64 << 8) | (1 << 16) | (1 << 24) | (1 << SK)
+WINO_SHAPES = [
+    # B, Cin, Cout, H, W, bias, relu
+    (16, 256, 256, 19, 19, False, False),     # layer3 conv2 at the bench shape: 184 tiles x 32 chunks over 256 workgroups
+    (16, 512, 512, 10, 10, False, False),     # layer4 conv2: 104 tiles x 64 chunks
+    (16, 256, 256, 19, 19, True, True),       # P4_2-like: bias + ReLU behind the hand-off
+    (3, 40, 96, 7, 10, True, False),          # ragged: tile tail, column tail (N = 96), C % 8 == 4 (last chunk half dead), 5 chunks
+    (2, 8, 64, 9, 9, False, False),           # one chunk per tile: nothing is cut, most workgroups idle
+]
+
+
+@pytest.mark.parametrize("shape", WINO_SHAPES, ids=[f"w{i}" for i in range(len(WINO_SHAPES))])
+def test_wino_stream_k(Z, shape):
+    """Values vs torch-CPU fp32 (tolerance of test_gpu_wino.py: 3e-4 of the output scale), fused BatchNorm partial rows = column sums of
+    the stored output, bit-identical reruns under a noisy neighbour, flags zero after every launch; the data-gradient form (rotated
+    filters) with accumulate + mask."""
+    L, ops = Z
+    B, Ci, Co, H, W, bias, relu = shape
+    g = torch.Generator().manual_seed(23 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, generator=g) if bias else None
+    y_ref = F.conv2d(x, w, b, 1, 1)
+    if relu:
+        y_ref = F.relu(y_ref)
+    cp = pad4(Ci)
+    st = L.stream_ptr()
+    xd, wd = dev(nhwc(x)), dev(ohwi(w))
+    U = make_u(L, ops, wd, Co, cp, 9 * cp, cp, False)
+    out = torch.full((B, H, W, Co), float("nan"), device="cuda")
+    src, ov = view_of(ops, xd, B, H, W, cp), view_of(ops, out, B, H, W, Co)
+    d = ops.fwd_desc(src, ov, cp, Co, 3, 1, 1, 1, wC=cp, relu=relu, tile_hint=WINO_SK)
+    bd = dev(b) if bias else None
+    L.check(L.lib.zsg_conv_wino(C.byref(d), xd.data_ptr(), U.data_ptr(), out.data_ptr(), bd.data_ptr() if bias else None, None, None, None, st), "wino stream-K")
+    sc = float(y_ref.abs().max())
+    assert_close(out.permute(0, 3, 1, 2), y_ref, 3e-4, 3e-4 * sc, "wino stream-K fwd")
+    assert flags_zero(L)
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    chunks = (tiles + 31) // 32
+    if not bias and not relu:
+        side = torch.cuda.Stream()
+        noise = torch.empty(32 << 20, device="cuda")
+        first = None
+        for rep in range(4):
+            part = torch.full((chunks, 2, Co), float("nan"), device="cuda")
+            out.fill_(float("nan"))
+            torch.cuda.synchronize()
+            if rep >= 2:
+                L.check(L.lib.zsg_memset_f32(noise.data_ptr(), noise.numel(), float(rep), C.c_void_p(side.cuda_stream)), "noise")
+            L.check(L.lib.zsg_conv_wino(C.byref(d), xd.data_ptr(), U.data_ptr(), out.data_ptr(), None, None, None, part.data_ptr(), st), "wino stream-K + stats")
+            torch.cuda.synchronize()
+            if first is None:
+                first = (out.clone(), part.clone())
+                assert_close(out.permute(0, 3, 1, 2), y_ref, 3e-4, 3e-4 * sc, "wino stream-K fwd + stats")
+                yo = out.reshape(-1, Co).double()
+                assert_close(part[:, 0].double().sum(0), yo.sum(0), 1e-5, 1e-5 * float(yo.abs().sum(0).max()), "partial sums = column sums of the stored output")
+                assert_close(part[:, 1].double().sum(0), (yo * yo).sum(0), 1e-5, 1e-7, "partial sums of squares")
+            else:
+                assert torch.equal(out, first[0]) and torch.equal(part, first[1]), f"wino stream-K: rerun {rep} differs"
+            assert flags_zero(L)
+        side.synchronize()
+    # data gradient: dy [B, Co] -> dx [B, Ci] with the rotated, transposed filters; accumulate + mask epilogue
+    gy = torch.randn(B, Co, H, W, generator=g)
+    dxr = torch.nn.grad.conv2d_input((B, Ci, H, W), w, gy, 1, 1).permute(0, 2, 3, 1)
+    Cop = pad4(Co)
+    dyd = dev(nhwc(gy, Cop))
+    wt = torch.empty((cp, 3, 3, Cop), device="cuda")
+    L.check(L.lib.zsg_transpose_w(wd.data_ptr(), wt.data_ptr(), Co, 9, cp, Cop, st), "transpose_w")
+    Ut = make_u(L, ops, wt, cp, Cop, 9 * Cop, Cop, True)
+    prev, mask = torch.randn(B, H, W, cp, generator=g), torch.randn(B, H, W, cp, generator=g)
+    dx, maskd = dev(prev), dev(mask)
+    dd = ops.dgrad_desc(view_of(ops, dyd, B, H, W, Cop), view_of(ops, dx, B, H, W, cp), Cop, cp, 3, 1, 1, 1, tile_hint=WINO_SK)
+    L.check(L.lib.zsg_conv_wino(C.byref(dd), dyd.data_ptr(), Ut.data_ptr(), dx.data_ptr(), None, dx.data_ptr(), maskd.data_ptr(), None, st), "wino stream-K dgrad")
+    ref = (prev[..., :Ci] + dxr) * (mask[..., :Ci] > 0)
+    assert_close(dx[..., :Ci], ref, 5e-4, 5e-4 * float(ref.abs().max()), "wino stream-K dgrad accumulate+mask")
+    assert flags_zero(L)
+    # refusals: a tile without a stream-K variant, split-K + stream-K
+    for bad in (64 | (64 << 8) | (1 << 16) | (1 << SK), 32 | (64 << 8) | (2 << 16) | (1 << 24) | (1 << SK)):
+        if ((bad >> 16) & 0xff) > (cp + 7) // 8:
+            continue                    # (the library clamps a split count beyond the chunk count to it: one chunk -> no split left to refuse)
+        d.tile_hint = bad
+        assert L.lib.zsg_conv_wino(C.byref(d), xd.data_ptr(), U.data_ptr(), out.data_ptr(), None, None, None, None, st) == -1, hex(bad)
     torch.cuda.synchronize()

@@ -57,10 +57,48 @@ def name_of(h):
     return s
 
 
+WINO_SHAPES = [
+    ("l3_conv2", 16, 256, 256, 19, 19),
+    ("l4_conv2", 16, 512, 512, 10, 10),
+    ("l2_conv2", 16, 128, 128, 38, 38),
+    ("P5_2", 16, 256, 256, 10, 10),
+]
+
+
+def wino_main(only, st):
+    for name, B, Ci, Co, H, W in WINO_SHAPES:
+        if only and name not in only:
+            continue
+        x = torch.randn(B, H, W, Ci, device="cuda")
+        w = torch.randn(Co, 3, 3, Ci, device="cuda") * 0.05
+        y = torch.empty(B, H, W, Co, device="cuda")
+        U = torch.empty(int(lib.zsg_wino_u_elems(Ci, Co)), device="cuda")
+        jobs = ops.WinoJobs()
+        jobs.add(w.data_ptr(), U.data_ptr(), Co, Ci, 9 * Ci, Ci, 0)
+        jobs.finish("cuda")
+        jobs.launch(st)
+        tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+        part = torch.empty(tiles // 32 + 2, 2, Co, device="cuda")
+        xv = ops.TView(x.view(-1), B, Ci, Ci, [ops.Level(0, H, W, H * W * Ci)])
+        yv = ops.TView(y.view(-1), B, Co, Co, [ops.Level(0, H, W, H * W * Co)])
+        gf = 2.0 * B * H * W * Co * Ci * 9 / 1e9
+        d0 = ops.fwd_desc(xv, yv, Ci, Co, 3, 1, 1, 1, wC=Ci)
+        res = []
+        for h in ops._wino_cands(d0):
+            if ((h >> 16) & 0xff) > 1:
+                continue
+            d = ops.fwd_desc(xv, yv, Ci, Co, 3, 1, 1, 1, wC=Ci, tile_hint=h)
+            res.append((timeit(lambda: lib.zsg_conv_wino(C.byref(d), x.data_ptr(), U.data_ptr(), y.data_ptr(), None, None, None, part.data_ptr(), st)), h))
+        res.sort()
+        print(f"{name:11s} tiles={tiles:5d} N={Co:4d} C={Ci:4d} {gf:6.2f} GF (direct) ideal {gf * 4 / 9 / 157.3 * 1e3:5.1f} us executed")
+        print("   winograd: " + "  ".join(f"{name_of(h)} {t:5.1f}" for t, h in res), flush=True)
+
+
 def main():
     only = sys.argv[1:]
     st = stream_ptr()
     ops.ensure_stream_scratch(st)
+    wino_main(only, st)
     for name, B, Ci, Co, H, W, k, s, p in SHAPES:
         if only and name not in only:
             continue

@@ -46,6 +46,11 @@ struct WnParams {
     int C, N, Npad, src_ld, out_ld, relu, nseg;
     int m_blocks, n_blocks, splits, chunks, vec, add_is_out;
     double alg_bytes;    // host only: algorithmic HBM bytes of the launch (profile)
+    // stream-K (SK kernels only; tile_hint bits 28-29, as igemm.hip): sk_grid workgroups share the (block tile, 8-channel chunk) units
+    // evenly, sk_per consecutive units each; the workgroup that holds a tile's first chunk completes it
+    int sk_grid, sk_per;
+    float* sk_ws;        // one partial OUTPUT tile [TB * 4 pixels][BN] per workgroup (the output transform is linear: partial sums of Y add)
+    unsigned* sk_flags;  // one word per workgroup: "its partial tile is published"; zero at entry, zero at exit
     WnSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -58,7 +63,15 @@ __device__ __forceinline__ float quad_other(float v) {
 
 // PS position groups per 32x32 sub-block: wave (ph, wm, wn) holds the 16/PS positions with i in {2ph, 2ph+1} (PS = 2) or
 // i = ph (PS = 4).  PS = 4 doubles the waves per SIMD for the same tile (64 instead of 128 accumulator registers each).
-template <int TM, int TN, int PS>
+//
+// SK (stream-K, round 6): the bottlenecks' conv2 at 19^2 / 10^2 are grids of 184 / 104 blocks of 32 tiles x 64 channels on 256 CUs — one
+// round with a quarter / more than half of the chip idle.  With SK the launch has 256 workgroups and the (block tile, chunk) units are
+// dealt evenly in tile-major order, exactly as in igemm.hip: a workgroup's range is at most the TAIL of one tile (a producer pass: K
+// loop, output transform, the partial OUTPUT tile published write-through, flag) followed by the HEAD of the next (the finishing pass:
+// K loop, output transform, + the partial tiles of the workgroups behind it in workgroup order — deterministic — and the complete
+// epilogue).  What is exchanged is the 2x2-pixel output tile (32 or 64 KB), not the 16 transformed-domain accumulators (4x as much):
+// the output transform is linear.  Producers never wait, so the finisher's poll cannot deadlock.
+template <int TM, int TN, int PS, bool SK = false>
 __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnParams p) {
     ZSG_SET_MAIN_PRIO();
     constexpr int NT = 64 * PS * TM * TN;        // PS position groups x TM x TN waves
@@ -84,17 +97,49 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     const int li = lane & 31, lh = lane >> 5;
 
     const int n_mn = p.m_blocks * p.n_blocks;
-    const int split = blockIdx.x / n_mn;
-    const int bid = xcd_remap(blockIdx.x - split * n_mn, n_mn);
-    const int mb = bid / p.n_blocks, nb = bid % p.n_blocks;
+    const int src_ld = p.src_ld;
+    // SK: this workgroup's range of (tile, chunk) units, [sk_u, sk_u1) in tile-major order (see igemm.hip)
+    int sk_l = 0, sk_u = 0, sk_u1 = 0;
+    if constexpr (SK) {
+        sk_l = xcd_remap(blockIdx.x, p.sk_grid);
+        sk_u = sk_l * p.sk_per;
+        sk_u1 = min(n_mn * p.chunks, sk_u + p.sk_per);
+        if (sk_u >= sk_u1) return;
+    }
+    // the tile of the current pass (what the epilogue behind the pass loop completes)
+    int split = 0, mb = 0, nb = 0, n0 = 0;
+    int sk_t = 0, sk_k0 = 0, sk_k1 = 0;          // SK: the tile of this pass and its chunks [sk_k0, sk_k1)
+    WnSegDev sg;
+    f32x16 acc[NP];
+    constexpr int LDC = BN + 4;
+    float* ct = smem;                               // [TB*4][LDC] — the output tile; reuses the staging area
+    float* red = smem + TB * 4 * LDC;               // [2][RPP][BN] (statistics)
+    constexpr int E_CG = BN / 4, E_RPP = NT / E_CG, E_NR = TB * 4 / E_RPP;
+    static_assert((TB * 4) % E_RPP == 0, "epilogue row passes");
+    f32x4 xpre[E_NR], apre[E_NR];
+    unsigned mpre[E_NR];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // One pass, unless SK (producer pass, then the finishing pass: the epilogue stays OUTSIDE the loop, see igemm.hip)
+  for (;;) {
+    int bid;
+    if constexpr (SK) {
+        sk_t = sk_u / p.chunks;
+        sk_k0 = sk_u - sk_t * p.chunks;
+        sk_k1 = min(p.chunks, sk_k0 + (sk_u1 - sk_u));
+        bid = sk_t;
+    } else {
+        split = blockIdx.x / n_mn;
+        bid = xcd_remap(blockIdx.x - split * n_mn, n_mn);
+    }
+    mb = bid / p.n_blocks;
+    nb = bid % p.n_blocks;
     int si = 0;
 #pragma unroll
     for (int s = 1; s < ZSG_MAX_SEG; ++s)
         if (s < p.nseg && mb >= p.seg[s].blk0) si = s;
-    const WnSegDev sg = p.seg[si];
+    sg = p.seg[si];
     const int m0 = (mb - sg.blk0) * TB;
-    const int n0 = nb * BN;
-    const int src_ld = p.src_ld;
+    n0 = nb * BN;
 
     // ---- loader state (fixed over the K loop) ------------------------------------------------------------------------
     const int q = tid & 3, g = (tid >> 2) & 1;
@@ -156,9 +201,12 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
         c0 = min(split * per, p.chunks);
         nc = min(per, p.chunks - c0);
     }
+    if constexpr (SK) {
+        c0 = sk_k0;
+        nc = sk_k1 - sk_k0;
+    }
 
     f32x4 ra[IA][4];
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto load_a = [&](int c, bool live) {          // c, live: wave-uniform
         if (!a_thr || !live) return;      // (a dead prefetch leaves ra as it is: it is stored into the idle buffer, never read)
         const int so = c * (WN_CK * 4);      // bytes, SGPR
@@ -209,7 +257,6 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
         }
     };
 
-    f32x16 acc[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
@@ -274,15 +321,8 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
     // ---- output transform: this wave's share of Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) ---------------------------------
     // z[i][b] = sum_j A^T[b][j] M[i][j];  Y[a][b] = sum_i A^T[a][i] z[i][b].  The position groups add their partial Y through
     // LDS one after the other (fixed order).
-    constexpr int LDC = BN + 4;
-    float* ct = smem;                               // [TB*4][LDC] — the staging area is no longer needed
-    float* red = smem + TB * 4 * LDC;               // [2][RPP][BN] (statistics)
     // BatchNorm-backward fusion: this thread's x values and ReLU bits (cold HBM reads) are requested before the output transform
-    constexpr int E_CG = BN / 4, E_RPP = NT / E_CG, E_NR = TB * 4 / E_RPP;
-    static_assert((TB * 4) % E_RPP == 0, "epilogue row passes");
-    f32x4 xpre[E_NR], apre[E_NR];
-    unsigned mpre[E_NR];
-    if (p.bnb.x) {
+    if (p.bnb.x && (!SK || sk_k0 == 0)) {
         const int en = n0 + 4 * (tid % E_CG);
 #pragma unroll
         for (int i = 0; i < E_NR; ++i) {
@@ -346,6 +386,52 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
                         else o[px * LDC] += y[px];
                     }
                 }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- stream-K hand-off, producer side: the partial output tile is published, then the next pass -------------------------------
+    if constexpr (!SK) break;
+    else {
+        if (sk_k0 == 0) break;                        // the head of a tile (or a whole tile): the finishing pass
+        const rsrc_t rs = make_rsrc(p.sk_ws + (size_t)sk_l * (TB * 4 * BN));
+        const int cg = tid % E_CG, rr = tid / E_CG;
+#pragma unroll
+        for (int i = 0; i < E_NR; ++i) {
+            const int row = rr + E_RPP * i;
+            const f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, 4 * (row * BN + 4 * cg), 0, 16);      // sc1: write-through
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores ...
+        __syncthreads();                                      // ... before the one flag store (also: ct / the staging area are free again)
+        if (tid == 0) __hip_atomic_store(p.sk_flags + sk_l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_u += sk_k1 - sk_k0;
+        if (sk_u >= sk_u1) return;                    // this workgroup's range ended inside the tile
+    }
+  }
+    // ---- stream-K hand-off, finisher side: + the partial tiles of the workgroups sk_l + 1 .. last, in that order -------------------------
+    if constexpr (SK) {
+        if (sk_k1 < p.chunks) {
+            const int last = ((sk_t + 1) * p.chunks - 1) / p.sk_per;
+            if (tid == 0) {
+                for (int j = sk_l + 1; j <= last; ++j) {
+                    int spins = 0;      // bounded poll (~1 s), see igemm.hip: a lost producer poisons the launch (ZSG_SK_ERR_WORD), it does not hang it
+                    while (__hip_atomic_load(p.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(4);
+                    if (spins >= (1 << 20)) __hip_atomic_store(p.sk_flags + ZSG_SK_ERR_WORD, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.sk_flags + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+                }
+            }
+            __syncthreads();
+            const int cg = tid % E_CG, rr = tid / E_CG;
+            for (int j = sk_l + 1; j <= last; ++j) {              // fixed order: deterministic
+                const rsrc_t rs = make_rsrc(p.sk_ws + (size_t)j * (TB * 4 * BN));
+                f32x4 v[E_NR];
+#pragma unroll
+                for (int i = 0; i < E_NR; ++i)
+                    v[i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, 4 * ((rr + E_RPP * i) * BN + 4 * cg), 0, 16));
+#pragma unroll
+                for (int i = 0; i < E_NR; ++i) *(f32x4*)(ct + (rr + E_RPP * i) * LDC + 4 * cg) += v[i];      // (each thread owns its (row, column group) cells)
             }
             __syncthreads();
         }
@@ -567,7 +653,7 @@ extern "C" int zsg_wino_weights(const void* jobs_dev, int32_t njobs, int32_t tot
     return 0;
 }
 
-template <int TM, int TN, int PS>
+template <int TM, int TN, int PS, bool SK = false>
 static int wino_launch(const WnParams& p, hipStream_t st, double flops, const char* kname) {
     constexpr int TB = 32 * TM, BN = 32 * TN, NT = 64 * PS * TM * TN;
     constexpr int SA = TB * 8 + 8, SB = BN * 8;
@@ -581,14 +667,34 @@ static int wino_launch(const WnParams& p, hipStream_t st, double flops, const ch
     (void)hipGetDevice(&dev);
     ZSG_REQUIRE(dev >= 0 && dev < ZSG_MAX_DEV, "conv_wino: device %d", dev);
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<TM, TN, PS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) ZSG_FAIL(-3, "wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
     ZSG_PROF(kname, st, flops, p.alg_bytes);
-    ZSG_LAUNCH((wino_kernel<TM, TN, PS>), dim3(p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
+    ZSG_LAUNCH((wino_kernel<TM, TN, PS, SK>), dim3(SK ? p.sk_grid : p.m_blocks * p.n_blocks * p.splits), dim3(NT), lds, st, p);
     ZSG_CHECK_LAUNCH("conv_wino");
     return 0;
+}
+// stream-K launch (profile name = kname + "+sk"): 256 workgroups (these tiles fill a CU's LDS: one workgroup per CU), the partial
+// output tiles and flags in the stream's scratch (zsg_set_stream_workspace)
+template <int TM, int TN, int PS>
+static int wino_launch_sk(WnParams& p, hipStream_t st, double flops, const char* kname) {
+    constexpr int TB = 32 * TM, BN = 32 * TN;
+    size_t ws_bytes = 0;
+    char* ws = (char*)zsg_stream_workspace(st, &ws_bytes);
+    ZSG_REQUIRE(ws, "conv_wino: a stream-K tile hint needs zsg_set_stream_workspace() for this stream");
+    const int tiles = p.m_blocks * p.n_blocks, grid = ZSG_NUM_CU;
+    ZSG_REQUIRE(tiles <= grid, "conv_wino: stream-K is for grids below one round (%d tiles, %d workgroups)", tiles, grid);
+    if ((size_t)ZSG_SK_FLAG_BYTES + (size_t)grid * TB * 4 * BN * sizeof(float) > ws_bytes)
+        ZSG_FAIL(-2, "conv_wino: stream-K needs %zu bytes of stream workspace (%zu registered)", (size_t)ZSG_SK_FLAG_BYTES + (size_t)grid * TB * 4 * BN * sizeof(float), ws_bytes);
+    p.sk_grid = grid;
+    p.sk_per = cdiv((int64_t)tiles * p.chunks, grid);
+    p.sk_flags = (unsigned*)ws;
+    p.sk_ws = (float*)(ws + ZSG_SK_FLAG_BYTES);
+    static char nm[96];
+    snprintf(nm, sizeof(nm), "%s+sk", kname);
+    return wino_launch<TM, TN, PS, true>(p, st, flops, nm);
 }
 // tile_hint = TB | (BN << 8) | (split_k << 16) | (four position groups << 24), TB (tiles per block) and BN in {32, 64};
 // 0 = 64x64, two position groups, no split
@@ -666,6 +772,14 @@ static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float*
             hipError_t e = hipMemsetAsync(out + d->seg[0].out_off, 0, (size_t)d->B * d->seg[0].out_bstride * sizeof(float), st);
             if (e != hipSuccess) ZSG_FAIL(-3, "conv_wino: memset: %s", hipGetErrorString(e));
         }
+    }
+    if (d->tile_hint && ((d->tile_hint >> 28) & 3)) {      // stream-K (one workgroup per CU whatever the field says: these tiles fill a CU's LDS)
+        ZSG_REQUIRE(splits == 1 && p.vec && d->nseg == 1, "conv_wino: stream-K needs one segment, no split-K, 16-byte addressable output rows");
+        const bool ps4 = (d->tile_hint >> 24) & 1;
+        // (only the 32-tile x 64-channel, four-group tile: inside the pass loop the 64-tile kernels spill — 96 registers at the four-group
+        // tile's 128-register budget, 97 at the two-group tile's 256 — and a spilling instantiation is not shipped, tools/kernel_resources.py)
+        if (TB == 32 && BN == 64 && ps4) return wino_launch_sk<1, 2, 4>(p, st, fl, "wino_kernel<1, 2, 4>");
+        ZSG_FAIL(-1, "conv_wino: no stream-K variant for tile %dx%d (four position groups %d)", TB, BN, (int)ps4);
     }
     if ((d->tile_hint >> 24) & 1) {            // four position groups: twice the waves per SIMD
         if (TB == 64 && BN == 64) return wino_launch<2, 2, 4>(p, st, fl, "wino_kernel<2, 2, 4>");

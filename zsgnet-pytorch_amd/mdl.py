@@ -77,6 +77,7 @@ FPN_ORDER_DEFAULT = "p6m"
 BN_PRE_MIN_MB = float(os.environ.get("ZSG_BN_PRE_MIN_MB", "40"))
 STAGE_INPUTS = os.environ.get("ZSG_STAGE_INPUTS", "1") != "0"      # (A/B: 0 = the separate torch copies of rounds 1-4)
 BN_TAIL = os.environ.get("ZSG_BN_TAIL", "1")
+SK_BWD = os.environ.get("ZSG_SK_BWD", "0") != "0"      # stream-K candidates also for the backward's data gradients (measured slower: ops.autotune_conv)
 BN_TAIL_MIN_ROWS = int(os.environ.get("ZSG_BN_TAIL_MIN_ROWS", "0"))      # (A/B: only launches with more partial rows than this finalise in-kernel)
 def prep_at() -> str:
     """ZSG_PREP_AT: where the backward's weight images are enqueued on the side stream during the forward (see _Plan._prep_index)."""
@@ -884,7 +885,7 @@ class _Plan:
             wargs = (dy.buf, U) + args[2:]
         # a split-K choice would cost the BatchNorm below its fused backward sums: a pass over dout and x plus a launch
         pen = (0.006 + 2 * dx.rows() * n * 4 / 4e9) if (completes_bn and BNB_FUSE and not d.zero_fill and mask is None) else 0.0
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), split_penalty_ms=pen, wino_args=wargs)
+        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), split_penalty_ms=pen, wino_args=wargs, allow_sk=SK_BWD)
         if self._side_prep and ((d.tile_hint >> 16) & 0xff) > 1 and args[4] is None and len(dx.levels) == 1:
             # split-K into a gradient buffer nothing has written yet: its zero-fill moves to the side-stream preparation (see conv())
             lv0 = dx.levels[0]

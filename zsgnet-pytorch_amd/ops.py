@@ -735,10 +735,13 @@ def deterministic() -> bool:
     return os.environ.get("ZSG_DETERMINISTIC", "0") == "1"
 
 
-def _wino_cands(d: ConvDesc) -> list:
+def _wino_cands(d: ConvDesc, allow_sk: bool = True) -> list:
     tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
     # (tiles per block, channels per block, split-K, four position groups instead of two = twice the waves per SIMD)
     cands = [tile_hint(64, 64, 1), tile_hint(32, 64, 1), tile_hint(64, 64, 1, 1), tile_hint(32, 64, 1, 1), tile_hint(32, 32, 1, 1)]
+    # stream-K (csrc/wino.hip, template flag SK): the 32 x 64 four-group tile over 256 workgroups, for grids below one round
+    if allow_sk and d.nseg == 1 and ((tiles + 31) // 32) * ((d.N + 63) // 64) <= 256 and os.environ.get("ZSG_SK", "1") != "0":
+        cands.append(tile_hint(32, 64, 1, 1) | (1 << SK_SHIFT))
     s0 = d.seg[0]
     dense = (d.nseg == 1 and not d.relu and d.out_ld == d.N and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
     if dense and not deterministic():
@@ -787,14 +790,18 @@ def igemm_partial_rows(d: ConvDesc) -> int:
 
 
 def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_bytes: int = 0, split_penalty_ms: float = 0.0,
-                  wino_args: Optional[Sequence] = None, wino_fn=None) -> int:
+                  wino_args: Optional[Sequence] = None, wino_fn=None, allow_sk: bool = True) -> int:
     """Pick d.tile_hint for `fn(d, *args, stream)` (kind: 'igemm' | 'wgrad') by timing the candidates on the real
     buffers.  Results are cached per geometry.  ZSG_AUTOTUNE=0 keeps the library heuristic.
     split_penalty_ms: what a split-K choice costs elsewhere (a convolution feeding BatchNorm loses the statistics fused
     in its epilogue: a separate statistics pass + finalize launch), added to the measured time of split candidates.
     wino_args: the same launch through zsg_conv_wino (args with the transformed filter image in place of the weight):
     its tile candidates are timed too; the result carries WINO_FLAG and d.use_wino is set when one of them wins.
-    wino_fn: the Winograd entry point that goes with `fn` (default zsg_conv_wino)."""
+    wino_fn: the Winograd entry point that goes with `fn` (default zsg_conv_wino).
+    allow_sk: offer the stream-K candidates (sk_cands).  The backward's data gradients pass False: a stream-K launch fills every CU with
+    equal shares of the work, which pays where the chain has the GPU to itself (the forward: 4.71 -> 4.68 ms) and costs where the other
+    stream's weight gradients would have used the CUs a one-round grid leaves idle — the backward is bound by the CU-time of BOTH
+    streams, and the hand-off adds to it (configs[1]: 13.21 -> 13.27 ms with stream-K data gradients, profiles/r06_ab_sk_igemm.txt)."""
     d.use_wino = False
     mode = wino_mode() if wino_args is not None else "0"
     if mode == "0":
@@ -810,7 +817,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     key = _sig(kind, d, (add_src is not None, mask is not None, add_src is not None and add_src is args[2], split_penalty_ms > 0,
                          mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
                          os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"),
-                         os.environ.get("ZSG_SK", "1") != "0"))
+                         allow_sk and os.environ.get("ZSG_SK", "1") != "0"))
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -830,7 +837,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
             cands += [tile_hint(bm, bn, 1, w8) | K64_FLAG for bm, bn in tiles for w8 in (0, 1) if not (bm == 128 and bn == 128 and not w8)]
         if fn is lib.zsg_conv_igemm and os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"):
             cands += pw_cands(d)          # (ZSG_MX=0: A/B switch for the streaming first-layer kernel alone)
-        if fn is not lib.zsg_conv_igemm_bnpre:
+        if allow_sk and fn is not lib.zsg_conv_igemm_bnpre:
             ensure_stream_scratch(stream)
             cands += sk_cands(d, rows)
         blocks64 = ((rows + 63) // 64) * ((d.N + 63) // 64)
@@ -863,7 +870,9 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     if wino_args is not None and kind == "igemm":
         wfn = wino_fn or lib.zsg_conv_wino
         wconv = marshal(wfn, (d,) + tuple(wino_args))
-        trials += [(wfn, wconv, h, WINO_FLAG) for h in _wino_cands(d)]
+        if allow_sk:
+            ensure_stream_scratch(stream)
+        trials += [(wfn, wconv, h, WINO_FLAG) for h in _wino_cands(d, allow_sk)]
     elif wino_args is not None:           # weight gradient: zsg_conv_wgrad_wino, split-K over 8-tile stages
         wconv = marshal(lib.zsg_conv_wgrad_wino, (d,) + tuple(wino_args))
         tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
