@@ -176,6 +176,10 @@ def parse():
     ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"], help="after the headline legs, time BASELINE configs[3] / [4]'s "
                     "per-GPU shapes (SSD-VGG16 300^2 B=32, ResNet-101 FPN 600^2 B=32) in this process; auto = only for the default headline "
                     "configuration at N=1 with a stamp-matched shipped tuning table (otherwise they would be autotuned for minutes)")
+    ap.add_argument("--ddp-variants", default="auto", choices=["auto", "on", "off"], help="data-parallel runs only: after the headline legs, two short "
+                    "legs with ONE thing changed each — the chain's wave priority off (zsg_set_main_priority(0): how do RCCL's priority-0 kernels "
+                    "fare beside a priority-3 backward?) and the other transport (ZSG_COMM torch <-> native) — printed beside the default in `rccl`; "
+                    "auto = whenever the run is data-parallel (N > 1 or --force-ddp)")
     ap.add_argument("--launch-check", action="store_true", help="only bring up the N-rank process group (backend ZSG_DIST_BACKEND, default "
                     "nccl), all-reduce one tensor and print a JSON line: tests the launcher without a GPU (gloo)")
     return ap.parse_args()
@@ -391,6 +395,60 @@ def main():
         torch.cuda.synchronize()
         red0.time_wait = False
         exposed_ms = red0.exposed_ms()
+    # Data-parallel runs: the same step with ONE thing changed, so that the first multi-GPU run answers by itself (a) whether the chain's
+    # wave priority starves or helps the collectives that run beside it and (b) which transport is faster.  Every
+    # rank runs the same legs in the same order; untimed warm-up + 20 timed steps each, max over ranks; not part of `value`.
+    variants = None
+    if model is not net and a.ddp_variants != "off":
+        def short_leg(n_warm=8, n=20):
+            for _ in range(n_warm):
+                step()
+            fence()
+            t0_ = time.perf_counter()
+            for _ in range(n):
+                step()
+            fence()
+            t_ = torch.tensor([time.perf_counter() - t0_], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            red_ = next((p.reducer for p in net._plans.values() if p.reducer is not None), None)
+            ex_ = None
+            if red_ is not None:
+                red_.time_wait = True
+                for _ in range(6):
+                    step()
+                torch.cuda.synchronize()
+                red_.time_wait = False
+                ex_ = red_.exposed_ms()
+            return {"ms_per_step": round(1e3 * float(t_.item()) / n, 3), "images_per_s": round(a.bs * world * n / float(t_.item()), 1),
+                    "exposed_allreduce_ms": round(ex_, 3) if ex_ is not None else None}
+        variants = {"what": "the headline step with one setting changed (20 timed steps each, max over ranks): wave priority of the dependent "
+                            "chain's kernels off; the other all-reduce transport", "default": {"main_priority": lib.zsg_get_main_priority(),
+                            "transport": "native" if model.comm is not None else "torch", "ms_per_step": round(1e3 * dt / a.steps, 3)}}
+        try:
+            prio0 = lib.zsg_get_main_priority()
+            lib.zsg_set_main_priority(0 if prio0 else 3)
+            variants["main_priority_%d" % (0 if prio0 else 3)] = short_leg()
+            lib.zsg_set_main_priority(prio0)
+            other = "torch" if model.comm is not None else "native"
+            if other == "native" and dist.is_initialized() and dist.get_backend() != "nccl":
+                raise RuntimeError("transport leg skipped: the native transport (RCCL inside libzsg.so) needs the nccl backend, one GPU per rank "
+                                   f"(this run: {dist.get_backend()})")
+            keep_model = model
+            model = zdist.DistributedDataParallel(net, device_ids=[local], broadcast_buffers=True, force_collectives=a.force_ddp, comm=other)
+            for p_ in net._plans.values():
+                p_.reducer = None            # (rebuilt by the next backward on the new wrapper's transport)
+            variants["transport_" + other] = short_leg()
+            if model.comm is not None:
+                model.close()
+            model = keep_model
+            object.__setattr__(net, "_ddp", keep_model)
+            for p_ in net._plans.values():
+                p_.reducer = None
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:               # (never lose the headline line to a secondary leg)
+            variants["error"] = f"{type(e).__name__}: {e}"
     per_rank = None
     if world > 1:                            # every rank's own clock and exposed wait, for the first scaling curve
         mine = torch.tensor([1e3 * dt / a.steps, median_ms, exposed_ms if exposed_ms is not None else -1.0], device="cuda", dtype=torch.float64)
@@ -548,6 +606,7 @@ def main():
                 "bn_buffer_broadcast_bytes_per_step": int(net._rmv.numel() * 4),
                 "exposed_allreduce_ms": round(exposed_ms, 3) if exposed_ms is not None else None,
                 "exposed_note": "time the compute stream stands behind the last bucket's collective after the backward's last launch (rank 0; mean per step)",
+                "variants": variants,
                 "per_rank": per_rank,
                 "per_rank_min_max_ms_per_step": [min(per_rank["ms_per_step"]), max(per_rank["ms_per_step"])] if per_rank else None}
     if rank == 0:

@@ -128,18 +128,6 @@ int zsg_conv_wgrad(const zsg_conv_desc* d, const float* src, const float* dy, fl
 int zsg_conv_wino(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias,
                   const float* add_src, const float* mask_src, float* bn_partials, void* stream);
 
-/* Winograd F(4x4,3x3) (round 5; csrc/wino4.hip): 2.25 instead of 4 (F(2x2,3x3)) or 9 multiply-adds per (pixel, cin, cout) for the
- * 3x3 / stride 1 / pad 1 convolutions BEHIND the network's last BatchNorm — the pyramid's output convolutions and the shared head
- * (fpn_resnet.py:157-172, mdl.py:211-244), forward and data gradient.  Same descriptor and epilogue terms as zsg_conv_wino (bias,
- * add_src / accumulate, ReLU, float ReLU mask; no split-K, no BatchNorm partials: it is never offered in front of a BatchNorm — its
- * rounding error, 6.5e-6 of the output range per layer against 4.8e-7, is only admissible where nothing amplifies it;
- * profiles/r05_wino_f4_gate.txt).  `U` is the transformed filter image made by zsg_wino4_weights ([C/8][36][Npad][8] floats =
- * zsg_wino4_u_elems); jobs as zsg_wino_weights (one record per convolution; blocks = ceil(chunks * Npad * 8 / 256) each). */
-int64_t zsg_wino4_u_elems(int32_t C, int32_t N);
-int zsg_wino4_weights(const void* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream);
-int zsg_conv_wino4(const zsg_conv_desc* d, const float* src, const float* U, float* out, const float* bias, const float* add_src,
-                   const float* mask_src, void* stream);
-
 /* Data gradient that COMPLETES dout of a train-mode BatchNorm (out = dgrad [+ add_src]; autograd's conv backward followed by
  * native_batch_norm_backward of fpn_resnet.py:86-97's conv-bn-relu chains): the epilogue also reduces that BatchNorm's
  * backward sums per output tile — partials[m_tile][0][n] = sum g, partials[m_tile][1][n] = sum g * (x - mean) * invstd with
@@ -427,6 +415,14 @@ int zsg_adam_step_range(float* p, const float* g, float* m, float* v, int64_t n,
                         float weight_decay, float grad_scale, int32_t* step_count, int32_t publish, void* stream);
 
 int zsg_memset_f32(float* p, int64_t n, float value, void* stream);
+
+/* Wave priority of the kernels of the step's dependent chain (convolutions forward / data gradient, BatchNorm passes, the small
+ * main-stream kernels): 3 (default) = they issue ahead of the weight-gradient kernels wherever a CU holds waves of both streams
+ * (s_setprio 3 as their first instruction), 0 = off.  A run-time switch since round 6 (a build-time constant before) so that a multi-GPU
+ * run can compare both beside RCCL's priority-0 kernels.  Applies to the CURRENT device, synchronises it; call between steps.  No
+ * reference counterpart (PyTorch / cuDNN kernels carry no priorities; the reference's overlap is NCCL's own, main_dist.py:36-40). */
+int zsg_set_main_priority(int32_t prio);
+int zsg_get_main_priority(void);
 
 /* Scratch for the launches of one stream (round 6).  The reference has no counterpart: cuDNN / cuBLAS take their split-K workspace from
  * PyTorch's caching allocator behind nn.Conv2d (mdl.py:149-156, fpn_resnet.py:86-100).  Here the caller owns it: `ws` (256-byte aligned,

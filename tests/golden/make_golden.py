@@ -207,14 +207,53 @@ def gen_learnable(R, S=128, B=16, steps=240, lr=1e-3, decay_at=200):
          steps=np.array([steps]), lr=np.array([lr]), decay_at=np.array([decay_at]), seed=np.array([3]), feat_sizes=np.array(fs))
 
 
+def gen_trajectory(R, S=300, B=16, steps=12, lr=1e-4):
+    """G16 (round 6): the REFERENCE's own first 12 optimisation steps at the configs[1] shape (ResNet-50 FPN, 300x300, B=16; mdl.py /
+    loss.py + torch.optim.Adam(lr 1e-4, betas (0.9, 0.99)) as main_dist.py:50) from a seeded start, a fresh synthetic batch and fresh
+    LSTM start states every step.  Recorded: every step's loss and three BatchNorm running statistics after the last step.
+    tests/test_gpu_fullshape.py::test_training_trajectory_and_eval_argmax_agreement steps the HIP model through the same stream of
+    batches (until round 5 it stepped the CPU oracle beside it inside the GPU test: 100 s of the GPU suite)."""
+    A, L, M, cfg = R["anchors"], R["loss"], R["mdl"], R["cfg"]
+    ratios = eval(cfg["ratios"], {})
+    scales = cfg["scale_factor"] * np.array(eval(cfg["scales"], {}))
+    sd = O.seeded_state_dict("resnet50", seed=17)
+    net = M.get_default_net(num_anchors=9, cfg=cfg)
+    net.load_state_dict(sd, strict=False)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=lr, betas=(0.9, 0.99))
+    lf = L.get_default_loss(ratios, scales, cfg)
+    gq = torch.Generator().manual_seed(8)
+    losses = []
+    for it in range(steps):
+        bt = O.synthetic_batch(B, S, S, seed=500 + it)
+        h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
+        net.lstm_init_hidden = lambda bs, h0=h0, c0=c0: (h0, c0)
+        out = net(bt)
+        if it == 0:
+            fs = [tuple(int(v) for v in r) for r in out["feat_sizes"].tolist()]
+            lf.anchs = A.create_anchors(fs, ratios, scales, device=torch.device("cpu")).float()
+        ls = lf(out, bt)
+        opt.zero_grad()
+        ls["loss"].mean().backward()
+        opt.step()
+        losses.append(float(ls["loss"].item()))
+        print(f"  g16 step {it}: loss {losses[-1]:.4f}", flush=True)
+    st = net.state_dict()
+    keys = ("backbone.encoder.bn1.running_mean", "backbone.encoder.layer2.3.bn3.running_var", "backbone.encoder.layer4.2.bn3.running_mean")
+    save("g16_trajectory", losses=np.array(losses, np.float64), seed=np.array([17]), batch_seed0=np.array([500]), hc_seed=np.array([8]),
+         lr=np.array([lr]), rm_bn1=st[keys[0]].numpy(), rv_l2=st[keys[1]].numpy(), rm_l4=st[keys[2]].numpy())
+
+
 def main():
     R = import_reference()
     A, L, E, M, cfg = R["anchors"], R["loss"], R["evaluator"], R["mdl"], R["cfg"]
-    if ONLY and all(o.startswith("g14") or o.startswith("g15") for o in ONLY):
+    if ONLY and all(o.startswith(("g14", "g15", "g16")) for o in ONLY):
         if any(o.startswith("g14") for o in ONLY):
             gen_resize(cfg)
         if any(o.startswith("g15") for o in ONLY):
             gen_learnable(R)
+        if any(o.startswith("g16") for o in ONLY):
+            gen_trajectory(R)
         return
     ratios = eval(cfg["ratios"], {})
     scales = cfg["scale_factor"] * np.array(eval(cfg["scales"], {}))
@@ -670,6 +709,7 @@ def main():
     save("g13_dataset", **d)
     gen_resize(cfg)
     gen_learnable(R)
+    gen_trajectory(R)
     print("done")
 
 

@@ -3,7 +3,7 @@
     every gradient norm, sampled gradients) and, parameter by parameter, against the fp32 CPU oracle (cosine / relative
     error).  At B=16 the BatchNorm statistics average over >= 1600 pixels per channel, so the bounds are tighter than
     the B=2 tests' (which have to allow for fp32 chaos through batch statistics of a handful of pixels).
-  * configs[4] per-GPU shape: ResNet-101 FPN at 600x600 (four-level pyramid), B=1.
+  * configs[4] per-GPU shape: ResNet-101 FPN at 600x600 (four-level pyramid), B=1 live and B=4 against an oracle-made fixture.
   * configs[3]: SSD-VGG16 at 300x300, B=2.
   * a 20-step training trajectory at the configs[1] shape and eval-mode arg-max agreement over 256 samples (the proxy for
     the north_star's Acc@IoU0.5 clause: no dataset is available offline).
@@ -169,13 +169,61 @@ def _fwd_bwd_vs_fp64(Z, arch, B, hw, six, kind="retina", seed=13):
     assert not bad, f"{len(bad)} gradients further from fp64 than allowed: {bad[:6]}"
 
 
-@pytest.mark.parametrize("B", [1, 2])
+@pytest.mark.parametrize("B", [1])
 def test_configs4_resnet101_600(Z, B):
-    """flickr30k_c1's per-GPU shape: ResNet-101 + FPN at 600x600 (four levels, fpn_resnet.py:173-174), B=1 and B=2 (batch
-    statistics over more than one image).  The reference cannot construct ResNet-101 (mdl.py:411 hard-codes resnet50), so there is
+    """flickr30k_c1's per-GPU shape: ResNet-101 + FPN at 600x600 (four levels, fpn_resnet.py:173-174), B=1 (B=4: the next test).
+    The reference cannot construct ResNet-101 (mdl.py:411 hard-codes resnet50), so there is
     no reference golden for this depth: the check is HIP vs the oracle's fp64 twin; every block type it is made of is pinned by
     reference goldens (g8_bottleneck, g8_fpn600)."""
     _fwd_bwd_vs_fp64(Z, "resnet101", B, 600, True)
+
+
+def test_configs4_resnet101_600_b4_vs_oracle_fixture(Z, gold):
+    """ResNet-101 + FPN at 600x600, B=4: outputs, loss and EVERY parameter gradient against the oracle's fp64 twin (VERDICT r05 item 5:
+    the largest batch whose CPU oracle is affordable — B=32 is not).  The oracle side — one fp32 and one fp64 forward + backward on the
+    host, minutes — is a committed fixture (tests/golden/o1_r101_600_b4.npz, made by tests/golden/make_oracle_fixtures.py from the
+    oracle whose blocks the reference goldens pin); the criterion is _fwd_bwd_vs_fp64's: the HIP path must be as close to fp64 as the
+    CPU fp32 oracle is (forward: max(4 x, 2e-3); per parameter: test_gpu_net.grad_tol), measured on the fixture's sampled gradient
+    entries (<= 512 per parameter, fixed stride) and scaled to the full tensor by the CPU oracle's own sampled / full ratio."""
+    from test_gpu_net import grad_tol
+    g = gold("o1_r101_600_b4")
+    B, hw = int(g["B"][0]), int(g["hw"][0])
+    cfg, net, sd, lf, ev = build(Z, arch="resnet101", seed=int(g["seed"][0]), resize_img=[hw, hw])
+    net.train()
+    bt = O.synthetic_batch(B, hw, hw, seed=int(g["batch_seed"][0]))
+    gq = torch.Generator().manual_seed(int(g["hc_seed"][0]))
+    h0, c0 = torch.randn(2, B, 128, generator=gq), torch.randn(2, B, 128, generator=gq)
+    inp = to_dev(bt)
+    inp["h0"], inp["c0"] = h0, c0
+    out = net(inp)
+    assert out["feat_sizes"].tolist() == g["feat_sizes"].tolist()
+    o_gpu = out["att_bbx_out"].detach().cpu().double()[:, ::int(g["out_stride"][0])]
+    err, err_cpu = float((o_gpu - torch.from_numpy(g["out64_s"])).abs().max()), float(g["fwd_err_cpu"][0])
+    print(f"resnet101 {hw}x{hw} B={B}: forward max abs err vs fp64 (sampled anchors): HIP {err:.2e}, CPU fp32 oracle (all anchors) {err_cpu:.2e}")
+    assert err <= max(4 * err_cpu, 2e-3)
+    ls = lf(out, inp)
+    l64, l32 = float(g["loss64"][0]), float(g["loss32"][0])
+    np.testing.assert_allclose(ls["loss"].item(), l64, rtol=max(5e-4, 4 * abs(l32 - l64) / abs(l64)))
+    ls["loss"].backward()
+    P = dict(net.named_parameters())
+    bad, worst = [], (0.0, "")
+    for i, n in enumerate(g["names"]):
+        n = str(n)
+        gh = P[n].grad.detach().cpu().double().reshape(-1)
+        k = gh.numel()
+        idx = np.arange(0, k, max(1, k // 512))[:512]
+        g64s, g32s = torch.from_numpy(g["g64_s"][i][:len(idx)]), torch.from_numpy(g["g32_s"][i][:len(idx)]).double()
+        e_hip_s, e_cpu_s = float((gh[idx] - g64s).norm()), float((g32s - g64s).norm())
+        n64, e_cpu = float(g["norm64"][i]), float(g["err32"][i])
+        # sampled -> full tensor: the sample covers len(idx) of k entries; both errors are scaled alike (sqrt(k / len(idx)))
+        scale = (k / len(idx)) ** 0.5
+        eg, ec = e_hip_s * scale, max(e_cpu, e_cpu_s * scale)
+        tol = grad_tol(ec, torch.tensor([n64]))
+        worst = max(worst, (eg / (n64 + 1e-300), n))
+        if eg > tol:
+            bad.append((n, eg, ec, n64))
+    print(f"resnet101 {hw}x{hw} B={B}: worst HIP gradient distance from fp64 (relative, sampled): {worst[0]:.2e} ({worst[1]}); {len(g['names'])} parameters")
+    assert not bad, f"{len(bad)} gradients further from fp64 than allowed: {bad[:6]}"
 
 
 def test_configs3_ssd_vgg_b2(Z):
@@ -292,28 +340,29 @@ def test_configs3_ssd_vgg_b32_properties(Z):
     _full_batch_properties(Z, "ssd_vgg", 32, 300, "ssd_vgg", seed=5, oracle_grads=True)
 
 
-def test_training_trajectory_and_eval_argmax_agreement(Z):
+def test_training_trajectory_and_eval_argmax_agreement(Z, gold):
     """Acc@IoU0.5 proxy (no dataset is available offline).  (1) 12 optimisation steps at the configs[1] shape (ResNet-50 FPN,
-    300x300, B=16; a fresh synthetic batch and fresh LSTM states every step, Adam lr 1e-4 as main_dist.py:50) next to the
-    CPU oracle stepping torch.optim.Adam from the same start.  Adam's first steps are ~lr*sign(g), so rounding-level
+    300x300, B=16; a fresh synthetic batch and fresh LSTM states every step, Adam lr 1e-4 as main_dist.py:50) against the
+    REFERENCE's own 12 steps from the same start on the same stream of batches (golden g16_trajectory: mdl.py / loss.py +
+    torch.optim.Adam on the CPU, tests/golden/make_golden.py gen_trajectory; until round 5 the CPU oracle was stepped beside the
+    HIP model inside this test — 100 s of the GPU suite).  Adam's first steps are ~lr*sign(g), so rounding-level
     gradient differences on near-zero elements flip their update and the two fp32 trajectories drift apart chaotically
     (any two fp32 implementations do; measured: up to ~10 % on single steps while the loss falls 8x): asserted are the
     same starting loss (2e-4), every step within 15 %, the mean of the last six steps within 5 %, and the same overall
-    decrease; BatchNorm running statistics within 1 %.  (2) the oracle's trained weights, loaded into both, in eval mode on 128
+    decrease; BatchNorm running statistics within 1 %.  (2) the trained weights, loaded into the CPU oracle, in eval mode on 128
     fresh samples: the arg-max-score anchor (evaluator.py:74) must equal the oracle's wherever the oracle's
     top-2 score gap exceeds 1e-3, and the Acc@IoU0.5 hit counts must agree to within the samples below that gap."""
     config, evaluator, loss, mdl, optim = Z
-    cfg, net, sd, lf, ev = build(Z, seed=17)
+    g = gold("g16_trajectory")
+    cfg, net, sd, lf, ev = build(Z, seed=int(g["seed"][0]))
     net.train()
-    opt = optim.FusedAdam(net, lr=1e-4, betas=(0.9, 0.99))
-    params = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
-    buffers = {k: v.clone() for k, v in sd.items() if k not in params}
-    opt_ref = torch.optim.Adam(list(params.values()), lr=1e-4, betas=(0.9, 0.99))
+    opt = optim.FusedAdam(net, lr=float(g["lr"][0]), betas=(0.9, 0.99))
     anc = torch.from_numpy(O.create_anchors(O.feat_sizes_for(300, 300), RATIOS, SCALES).astype(np.float32))
-    gq = torch.Generator().manual_seed(8)
+    gq = torch.Generator().manual_seed(int(g["hc_seed"][0]))
+    ref_losses = [float(v) for v in g["losses"]]
     curve = []
-    for it in range(12):
-        bt = O.synthetic_batch(16, 300, 300, seed=500 + it)
+    for it in range(len(ref_losses)):
+        bt = O.synthetic_batch(16, 300, 300, seed=int(g["batch_seed0"][0]) + it)
         h0, c0 = torch.randn(2, 16, 128, generator=gq), torch.randn(2, 16, 128, generator=gq)
         inp = to_dev(bt)
         inp["h0"], inp["c0"] = h0, c0
@@ -322,26 +371,23 @@ def test_training_trajectory_and_eval_argmax_agreement(Z):
         ls = lf(out, inp)
         ls["loss"].mean().backward()
         opt.step()
-        lr, _ = O.cpu_train_step(params, buffers, opt_ref, bt, h0, c0, anc, arch="resnet50")
-        curve.append((ls["loss"].item(), lr["loss"].item()))
+        curve.append((ls["loss"].item(), ref_losses[it]))
     dev_ = max(abs(a - b) / abs(b) for a, b in curve)
     tail_h, tail_o = np.mean([a for a, _ in curve[-6:]]), np.mean([b for _, b in curve[-6:]])
-    print("loss curve (hip, oracle):", [(round(a, 3), round(b, 3)) for a, b in curve], f"max rel deviation {dev_:.2e}; last-6 mean {tail_h:.3f} vs {tail_o:.3f}")
+    print("loss curve (hip, reference):", [(round(a, 3), round(b, 3)) for a, b in curve], f"max rel deviation {dev_:.2e}; last-6 mean {tail_h:.3f} vs {tail_o:.3f}")
     np.testing.assert_allclose(curve[0][0], curve[0][1], rtol=2e-4)
     assert dev_ <= 0.15, curve
     assert abs(tail_h - tail_o) <= 0.05 * tail_o
     assert curve[-1][0] < 0.5 * curve[0][0] and curve[-1][1] < 0.5 * curve[0][1]
     got = net.state_dict()
-    for k in ("backbone.encoder.bn1.running_mean", "backbone.encoder.layer2.3.bn3.running_var", "backbone.encoder.layer4.2.bn3.running_mean"):
-        e = rel_err(got[k].cpu(), buffers[k])
+    for k, gk in (("backbone.encoder.bn1.running_mean", "rm_bn1"), ("backbone.encoder.layer2.3.bn3.running_var", "rv_l2"),
+                  ("backbone.encoder.layer4.2.bn3.running_mean", "rm_l4")):
+        e = rel_err(got[k].cpu(), torch.from_numpy(g[gk]))
         print(f"{k}: rel diff after 12 steps {e:.2e}")
         assert e <= 1e-2, f"{k}: running statistic differs by {e:.3g} after 12 steps"
-    # (2) eval-mode arg-max agreement on 128 fresh samples at the ORACLE's trained weights (after 12 chaotic Adam steps the
-    # two weight sets differ, so each model's own arg-max anchors are not comparable; the eval path — BatchNorm folded into
-    # the convolutions, evaluator kernel — is what is compared here, at weights whose scores are no longer near-ties)
-    sd_ref = {k: v.detach() for k, v in params.items()}
-    sd_ref.update(buffers)
-    net.load_state_dict(sd_ref)
+    # (2) eval-mode arg-max agreement on 128 fresh samples at the TRAINED weights, loaded into the CPU oracle (the eval path — BatchNorm
+    # folded into the convolutions, evaluator kernel — is what is compared here, at weights whose scores are no longer near-ties)
+    sd_ref = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}      # the trained weights, for the CPU oracle
     net.eval()
     n_sure = n_agree = 0
     acc_hip = acc_ref = 0.0

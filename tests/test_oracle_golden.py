@@ -365,3 +365,21 @@ def test_learnable_task_first_step_vs_reference(gold):
     ls = O.torch_loss(out, bt["annot"], anc)
     np.testing.assert_allclose(float(ls["loss"]), g["losses"][0], rtol=2e-5)
     assert g["losses"][-10:].mean() < 0.01 * g["losses"][0] and g["hits"].sum() >= 0.95 * 256      # (the reference did learn the task)
+
+
+def test_g16_oracle_reproduces_the_reference_trajectory_start(gold):
+    """G16 (the reference's own 12-step training run at the configs[1] shape, tests/golden/make_golden.py gen_trajectory): the oracle's
+    first step from the same seeded start on the same batch must give the reference's first loss (rel 2e-5) — the later steps are what
+    the GPU suite steps the HIP model through (test_gpu_fullshape.py)."""
+    g = gold("g16_trajectory")
+    sd = O.seeded_state_dict("resnet50", int(g["seed"][0]))
+    bt = O.synthetic_batch(16, 300, 300, seed=int(g["batch_seed0"][0]))
+    gq = torch.Generator().manual_seed(int(g["hc_seed"][0]))
+    h0, c0 = torch.randn(2, 16, 128, generator=gq), torch.randn(2, 16, 128, generator=gq)
+    with torch.no_grad():
+        ref = O.zsgnet_forward(sd, bt, h0, c0, arch="resnet50")
+        r, s = O.default_ratios_scales()
+        anc = torch.from_numpy(O.create_anchors([tuple(x) for x in ref["feat_sizes"].tolist()], r, s).astype(np.float32))
+        ls = O.torch_loss(ref, bt["annot"], anc)
+    np.testing.assert_allclose(float(ls["loss"]), float(g["losses"][0]), rtol=2e-5)
+    assert len(g["losses"]) == 12 and g["losses"][-1] < 0.5 * g["losses"][0]

@@ -1,13 +1,15 @@
 """Developer tool (GPU box): single-launch times of zsg_conv_wino4 next to zsg_conv_wino's best tile on the shapes F(4x4,3x3) is offered
 for (pyramid output P3_2, the head's levels): us per launch (mean of 20 back-to-back launches) and executed / algorithmic TFLOP/s.
-usage: python tools/bench_wino4.py"""
+usage: ZSG_LIB_PATH=<EXPERIMENTS=1 build> python tools/experiments/wino4/bench_wino4.py"""
 import ctypes as C
 import os
 import sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))), os.path.dirname(os.path.abspath(__file__))]
 from zsgnet_pytorch_amd import ops                                   # noqa: E402
-from zsgnet_pytorch_amd._lib import lib, check, stream_ptr           # noqa: E402
+from zsgnet_pytorch_amd._lib import lib, check, stream_ptr
+from bind import bind
+bind()           # noqa: E402
 
 
 def timeit(fn, reps=20):

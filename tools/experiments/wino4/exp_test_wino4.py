@@ -1,4 +1,4 @@
-"""Winograd F(4x4,3x3) convolution (csrc/wino4.hip: zsg_wino4_weights + zsg_conv_wino4) through the raw C ABI, forward and data
+"""EXPERIMENT (tools/experiments/README.md).  Winograd F(4x4,3x3) convolution (wino4.hip: zsg_wino4_weights + zsg_conv_wino4) through the raw C ABI, forward and data
 gradient, against torch in float64 — the pyramid-output / shared-head convolutions of fpn_resnet.py:157-172 and mdl.py:211-244.
 Numeric gate of VERDICT r04 item 7: op-level error against fp64 <= 1e-5 of the output range on head-shaped operands (C = 256, post-ReLU
 activations, He-scaled weights); the general cases are held to 5e-5 of the output range (random-sign inputs of smaller fan-in).
@@ -10,7 +10,15 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from test_gpu_ops import Z, dev, nhwc, ohwi, pad4, view_of  # noqa: F401
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests"), os.path.dirname(os.path.abspath(__file__))]
+from test_gpu_ops import Z, dev, nhwc, ohwi, pad4, view_of  # noqa: E402,F401
+from bind import bind  # noqa: E402
+
+bind()      # (the experiment's three symbols on the loaded library: a build made with EXPERIMENTS=1, see ../README.md)
 
 pytestmark = pytest.mark.gpu
 

@@ -1,9 +1,11 @@
 """Developer tool (GPU box): zsg_conv_wino4 launch time against the number of 8-channel chunks (P3_2's geometry): t = fixed + per-chunk."""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))), os.path.dirname(os.path.abspath(__file__))]
 from zsgnet_pytorch_amd import ops
 from zsgnet_pytorch_amd._lib import lib, check, stream_ptr
-from tools.bench_wino4 import timeit, levels
+from bind import bind
+bind()
+from bench_wino4 import timeit, levels
 B, Co = 16, 256
 st = C.c_void_p(stream_ptr())
 for Ci in (8, 64, 128, 256, 512):

@@ -30,6 +30,7 @@
 // single LDS stage ran 5 us per chunk (177 us for P3_2 against 140 us for F(2x2,3x3)); patch rows by LDS-DMA made hipcc drain every
 // register load at the top of each chunk (vmcnt(0)), and hand-counted inline-asm loads around that cost 70 spilled registers.
 #include "common.h"
+#include "zsg_wino4.h"      // (the experiment's own declarations: not part of include/zsg.h)
 
 #define W4_CK 8
 #define W4_TB 32

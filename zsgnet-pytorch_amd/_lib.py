@@ -56,9 +56,6 @@ SIGNATURES = {
     "zsg_comm_wait": (I32, [P, P]),
     "zsg_comm_destroy": (I32, [P]),
     "zsg_conv_wino": (I32, [DP, P, P, P, P, P, P, P, P]),
-    "zsg_wino4_u_elems": (I64, [I32, I32]),
-    "zsg_wino4_weights": (I32, [P, I32, I32, P]),
-    "zsg_conv_wino4": (I32, [DP, P, P, P, P, P, P, P]),
     "zsg_bn_relu_maxpool_fwd": (I32, [P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P]),
     "zsg_bn_relu_maxpool_bwd": (I32, [P, P, P, I32, I32, I32, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, I32, P, SZ, P]),
     "zsg_conv_igemm_bnb": (I32, [DP, P, P, P, P, P, P, P, P, P, P]),
@@ -124,6 +121,8 @@ SIGNATURES = {
     "zsg_adam_step_range": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, P, I32, P]),
     "zsg_memset_f32": (I32, [P, I64, F32, P]),
     "zsg_set_stream_workspace": (I32, [P, P, SZ]),
+    "zsg_set_main_priority": (I32, [I32]),
+    "zsg_get_main_priority": (I32, []),
     "zsg_event_create": (P, []),
     "zsg_event_destroy": (I32, [P]),
     "zsg_set_completion_event": (I32, [P]),

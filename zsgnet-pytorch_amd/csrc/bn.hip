@@ -5,6 +5,8 @@
 
 #include "common.h"
 
+ZSG_DEFINE_PRIO_FLAG()
+
 struct BnGeom {
     int lanes;      // float4 lanes across channels inside a block (<= 64)
     int rowlanes;   // 256 / lanes

@@ -20,7 +20,12 @@
 //             polls the counter (relaxed sc1 loads + s_sleep) until every other storing wave has arrived, reads the rows with sc1
 //             loads (they bypass this CU's L1; the rows never sat dirty in another XCD's L2), reduces, publishes, and stores 0 into the
 //             counter (zero again when the kernel ends: no memset per call).
-// The producers do not depend on the reducer, so the poll cannot deadlock: it holds one CU slot while the rest of the grid drains.
+// The producers do not depend on the reducer, so the poll cannot deadlock: it holds one CU slot while the rest of the grid drains
+// (every producer only has to be DISPATCHED; a grid larger than the resident capacity drains in dispatch order — the reducer is the column
+// block's LAST row tile, dispatched among the last).  Visibility rests on the pairing the guide prescribes for payloads of this size
+// (MI355X_MICROARCH.md, inter-workgroup visibility: `sc1` write-through stores AND `sc1` loads on both sides, the producer's stores
+// drained with s_waitcnt vmcnt(0) before its arrival) — not on fences, which write back / invalidate a whole XCD L2 (5-30x slower,
+// DESIGN.md section 8 round 2).  The poll is bounded (below).
 // The output stores of a tile are never waited for on their own account (nobody reads them in this launch).
 //
 // Results do not depend on dispatch order or XCD placement; counters must be zero at entry (the host allocates them zeroed, one word
@@ -72,12 +77,20 @@ __device__ __forceinline__ void bn_tail_reduce(const BnTail& t, unsigned* counte
     const int tid = threadIdx.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's own partial row (every storing wave drains)
     __syncthreads();
+    // Bounded poll (~1-2 s): a lost arrival — an aborted launch that left the word nonzero, a producer workgroup that never
+    // became resident — must not hang the training step.  The reducer then gives up, re-zeroes the counter and POISONS what it
+    // publishes (NaN statistics / coefficients): the loss turns NaN at once and the trainer's NaN handling names the step, instead of a
+    // silent wait.  sh[0] carries the verdict to the other threads.
     if (tid == 0) {
         const unsigned expect = (unsigned)(nrows - 1) * SW;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect) __builtin_amdgcn_s_sleep(8);
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+        *(volatile int*)sh = spins >= (1 << 20) ? 1 : 0;
     }
     __syncthreads();
+    const bool poisoned = *(volatile int*)sh != 0;
+    __syncthreads();                      // (sh is reused below)
     const int cg = tid % CG, kind = (tid / CG) & 1, rl = tid / (2 * CG);
     const int n = n0 + 4 * cg;
     double v[4] = {0, 0, 0, 0};
@@ -114,6 +127,7 @@ __device__ __forceinline__ void bn_tail_reduce(const BnTail& t, unsigned* counte
         }
         const int c = n0 + tid;
         const double cnt = (double)t.rows;
+        if (poisoned) s = ss = __builtin_nan("");
         if (t.mode == 0) {
             const double m = s / cnt;
             double var = ss / cnt - m * m;

@@ -34,10 +34,25 @@ int zsg_conv_mx_launch(const zsg_conv_desc* d, const float* src, const float* wt
 
 // Wave priority of the kernels of the step's dependent (main-stream) chain: convolutions, BatchNorm passes.  The weight-gradient kernels
 // (side stream) stay at 0, so where a CU holds blocks of both streams the SIMD's arbiter serves the critical chain first.
+// Round 6: a RUN-TIME switch (zsg_set_main_priority; default ZSG_MAIN_PRIO = 3).  s_setprio takes an immediate, so the kernels branch on a
+// flag word: one __constant__ int per translation unit (no relocatable device code: every .hip file is its own code object), set by a
+// per-file setter that registers itself with api.cpp.  The read is one scalar load next to the kernel-argument loads.
 #ifndef ZSG_MAIN_PRIO
 #define ZSG_MAIN_PRIO 3
 #endif
-#define ZSG_SET_MAIN_PRIO() do { if (ZSG_MAIN_PRIO) __builtin_amdgcn_s_setprio(ZSG_MAIN_PRIO); } while (0)
+typedef int (*zsg_prio_setter_t)(int);
+void zsg_register_prio_setter(zsg_prio_setter_t fn);
+#define ZSG_DEFINE_PRIO_FLAG()                                                                                                      \
+    __constant__ int zsg_prio_flag_c = ZSG_MAIN_PRIO;                                                                               \
+    static int zsg_prio_set_(int v) {                                                                                               \
+        return hipMemcpyToSymbol(HIP_SYMBOL(zsg_prio_flag_c), &v, sizeof(int), 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -3;      \
+    }                                                                                                                               \
+    namespace {                                                                                                                     \
+    struct ZsgPrioReg {                                                                                                             \
+        ZsgPrioReg() { zsg_register_prio_setter(zsg_prio_set_); }                                                                   \
+    } zsg_prio_reg_;                                                                                                                \
+    }
+#define ZSG_SET_MAIN_PRIO() do { if (zsg_prio_flag_c) __builtin_amdgcn_s_setprio(3); } while (0)
 
 #define ZSG_WAVE 64
 #define ZSG_NUM_CU 256

@@ -15,6 +15,8 @@
 #include "common.h"
 #include "bn_tail.h"
 
+ZSG_DEFINE_PRIO_FLAG()
+
 #define IG_BK 32
 #define IG_LDK 36
 
@@ -791,9 +793,13 @@ template <int BM, int BN, int NW, bool MX, int KS = 1>
 static int launch_cfg(const IgParams& p, hipStream_t st, double flops, const char* kname) {
     if constexpr (!MX) {
         if (p.pre.y) {                   // the BatchNorm-applying loader (32-deep K tiles; profile name = kname + "+pre")
-            static char nm[96];
-            snprintf(nm, sizeof(nm), "%s+pre", kname);
-            return launch_cfg1<BM, BN, NW, MX, KS, IG_BK, true>(p, st, flops, nm);
+            // (not for the 4-wave 128x128 tile: its 64 accumulator registers + the loader's residual / coefficient stages spill)
+            if constexpr (BM * BN >= 128 * 128 && NW * KS <= 4) ZSG_FAIL(-1, "conv_igemm_bnpre: no 4-wave 128x128 variant (use the 8-wave tile)");
+            else {
+                static char nm[96];
+                snprintf(nm, sizeof(nm), "%s+pre", kname);
+                return launch_cfg1<BM, BN, NW, MX, KS, IG_BK, true>(p, st, flops, nm);
+            }
         }
     }
     if constexpr (!MX) {
@@ -995,6 +1001,11 @@ extern "C" int32_t zsg_conv_bn_tail_tickets(const zsg_conv_desc* d, int32_t is_w
     if (!d || !d->tile_hint || ((d->tile_hint >> 16) & 0xff) > 1 || d->merge_x) return -1;
     const int bm = d->tile_hint & 0xff, bn = (d->tile_hint >> 8) & 0xff;
     if (bm <= 0 || bn <= 0) return -1;
+    // the vectorised epilogue conv_*_impl requires for the in-kernel finalize: 16-byte addressable output rows (the same
+    // predicates here, so that a mismatch is a -1 at lowering time, not a failed launch in the first forward)
+    if ((d->out_ld % 4) != 0 || (d->N % 4) != 0) return -1;
+    for (int s = 0; s < d->nseg; ++s)
+        if ((d->seg[s].out_off % 4) != 0 || (d->seg[s].out_bstride % 4) != 0) return -1;
     int64_t t = 0;
     if (is_wino) {
         if (!((bm == 32 || bm == 64) && (bn == 32 || bn == 64))) return -1;

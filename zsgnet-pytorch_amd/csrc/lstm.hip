@@ -58,6 +58,9 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(const float* __restrict
                 pre += w[k] * hv[0] + w[k + 1] * hv[1] + w[k + 2] * hv[2] + w[k + 3] * hv[3];
             }
         } else {
+            // (not fully unrolled: hipcc hoists all H / 4 row loads in front of the sum — 256 registers at H = 256, 162 of them spilled
+            // at this block's 128-register budget; 8 loads in flight are plenty for an L2-resident row)
+#pragma unroll 8
             for (int k = 0; k < H; k += 4) {
                 const f32x4 hv = *(const f32x4*)(hs + k);
                 const f32x4 wv = *(const f32x4*)(w_hh + (size_t)j * H + k);

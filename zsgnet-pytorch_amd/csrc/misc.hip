@@ -3,6 +3,8 @@
 // All of them move 16 bytes per lane with channel-contiguous (coalesced) accesses.
 #include "common.h"
 
+ZSG_DEFINE_PRIO_FLAG()
+
 static inline int grid_for(int64_t n_items, int block = 256, int cap = ZSG_NUM_CU * 16) {
     int64_t b = (n_items + block - 1) / block;
     if (b < 1) b = 1;

@@ -29,6 +29,8 @@
 // The K sum of an output runs over tap rows, then k slots, in the same order as the implicit GEMM's merge_x tile.
 #include "common.h"
 
+ZSG_DEFINE_PRIO_FLAG()
+
 #define MX_TB 68          // floats per row of a wave's tile buffer: 64 + 4 = 17 x 16 B (odd: conflict-free b128 rows)
 #define MX_LDW 36         // floats per filter row in LDS: 32 k slots + 4 (9 x 16 B, odd)
 #define MX_WAVES 8

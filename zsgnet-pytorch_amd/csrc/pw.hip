@@ -33,6 +33,8 @@
 #define PW_LDS_MAX (160 * 1024)
 #include <stdlib.h>
 
+ZSG_DEFINE_PRIO_FLAG()
+
 struct PwParams {
     const float* src;
     const float* wt;
@@ -478,7 +480,12 @@ static int pw_launch2(const PwParams& p, int grid, size_t lds, hipStream_t st, d
 }
 template <int NJ>
 static int pw_launch1(const PwParams& p, int grid, size_t lds, hipStream_t st, double flops, const char* k0, const char* k1, const char* k2) {
-    if (p.bnb.x) return pw_launch2<NJ, 2>(p, grid, lds, st, flops, k2);
+    if (p.bnb.x) {
+        // (128-channel units have no BatchNorm-backward form: x / add / bits of a pass next to 64 accumulator registers spill 126
+        // registers; zsg_conv_pw_launch runs such launches as 64-channel units and refuses the one geometry that cannot)
+        if constexpr (NJ == 4) ZSG_FAIL(-1, "conv_igemm_bnb: the streaming 1x1 kernel has no 128-channel-unit variant for this geometry");
+        else return pw_launch2<NJ, 2>(p, grid, lds, st, flops, k2);
+    }
     if (p.add_src || p.mask_src) return pw_launch2<NJ, 1>(p, grid, lds, st, flops, k1);
     return pw_launch2<NJ, 0>(p, grid, lds, st, flops, k0);
 }

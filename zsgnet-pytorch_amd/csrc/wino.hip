@@ -24,6 +24,8 @@
 #include "common.h"
 #include "bn_tail.h"
 
+ZSG_DEFINE_PRIO_FLAG()
+
 #define WN_CK 8
 
 struct WnSegDev {

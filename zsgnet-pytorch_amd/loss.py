@@ -10,36 +10,86 @@ from ._lib import lib, check, stream_ptr
 from .anchors import create_anchors
 
 
+_ONES = {}
+
+
+def _one(device) -> torch.Tensor:
+    """the constant 1.0 on `device` (never written): the default upstream gradient of a scalar loss, created once instead of by a fill
+    launch per backward — and recognisable in _LossFn.backward by its address"""
+    key = (device.type, device.index)
+    if key not in _ONES:
+        _ONES[key] = torch.ones((), device=device)
+    return _ONES[key]
+
+
+class _LossScalar(torch.Tensor):
+    """The 0-dim loss ZSGLoss returns.  The reference's trainer calls `loss.mean().backward()` on it (utils.py:412); on a 0-dim tensor
+    that is a reduce launch, a fill launch for the implicit upstream gradient and a multiply — three dependent ~6 us launches between
+    the loss kernels and the network's backward.  Here `.mean()` / `.sum()` of the scalar are the scalar itself and `.backward()`
+    passes the cached constant 1 as the upstream gradient, which _LossFn.backward recognises: the gradient the loss kernel has
+    already written into the network's incoming-gradient buffer is used as it stands — no launch at all.  Any other use (scaling the
+    loss, adding losses, an explicit gradient) takes autograd's general path."""
+
+    def mean(self, *a, **k):
+        return self if (self.dim() == 0 and not a and not k) else super().mean(*a, **k)
+
+    def sum(self, *a, **k):
+        return self if (self.dim() == 0 and not a and not k) else super().sum(*a, **k)
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if gradient is None and self.dim() == 0 and not create_graph:
+            gradient = _one(self.device)
+        return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out5, mod, annot):
         B, A, _ = out5.shape
         dev = out5.device
         losses = torch.empty(3, device=dev)
-        grad5 = torch.empty_like(out5)
+        # Where d(loss)/d(out5) goes: straight into the incoming-gradient buffer of the network plan that produced out5 (ZSGNet.forward
+        # attaches it), already scaled by 1 / world under data parallelism (the reducer SUMs) — the backward then needs no launch of
+        # its own when the upstream gradient is the constant 1.  Only the FIRST loss applied to an output may take the buffer.
+        plan = getattr(out5, "_zsg_plan", None)
+        buf = getattr(out5, "_zsg_g5", None)
+        fast = (plan is not None and buf is not None and buf.numel() == out5.numel() and buf.device == dev and not getattr(out5, "_zsg_g5_taken", False))
+        scale = 1.0
+        if fast:
+            out5._zsg_g5_taken = True
+            grad5 = buf.view_as(out5)
+            ddp = getattr(plan.net, "_ddp", None)
+            if ddp is not None and ddp.active:
+                scale = 1.0 / ddp.world
+            plan.g5_from_loss = (plan.fwd_id, scale)
+        else:
+            grad5 = torch.empty_like(out5)
         mod.match_idx = torch.empty(B, dtype=torch.int32, device=dev)
         mod.npos = torch.empty(B, dtype=torch.int32, device=dev)
         wsb = lib.zsg_loss_workspace_bytes(B, A)
         ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
         flags = (1 if mod.use_focal else 0) | (2 if mod.use_multi else 0) | (4 if mod.use_softmax else 0)
         check(lib.zsg_loss_fwd_bwd(out5.data_ptr(), annot.data_ptr(), mod.anchs.data_ptr(), B, A, mod.alpha, float(mod.gamma),
-                                   float(mod.lamb_reg), float(mod.cfg["matching_threshold"]), flags, 1.0, losses.data_ptr(),
+                                   float(mod.lamb_reg), float(mod.cfg["matching_threshold"]), flags, scale, losses.data_ptr(),
                                    grad5.data_ptr(), mod.match_idx.data_ptr(), mod.npos.data_ptr(), ws.data_ptr(), wsb,
                                    stream_ptr()), "zsg_loss_fwd_bwd")
-        ctx.save_for_backward(grad5)
-        ctx.g5_buf = getattr(out5, "_zsg_g5", None)      # the network plan's incoming-gradient buffer, when out5 came from ZSGNet
+        ctx.fast, ctx.scale, ctx.plan = fast, scale, plan
+        if fast:
+            ctx.grad5 = grad5                 # (the plan's own buffer: not a saved tensor — the plan enforces one backward per forward)
+        else:
+            ctx.save_for_backward(grad5)
         mod._last_losses = losses
         # (a view of the 3-float result, not a copy: one dependent launch less between the loss kernels and the backward)
         return losses.narrow(0, 0, 1).view(())
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fast:
+            grad5 = ctx.grad5
+            if g.data_ptr() != _one(g.device).data_ptr():      # a scaled / combined loss: one in-place multiply, as before
+                grad5.mul_(g)
+            return grad5, None, None
         (grad5,) = ctx.saved_tensors
-        buf = ctx.g5_buf
-        if buf is not None and buf.numel() == grad5.numel() and buf.device == grad5.device:
-            out = buf.view_as(grad5)             # one launch writes g * grad5 where the network's backward reads it
-            torch.mul(grad5, g, out=out)
-            return out, None, None
         return grad5 * g, None, None
 
 
@@ -71,6 +121,8 @@ class ZSGLoss(nn.Module):
             self.anchs = self.get_anchors(fs, device=out5.device)
         assert self.anchs.shape[0] == out5.shape[1], "anchor count does not match the network output"
         loss = _LossFn.apply(out5, self, annot)
+        if loss.requires_grad:
+            loss = loss.as_subclass(_LossScalar)      # (stays attached to the autograd graph; see _LossScalar)
         ls = self._last_losses
         return {"loss": loss, "cls_ls": ls[1], "box_ls": ls[2]}
 

@@ -29,7 +29,7 @@ from torch import nn
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
 from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, ensure_stream_scratch, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
-                  shared_side_stream, wino_mode, wino_ok)
+                  shared_side_stream, tile_hint, wino_mode, wino_ok)
 from .params import ParamStore, pad4, register_named
 
 VGG_BASE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]     # ssd_vgg.py:174-177
@@ -453,7 +453,8 @@ class ZSGNet(nn.Module):
         plan.expect_backward = torch.is_grad_enabled()      # (grad mode is off inside autograd.Function.forward: decide here)
         out5 = _NetFn.apply(self, plan, img, qvec, qlens, h0, c0, self._anchor)
         if plan.training:
-            out5._zsg_g5 = plan.g5_in           # where the loss may write d(loss)/d(out5) directly (loss._LossFn.backward): no copy
+            out5._zsg_g5 = plan.g5_in           # where the loss may write d(loss)/d(out5) directly (loss._LossFn.forward): no copy, no multiply
+            out5._zsg_plan = plan
         return dict(att_out=out5[..., 4:5], bbx_out=out5[..., :4], feat_sizes=plan.feat_sizes_t,
                     num_f_out=plan.num_f_out_t, att_bbx_out=out5)
 
@@ -492,6 +493,7 @@ class _Plan:
         self._out_slots_v = False
         self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
+        self.g5_from_loss = None         # (fwd_id, scale): the loss kernel wrote d(loss)/d(out5) x scale into g5_in for that forward
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
         self.bwd.side_defer = 1      # (ops.SIDE_DEFER; round 5, with the main chain at wave priority 3: 1 wins at every size)
@@ -730,7 +732,14 @@ class _Plan:
         fn = lib.zsg_conv_igemm_bnpre
         pre = (pend["mean"], pend["invstd"], pend["gam"], pend["bet"], pend["residual"].buf, src.buf, pend["rmask"])
         autotune_conv("igemm", fn, d, (x.buf, wt, out.buf, None, None, None, None, None, None, 0.1, 1e-5) + pre, stream_ptr())
-        assert d.tile_hint and ((d.tile_hint >> 16) & 0xff) <= 1, "no tile of the BatchNorm-applying loader fits this convolution"
+        h = d.tile_hint
+        admissible = (h and ((h >> 16) & 0xff) <= 1 and (h & 0xff) in (64, 128) and not (h >> 27) & 1 and not (h >> 28) & 3
+                      and not ((h & 0xffff) == 0x8080 and not (h >> 24) & 1))
+        if not admissible:
+            # no tuner (ZSG_AUTOTUNE=0, heuristic hint 0) or a cached / shipped entry the BatchNorm-applying loader has no variant for
+            # (split-K, 64-deep K tiles, stream-K, the streaming 1x1 kernel, the 4-wave 128x128 tile): the 64x64 tile always applies —
+            # lowering must not crash on a table it did not make
+            d.tile_hint = tile_hint(64, 64, 1)
         lane = 2 if pend["join"] else self._lane
         chunks = igemm_partial_rows(d)
         assert chunks * 2 * L.cout * 4 <= self.ws_bytes
@@ -1775,23 +1784,24 @@ class _Plan:
         elif do_prep:
             cuts.append((k_prep, run_prep))
         cuts.sort(key=lambda c: c[0])
+        slots, out = self._out_slots(), None
+        if slots:
+            # the [B, A, 5] output is written straight into a FRESH tensor (the launches that produce it take its address per call), so
+            # the caller owns it as with the reference's module — the copy out of the plan's static buffer (a dependent 6 us launch
+            # between the head's last convolution and the loss kernels) is gone.  The slots are patched BEFORE any launch range of this
+            # forward is replayed: they still hold the previous step's tensor, which may have been freed since.
+            out = torch.empty(B, self.A, 5, device=self.out5.buf.device, dtype=torch.float32)
+            for a in slots:
+                a.value = out.data_ptr()
         pos = 1
         for idx, action in cuts:
             if idx > pos:
                 self.fwd.run(stream_ptr(), pos, idx, join=False)
                 pos = idx
             action()
-        slots = self._out_slots()
-        if slots:
-            # the [B, A, 5] output is written straight into a FRESH tensor (the launches that produce it take its address per call), so
-            # the caller owns it as with the reference's module — the copy out of the plan's static buffer (a dependent 6 us launch
-            # between the head's last convolution and the loss kernels) is gone
-            out = torch.empty(B, self.A, 5, device=self.out5.buf.device, dtype=torch.float32)
-            for a in slots:
-                a.value = out.data_ptr()
-            self.fwd.run(stream_ptr(), pos)
-            return out
         self.fwd.run(stream_ptr(), pos)
+        if out is not None:
+            return out
         return self.out5.buf.view(B, self.A, 5).clone()
 
     def _out_slots(self):
@@ -1802,13 +1812,14 @@ class _Plan:
             return self._out_slots_v
         import ctypes as C_
         from .ops import HIP_GRAPH
-        ptr = self.out5.buf.data_ptr()
+        ptr, nbytes = self.out5.buf.data_ptr(), self.out5.buf.numel() * 4
 
         def holders(prog):
-            return [a for _, args, _ in prog.calls for a in args if isinstance(a, C_.c_void_p) and a.value == ptr]
+            # every pointer argument that points INTO the buffer; one at an offset cannot be re-based by value and disables the path
+            return [a for _, args, _ in prog.calls for a in args if isinstance(a, C_.c_void_p) and a.value is not None and ptr <= a.value < ptr + nbytes]
         mine = holders(self.fwd)
         others = sum(len(holders(pr)) for pr in (self.bwd, self.prep, self.prep_u) if pr is not None)
-        ok = bool(mine) and not others and not HIP_GRAPH and os.environ.get("ZSG_FRESH_OUT", "1") != "0"
+        ok = (bool(mine) and all(a.value == ptr for a in mine) and not others and not HIP_GRAPH and os.environ.get("ZSG_FRESH_OUT", "1") != "0")
         self._out_slots_v = mine if ok else None
         return self._out_slots_v
 
@@ -1869,7 +1880,9 @@ class _Plan:
             net._grad_reduced = True
             # average over ranks: pre-scale the incoming gradient (backward is linear), then SUM-all-reduce buckets as
             # soon as the launches that fill them are enqueued; the optimizer waits through wait_gradients().
-            self.g5_in.mul_(1.0 / ddp.world)
+            if not (g5.data_ptr() == self.g5_in.data_ptr() and self.g5_from_loss == (self.fwd_id, 1.0 / ddp.world)):
+                self.g5_in.mul_(1.0 / ddp.world)       # (the loss kernel writes the gradient pre-scaled when it can: loss._LossFn.forward)
+            self.g5_from_loss = None
             if self.reducer is None:
                 ents = net.store.entries
                 spans = [(ents[n].offset, (ents[n].size + 3) // 4 * 4, self.grad_ready.get(n, -1)) for n in net._param_names]
