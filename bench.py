@@ -180,6 +180,8 @@ def parse():
                     "legs with ONE thing changed each — the chain's wave priority off (zsg_set_main_priority(0): how do RCCL's priority-0 kernels "
                     "fare beside a priority-3 backward?) and the other transport (ZSG_COMM torch <-> native) — printed beside the default in `rccl`; "
                     "auto = whenever the run is data-parallel (N > 1 or --force-ddp)")
+    ap.add_argument("--refine", default="auto", choices=["auto", "off"], help="auto: when this process autotuned any launch shape itself, re-rank the "
+                    "tuner's near-ties inside the real step before the timed region (ZSGNet.refine_tuning; untimed, N = 1 only)")
     ap.add_argument("--launch-check", action="store_true", help="only bring up the N-rank process group (backend ZSG_DIST_BACKEND, default "
                     "nccl), all-reduce one tensor and print a JSON line: tests the launcher without a GPU (gloo)")
     return ap.parse_args()
@@ -335,6 +337,13 @@ def main():
 
     for _ in range(a.warmup):
         ls, em = step()
+    # Shapes this process had to tune itself (no stamp-matched shipped table): the tuner's near-ties are re-ranked INSIDE the step
+    # (ops.refine_in_step: both streams, real neighbours) before anything is timed — what round 5 did by hand with six fresh tunings.
+    # Untimed; single-GPU runs only (under DDP rank 0's table is broadcast before the other ranks lower).
+    if model is net and a.refine != "off" and tuning_info()["tuned_now"] > 0:
+        net.refine_tuning(batch, log=(lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("ZSG_REFINE_LOG") else None)
+        for _ in range(3):
+            ls, em = step()
 
     # Untimed settle phase AFTER the requested warm-up: the shader clock leaves its idle state and the launch queues
     # fill over the first few dozen steps (a 5-step warm-up is 70 ms of GPU work), which put the driver's 20-step mean 1.7 % above its

@@ -470,6 +470,12 @@ def test_conv_igemm_bnpre(Z, case):
             use_tail = tail and ntk > 0
             if tail and not use_tail:
                 continue
+            if (bm, bn_, w8) == (128, 128, 0):      # no BatchNorm-applying loader for the 4-wave 128x128 tile (it spilled: round 6): refused, loudly
+                rc = L.lib.zsg_conv_igemm_bnpre(C.byref(d1), xd.data_ptr(), wd.data_ptr(), o1.data_ptr(), part.data_ptr(), None, mo.data_ptr(), io.data_ptr(),
+                                                None, None, 0.1, 1e-5, md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y1.data_ptr(),
+                                                m1.data_ptr(), st)
+                assert rc == -1 and b"8-wave" in L.lib.zsg_last_error()
+                continue
             L.check(L.lib.zsg_conv_igemm_bnpre(C.byref(d1), xd.data_ptr(), wd.data_ptr(), o1.data_ptr(), part.data_ptr(),
                                                tk.data_ptr() if use_tail else None, mo.data_ptr(), io.data_ptr(), None, None, 0.1, 1e-5,
                                                md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y1.data_ptr(), m1.data_ptr(), st),

@@ -1,7 +1,10 @@
 """Developer tool (GPU box): build the shipped tuning table zsgnet-pytorch_amd/tuning/gfx950.json.
 Lowers (= autotunes, median of ZSG_TUNE_ROUNDS interleaved samples per candidate) the training and eval plans of the BASELINE.json
 configurations in a FRESH tuning state and writes every choice with the sha256 stamp of the kernel sources.
-usage: ZSG_SHIPPED_TUNE=0 python tools/make_tuning_table.py [out.json] [--seed cache.json] [configs: r50 r18 ssd r101 ...]
+usage: ZSG_SHIPPED_TUNE=0 python tools/make_tuning_table.py [out.json] [--seed cache.json] [--no-refine] [--verbose] [configs: r50 r18 ssd r101 ...]
+After the single-launch tuning of a configuration's training plan, the near-ties are re-ranked INSIDE the step (ZSGNet.refine_tuning ->
+ops.refine_in_step: both streams, the launch's real neighbours), so the table does not depend on which of two equal-looking tiles the
+single-launch median happened to prefer (round 5: 1.1 % of the step between fresh tunings).
 --seed: start from the choices of a tuning cache (ZSG_TUNE_CACHE format) instead of an empty state — tools/best_of_tunings.sh selects, among
 N complete fresh tunings of the headline configuration, the one whose STEP is fastest (the tuner ranks single launches by latency; which of
 two near-equal tiles is better inside the two-stream step it cannot see), and the table is then built around it."""
@@ -37,6 +40,11 @@ def lower(arch, B, img, backbone):
         lf(net(bt), bt)["loss"].backward()
         for p in net.parameters():
             p.grad = None
+    if "--no-refine" not in sys.argv:
+        # the tuner's near-ties re-ranked inside the real two-stream step (ops.refine_in_step) — what tools/best_of_tunings.sh +
+        # refine_tuning.py did by hand in round 5
+        res = net.refine_tuning(bt, log=(print if "--verbose" in sys.argv else None))
+        print(f"  in-step refinement: {res}", flush=True)
     net.eval()
     with torch.no_grad():
         net(bt)

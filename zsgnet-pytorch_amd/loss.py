@@ -36,6 +36,9 @@ class _LossScalar(torch.Tensor):
     def sum(self, *a, **k):
         return self if (self.dim() == 0 and not a and not k) else super().sum(*a, **k)
 
+    def __reduce_ex__(self, proto):
+        return self.as_subclass(torch.Tensor).__reduce_ex__(proto)      # (pickles / torch.save as the plain tensor it is)
+
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         if gradient is None and self.dim() == 0 and not create_graph:
             gradient = _one(self.device)

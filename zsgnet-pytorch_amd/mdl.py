@@ -28,7 +28,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import (Level, Program, TView, WinoJobs, autotune_conv, conv_out, ensure_stream_scratch, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
+from .ops import (Level, Program, TView, WinoJobs, apply_main_priority_env, autotune_conv, conv_out, ensure_stream_scratch, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
                   shared_side_stream, tile_hint, wino_mode, wino_ok)
 from .params import ParamStore, pad4, register_named
 
@@ -400,6 +400,36 @@ class ZSGNet(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     # forward / backward
     # ------------------------------------------------------------------------------------------------------
+    def refine_tuning(self, inp: Dict[str, Any], steps: int = 9, log=None) -> dict:
+        """In-step refinement of the autotuner's near-ties for the training plan of `inp`'s geometry (ops.refine_in_step): alternatives
+        the tuner timed within a few percent of its winner ALONE on the GPU are tried in the real step — forward + backward of the
+        lowered plan on both streams, a fixed incoming gradient, no optimizer — and kept when the step gets faster.  Only shapes this
+        process tuned itself have alternatives (a stamp-matched shipped table has none: nothing happens).  Not under DDP (rank 0's
+        choices are broadcast before any rank lowers, dist._sync_tuning).  Returns ops.TUNE_INFO['refined']."""
+        from . import ops as _ops
+        assert self.training, "refine_tuning measures the training step"
+        out = self(inp)                                   # lowers (and tunes) the plan if it is new
+        plan = self._plan_for(*self.plan_geometry(inp))
+        g = torch.randn(out["att_bbx_out"].shape, device=out["att_bbx_out"].device) * 1e-3
+        out["att_bbx_out"].backward(g)
+
+        def measure():
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            o = self(inp)
+            o["att_bbx_out"].backward(g)
+            ev[0].record()
+            for i in range(steps):
+                o = self(inp)
+                o["att_bbx_out"].backward(g)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            t = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+            return t[len(t) // 2]
+        res = _ops.refine_in_step(plan._tunables, measure, log=log)
+        for p in self.parameters():
+            p.grad = None
+        return res
+
     def lstm_init_hidden(self, bs: int):
         """Reference mdl.py:279-294: two CPU draws (hidden_a then hidden_b) per forward, train and eval."""
         n = 2 if self.bid else 1
@@ -483,6 +513,7 @@ class _Plan:
     def __init__(self, net: ZSGNet, B: int, H: int, W: int, T: int, training: bool):
         self.net, self.B, self.H, self.W, self.T, self.training = net, B, H, W, T, training
         self.dev = net.device
+        apply_main_priority_env()
         self.fwd = Program("fwd")
         self.prep = Program("bwd-prep")
         self._prep_stream, self._prep_ev, self._prep_fwd, self._prep_pending = None, None, -1, False
@@ -493,6 +524,7 @@ class _Plan:
         self._out_slots_v = False
         self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
+        self._tunables = []              # convolution descriptors of this plan, as lowered (ops.refine_in_step)
         self.g5_from_loss = None         # (fwd_id, scale): the loss kernel wrote d(loss)/d(out5) x scale into g5_in for that forward
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
@@ -590,6 +622,12 @@ class _Plan:
         return self.net.store.raw(name, self.net.store.grad)
 
     # ---- op lowering ---------------------------------------------------------------------------------------------
+    def _tune(self, kind, fn, d, *a, **k):
+        """autotune_conv + remember the descriptor: ops.refine_in_step may later switch its tile hint in place (ZSGNet.refine_tuning)"""
+        r = autotune_conv(kind, fn, d, *a, **k)
+        self._tunables.append(d)
+        return r
+
     def _wino_u(self, src_ptr: int, N: int, Cred: int, row_ld: int, tap_ld: int, flip: int):
         """Transformed filter image of one 3x3 convolution (+ a one-off transform so that the tuner times real data);
         the job joins the program's batched transform only if the Winograd kernel wins the tuning."""
@@ -660,7 +698,7 @@ class _Plan:
         if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
             U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
             wargs = (rd.buf, U, out.buf, bias, None, None, None)
-        autotune_conv("igemm", ig_fn, d, (rd.buf, wt, out.buf, bias, None, None, None), stream_ptr(),
+        self._tune("igemm", ig_fn, d, (rd.buf, wt, out.buf, bias, None, None, None), stream_ptr(),
                       split_penalty_ms=pen, wino_args=wargs, wino_fn=wn_fn)
         fn = ig_fn
         if d.use_wino:
@@ -731,7 +769,7 @@ class _Plan:
         x = pend["x"]
         fn = lib.zsg_conv_igemm_bnpre
         pre = (pend["mean"], pend["invstd"], pend["gam"], pend["bet"], pend["residual"].buf, src.buf, pend["rmask"])
-        autotune_conv("igemm", fn, d, (x.buf, wt, out.buf, None, None, None, None, None, None, 0.1, 1e-5) + pre, stream_ptr())
+        self._tune("igemm", fn, d, (x.buf, wt, out.buf, None, None, None, None, None, None, 0.1, 1e-5) + pre, stream_ptr())
         h = d.tile_hint
         admissible = (h and ((h >> 16) & 0xff) <= 1 and (h & 0xff) in (64, 128) and not (h >> 27) & 1 and not (h >> 28) & 3
                       and not ((h & 0xffff) == 0x8080 and not (h >> 24) & 1))
@@ -797,7 +835,7 @@ class _Plan:
         if wino_ok(L.k, L.stride, L.pad, L.dil) and not L.merge_x and wino_mode() != "0":
             U, job = self._wino_u(wt.data_ptr(), L.cout, L.cpad, L.k * L.k * L.cpad, L.cpad, 0)
             wargs = (x.buf, U) + args[2:]
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), wino_args=wargs)
+        self._tune("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), wino_args=wargs)
         if d.use_wino:
             self.wino_jobs["fwd"].add(*job)
             self.fwd.add(lib.zsg_conv_wino, d, *wargs, what=L.name + "+bn")
@@ -862,7 +900,7 @@ class _Plan:
         s0 = d.seg[0]
         wino = (d.wR == 3 and d.wS == 3 and s0.sy == 1 and s0.ty.d0 == -1 and s0.ty.dstep == 1 and not d.merge_x
                 and dy.ld % 4 == 0 and wino_mode() != "0")       # 3x3 / stride 1 / pad 1: Winograd F(3x3,2x2) candidates
-        autotune_conv("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
+        self._tune("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
         self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None, completes_bn: bool = False):
@@ -894,7 +932,7 @@ class _Plan:
             wargs = (dy.buf, U) + args[2:]
         # a split-K choice would cost the BatchNorm below its fused backward sums: a pass over dout and x plus a launch
         pen = (0.006 + 2 * dx.rows() * n * 4 / 4e9) if (completes_bn and BNB_FUSE and not d.zero_fill and mask is None) else 0.0
-        autotune_conv("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), split_penalty_ms=pen, wino_args=wargs, allow_sk=SK_BWD)
+        self._tune("igemm", lib.zsg_conv_igemm, d, args, stream_ptr(), split_penalty_ms=pen, wino_args=wargs, allow_sk=SK_BWD)
         if self._side_prep and ((d.tile_hint >> 16) & 0xff) > 1 and args[4] is None and len(dx.levels) == 1:
             # split-K into a gradient buffer nothing has written yet: its zero-fill moves to the side-stream preparation (see conv())
             lv0 = dx.levels[0]
@@ -1601,7 +1639,7 @@ class _Plan:
             if wino_mode() != "0":
                 U0, job0 = self._wino_u(self.P(W0n).data_ptr(), 256, Cf, 9 * cp, cp, 0)
                 wargs = (Fp.buf, U0) + a0[2:]
-            autotune_conv("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr(), wino_args=wargs)
+            self._tune("igemm", lib.zsg_conv_igemm, d0, a0, stream_ptr(), wino_args=wargs)
             if d0.use_wino:
                 self.wino_jobs["fwd"].add(*job0)
                 self.fwd.add(lib.zsg_conv_wino, d0, *wargs, what=L0.name)

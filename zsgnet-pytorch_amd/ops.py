@@ -254,6 +254,20 @@ SCRATCH_BYTES = (16 << 10) + 512 * 128 * 128 * 4
 _SCRATCH = {}
 
 
+_PRIO_APPLIED = set()
+
+
+def apply_main_priority_env():
+    """ZSG_MAIN_PRIO=0|3 (wave priority of the dependent chain's kernels, zsg_set_main_priority) applied to the current device, once —
+    when its first launch plan is built (nothing touches the GPU at import time: a DDP rank has not picked its device yet)."""
+    v = os.environ.get("ZSG_MAIN_PRIO")
+    dev = torch.cuda.current_device()
+    if v is None or dev in _PRIO_APPLIED:
+        return
+    _PRIO_APPLIED.add(dev)
+    check(lib.zsg_set_main_priority(int(v)), "set_main_priority")
+
+
 def ensure_stream_scratch(stream: int):
     """Register this process's scratch buffer for `stream` (a hipStream_t as an integer) with the library, once."""
     key = (torch.cuda.current_device(), int(stream or 0))
@@ -691,12 +705,19 @@ def _pick_best(trials, set_hint, stream, penalty):
                 if s_[0] > 1.25 * lead:
                     samples[i] = None
     best, best_t = 0, float("inf")
+    ranked = []
     for (f, conv, h, flag), s_ in zip(live, samples):
         if s_:
             t = sorted(s_)[len(s_) // 2]
+            ranked.append((t, h | flag))
             if t < best_t:
                 best, best_t = h | flag, t
+    _LAST_RANKING[:] = sorted(ranked)
     return best
+
+
+_LAST_RANKING = []           # [(median ms incl. penalty, hint | flag)] of the last _pick_best call, fastest first
+_TUNE_ALTS = {}              # cache key -> that ranking, for the shapes THIS process tuned: what refine_in_step() may try inside the step
 
 
 WINO_FLAG = 1 << 30          # tuner result: the Winograd kernel won (its own tile hint in the low bits)
@@ -818,6 +839,7 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
                          mode if wino_args is not None else "", deterministic(), "fp32", fn.__name__,
                          os.environ.get("ZSG_PW", "1") != "0" and not (d.merge_x and os.environ.get("ZSG_MX", "1") == "0"),
                          allow_sk and os.environ.get("ZSG_SK", "1") != "0"))
+    d._tune_key = key
     if key in _TUNE_CACHE:
         v = _TUNE_CACHE[key]
         d.tile_hint, d.use_wino = v & ~WINO_FLAG, bool(v & WINO_FLAG)
@@ -891,7 +913,106 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     best = _pick_best(trials, set_hint, stream, lambda h: split_penalty_ms if (kind == "igemm" and ((h >> 16) & 0xff) > 1) else 0.0)
     d.tile_hint, d.use_wino = best & ~WINO_FLAG, bool(best & WINO_FLAG)
     _TUNE_CACHE[key] = best
+    _TUNE_ALTS[key] = list(_LAST_RANKING)
     global _TUNE_DIRTY
     _TUNE_DIRTY = True
     TUNE_INFO["tuned_now"] += 1
     return best
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# In-step refinement of the tuner's near-ties (round 6).
+# ---------------------------------------------------------------------------------------------------------------------
+# The tuner above ranks the candidates of ONE launch by their latency alone on the GPU.  Inside the step a launch runs between its real
+# neighbours, beside the other stream's kernels: round 5 found ONE entry — the head's Winograd data gradient, two position groups
+# against four — that ties in isolation and is worth 0.11 ms of the 13.2 ms step (the shipped table had to be seeded by hand from the best
+# of six fresh tunings); round 6 found the stream-K data gradients, faster alone and slower in the step.  refine_in_step() closes that
+# loop without a hand: for every tuned shape whose runner-up candidates lie within REFINE_WINDOW of the winner AND can replace it in the
+# lowered plan as it stands (same kernel family, same partial-row / ticket counts — only the tile hint changes, in place), the
+# alternative is run in the REAL step (forward + backward of the plan, both streams, a fixed incoming gradient) and kept when the step
+# gets faster by more than the measurement noise, twice.
+REFINE_WINDOW = float(os.environ.get("ZSG_REFINE_WINDOW", "1.08"))           # runner-ups within this factor of the winner's isolated time ...
+REFINE_WINDOW_WAVES = float(os.environ.get("ZSG_REFINE_WINDOW_WAVES", "1.30"))   # ... a wider one for the SAME tile with the other wave count
+REFINE_NOISE = float(os.environ.get("ZSG_REFINE_NOISE", "0.003"))        # fraction of the measured step a change has to beat, twice
+
+
+def hint_compatible(d: ConvDesc, kind: str, cur: int, alt: int) -> bool:
+    """May `alt` (hint | WINO_FLAG) replace `cur` in an already lowered launch of descriptor d?  Only what leaves every buffer size and
+    every sibling launch of the plan untouched: the same kernel family, no split-K on either side (zero fills, lost epilogue fusions),
+    the same number of BatchNorm partial rows and of in-kernel-finalize tickets."""
+    if (cur ^ alt) & WINO_FLAG:
+        return False
+    hc, ha = cur & ~WINO_FLAG, alt & ~WINO_FLAG
+    if kind == "wgrad":
+        return True                      # (slabs live in the one shared workspace the candidates were sized for)
+    if ((hc >> 16) & 0xff) > 1 or ((ha >> 16) & 0xff) > 1:
+        return False
+    keep = d.tile_hint
+    try:
+        if cur & WINO_FLAG:
+            if (hc & 0xff) != (ha & 0xff):
+                return False
+            d.tile_hint = hc
+            tc = lib.zsg_conv_bn_tail_tickets(C.byref(d), 1)
+            d.tile_hint = ha
+            return tc == lib.zsg_conv_bn_tail_tickets(C.byref(d), 1)
+        d.tile_hint = hc
+        rc, tc = lib.zsg_conv_igemm_partial_rows(C.byref(d)), lib.zsg_conv_bn_tail_tickets(C.byref(d), 0)
+        d.tile_hint = ha
+        return rc == lib.zsg_conv_igemm_partial_rows(C.byref(d)) and tc == lib.zsg_conv_bn_tail_tickets(C.byref(d), 0)
+    finally:
+        d.tile_hint = keep
+
+
+def refine_in_step(descs: Sequence[ConvDesc], measure, log=None, max_alts: int = 3) -> dict:
+    """descs: the convolution descriptors of a lowered plan (each carries _tune_key from autotune_conv; launches that share a key are
+    switched together).  measure() -> milliseconds of the real step (median of a few replays).  An alternative is tried when the tuner
+    timed it within REFINE_WINDOW of the current choice alone on the GPU — or within REFINE_WINDOW_WAVES when it is the same tile with
+    the other wave count (tile_hint bit 24: 8-wave workgroups / four Winograd position groups): those change how a launch shares a CU
+    with the other stream's blocks, which a single-launch timing cannot see (round 5: the head's data gradient, 15 % slower alone with
+    four groups, 0.11 ms faster in the step).  It is kept when it beats the incumbent by more than REFINE_NOISE in two measurements
+    that bracket a fresh measurement of the incumbent (clock drift cannot fake a win).  The winning choices go into the tuning cache
+    (and from there into ZSG_TUNE_CACHE / the shipped table)."""
+    global _TUNE_DIRTY
+    groups = {}
+    for d in descs:
+        k = getattr(d, "_tune_key", None)
+        if k is not None and k in _TUNE_ALTS:
+            groups.setdefault(k, []).append(d)
+    base = min(measure(), measure())
+    t_start, tried, kept = base, 0, 0
+
+    def put(ds, h):
+        for d in ds:
+            d.tile_hint = h & ~WINO_FLAG
+    for key, ds in groups.items():
+        rank, cur, kind = _TUNE_ALTS[key], _TUNE_CACHE[key], key[0]
+        t_cur = next((t for t, h in rank if h == cur), rank[0][0])
+        alts = []
+        for t, h in rank:
+            if h == cur:
+                continue
+            waves_only = ((h ^ cur) & ~(1 << 24)) == 0
+            if t <= (REFINE_WINDOW_WAVES if waves_only else REFINE_WINDOW) * t_cur and all(hint_compatible(d, kind, cur, h) for d in ds):
+                alts.append(h)
+        for alt in alts[:max_alts]:
+            put(ds, alt)
+            t = measure()
+            tried += 1
+            verdict = ""
+            if t < base * (1 - REFINE_NOISE):
+                put(ds, cur)
+                b2 = measure()                      # the incumbent again, now: drift cannot fake a win
+                put(ds, alt)
+                t2 = measure()
+                if max(t, t2) < min(base, b2) * (1 - REFINE_NOISE / 2):
+                    cur, base, kept, verdict = alt, (t + t2) / 2, kept + 1, " -> kept"
+                    _TUNE_CACHE[key] = alt
+                    _TUNE_DIRTY = True
+                else:
+                    base, verdict = (base + b2) / 2, f" (incumbent again {b2:.3f}, alternative again {t2:.3f}: not kept)"
+            if log:
+                log(f"refine {kind} {str(key[1:5])} {hex(alt)}: {t:.3f} ms vs {base:.3f}{verdict}")
+            put(ds, cur)
+    TUNE_INFO["refined"] = {"shapes": len(groups), "tried": tried, "kept": kept, "ms_before": round(t_start, 4), "ms_after": round(base, 4)}
+    return TUNE_INFO["refined"]
