@@ -92,6 +92,10 @@ typedef struct {
                            * 256 x that many workgroups share the (tile, K step) units evenly, cut tiles are completed in a fixed
                            * order (deterministic; needs zsg_set_stream_workspace, fewer tiles than workgroups, one segment,
                            * split_k <= 1)                                                                                    */
+    int32_t epi_flags;    /* bit 0, BatchNorm-backward epilogues only (zsg_conv_*_bnb, *_bnb_tail): STORE the ReLU-masked gradient
+                           * g = (acc [+ add_src]) * relu-bit instead of the unmasked sum — the stored dout is then at once the
+                           * residual branch's gradient (autograd's ReLU backward of `out = relu(bn3(x) + residual)`,
+                           * fpn_resnet.py:96-100), and the BatchNorm's apply pass needs neither the mask nor a second output     */
     zsg_seg seg[ZSG_MAX_SEG];
 } zsg_conv_desc;
 

@@ -112,6 +112,16 @@ def test_dgrad_with_bn_backward_sums(Z, case):
     L.check(fn_bnb(C.byref(d1), dyd.data_ptr(), wop.data_ptr(), dx1.data_ptr(), dx1.data_ptr() if acc else None, xd.data_ptr(), md.data_ptr(),
                    isd.data_ptr(), maskb.data_ptr() if use_mask else None, part.data_ptr(), st), "dgrad + bn-backward sums")
     assert torch.equal(dx0, dx1), "the fused launch must store exactly what the plain launch stores"
+    # round 6: epi_flags bit 0 — the same launch STORES the ReLU-masked gradient (the residual branch's gradient); same partial rows
+    if use_mask:
+        dxm = fresh()
+        dm = ops.dgrad_desc(dyv, view_of(ops, dxm, B, H, W, Ci), Cop, Ci, k, s, p, 1, tile_hint=hint)
+        dm.epi_flags = 1
+        partm = torch.full((chunks, 2, Ci), float("nan"), device="cuda")
+        L.check(fn_bnb(C.byref(dm), dyd.data_ptr(), wop.data_ptr(), dxm.data_ptr(), dxm.data_ptr() if acc else None, xd.data_ptr(), md.data_ptr(),
+                       isd.data_ptr(), maskb.data_ptr(), partm.data_ptr(), st), "dgrad + bn-backward sums, masked store")
+        assert torch.equal(dxm.cpu(), dx1.cpu() * bits.float()), "epi_flags bit 0: stored dout = dout x ReLU bit, bit for bit"
+        assert torch.equal(partm, part), "masked store: the partial rows are those of the unmasked launch"
     assert float((dx1.double().cpu() - dxr).abs().max()) < 2e-4 * float(dxr.abs().max())
     s1, s2 = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
     assert not torch.isnan(part).any()

@@ -19,13 +19,13 @@ if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 
-DEFAULTS = {"igemm_kernel": [None] * 4 + ["1", "32"], "wino_kernel": [None] * 3, "wgrad_kernel": [None] * 5 + ["true"]}
+DEFAULTS = {"igemm_kernel": [None] * 4 + ["1"], "wino_kernel": [None] * 3, "wgrad_kernel": [None] * 5 + ["true"]}
 
 
 def klass(name):
     """the kernel name as libzsg's event profiler reports it — 'igemm_kernel<64, 64, 4, false, 2>', 'wino_kernel<2, 2, 4>',
     'wgrad_kernel<2, 1, 16, 2, 4>': rocprofv3 prints every template argument, libzsg leaves trailing defaults out and writes the
-    64-deep-K variant as a '+k64' suffix"""
+    variants as suffixes: '+pre' (BatchNorm-applying loader), '+sk' (stream-K), '+k64' (64-deep K tile)"""
     name = name.replace("void ", "").split("(")[0]
     if name.startswith("wgrad_reduce"):
         return "wgrad_reduce_kernel"
@@ -34,8 +34,14 @@ def klass(name):
         args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
         suffix = ""
         if base == "igemm_kernel" and len(args) >= 6:
-            suffix = "+k64" if args[5] == "64" else ""
-            args[5] = "32"
+            # <BM, BN, NW, MERGE_X, KS, BK, PRE, SK>
+            pre = len(args) > 6 and args[6] == "true"
+            sk = len(args) > 7 and args[7] == "true"
+            suffix = ("+pre" if pre else "") + ("+sk" if sk else "") + ("+k64" if args[5] == "64" else "")
+            args = args[:5]
+        if base == "wino_kernel" and len(args) >= 4:
+            suffix = "+sk" if args[3] == "true" else ""
+            args = args[:3]
         dflt = DEFAULTS[base]
         while len(args) > 1 and len(args) <= len(dflt) and dflt[len(args) - 1] is not None and args[-1] == dflt[len(args) - 1]:
             args.pop()

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("N", C.c_int32), ("src_ld", C.c_int32), ("out_ld", C.c_int32),
                 ("wR", C.c_int32), ("wS", C.c_int32), ("wC", C.c_int32), ("wc0", C.c_int32), ("wt_ld", C.c_int32),
                 ("relu", C.c_int32), ("merge_x", C.c_int32), ("nseg", C.c_int32), ("tile_hint", C.c_int32),
-                ("seg", Seg * ZSG_MAX_SEG)]
+                ("epi_flags", C.c_int32), ("seg", Seg * ZSG_MAX_SEG)]
 
 
 class ProfEntry(C.Structure):

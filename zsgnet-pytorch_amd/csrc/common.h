@@ -20,6 +20,7 @@ struct BnbDev {
     const float* mean;
     const float* invstd;
     const unsigned char* mask;    // 4 ReLU bits per 16-byte group (bn_apply's relu_mask) or nullptr
+    int store_masked;             // zsg_conv_desc.epi_flags bit 0: the STORED value is the masked gradient g (round 6)
 };
 
 // pw.hip: the filter-resident streaming kernel behind zsg_conv_igemm's tile_hint BM = 32 (uw = the hint's BN field)

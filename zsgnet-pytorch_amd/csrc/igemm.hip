@@ -604,10 +604,10 @@ void igemm_kernel(const IgParams p) {
                     if (ro < 0) continue;
                     f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
                     if (p.add_src) v += apre[i];
-                    apre[i] = v;
                     f32x4 g = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = ((mpre[i] >> e) & 1u) ? g[e] : 0.f;
+                    apre[i] = p.bnb.store_masked ? g : v;
                     q1 += g;
                     q2 += g * ((xpre[i] - mu) * is);
                 }
@@ -906,6 +906,7 @@ static int conv_igemm_impl(const zsg_conv_desc* d, const float* src, const float
                     "conv_igemm_bnb: needs an unsplit, bias-free convolution with 16-byte addressable output rows");
         ZSG_REQUIRE((((uintptr_t)bnb->x | (uintptr_t)bnb->mean | (uintptr_t)bnb->invstd) & 15) == 0, "conv_igemm_bnb: operands not 16-byte aligned");
         p.bnb = *bnb;
+        p.bnb.store_masked = d->epi_flags & 1;
     } else if (bn_partials) {
         ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu, "conv_igemm: BN-statistics fusion needs a plain (bias-free, unsplit) convolution");
     }

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void pw_kernel(const PwParams p) {
                         // a dead column's sums are never written out)
                         s1[jp] += g;
                         s2[jp] += g * ((xb[i] - mu) * is);
+                        if (p.bnb.store_masked) v[i] = g;      // (wave-uniform: the stored dout is the masked gradient)
                     }
                 } else {
                     if (MODE == 0 && p.stats) {          // (plain convolution: the host excludes bias / add / ReLU here)
@@ -516,6 +517,7 @@ int zsg_conv_pw_launch(const zsg_conv_desc* d, int uw_hint, const float* src, co
         ZSG_REQUIRE(bn_partials && bnb->x && bnb->mean && bnb->invstd && !bias && !d->relu && !mask_src, "conv_igemm_bnb: bad argument");
         ZSG_REQUIRE((((uintptr_t)bnb->x | (uintptr_t)bnb->mean | (uintptr_t)bnb->invstd) & 15) == 0, "conv_igemm_bnb: operands not 16-byte aligned");
         p.bnb = *bnb;
+        p.bnb.store_masked = d->epi_flags & 1;
     } else if (bn_partials) {
         ZSG_REQUIRE(!bias && !add_src && !d->relu && !mask_src, "conv_igemm: BN-statistics fusion needs a plain (bias-free) convolution");
     }

@@ -470,10 +470,10 @@ __global__ __launch_bounds__(64 * PS * TM * TN, 2) void wino_kernel(const WnPara
                     if (dead) continue;
                     f32x4 v = *(const f32x4*)(ct + row * LDC + 4 * cg);
                     if (p.add_src) v += apre[i];
-                    apre[i] = v;
                     f32x4 g = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = ((mpre[i] >> e) & 1u) ? g[e] : 0.f;
+                    apre[i] = p.bnb.store_masked ? g : v;
                     s1 += g;
                     s2 += g * ((xpre[i] - mu) * is);
                 }
@@ -752,6 +752,7 @@ static int conv_wino_impl(const zsg_conv_desc* d, const float* src, const float*
         ZSG_REQUIRE(splits == 1 && p.vec && !bias && !d->relu && !mask_src, "conv_wino_bnb: needs an unsplit, bias-free convolution with 16-byte addressable output rows");
         ZSG_REQUIRE((((uintptr_t)bnb->x | (uintptr_t)bnb->mean | (uintptr_t)bnb->invstd) & 15) == 0, "conv_wino_bnb: operands not 16-byte aligned");
         p.bnb = *bnb;
+        p.bnb.store_masked = d->epi_flags & 1;
     } else if (bn_partials) {
         ZSG_REQUIRE(splits == 1 && !bias && !add_src && !d->relu && p.vec, "conv_wino: BN-statistics fusion needs a plain (bias-free, unsplit, 16-byte addressable) convolution");
     }

@@ -77,6 +77,7 @@ FPN_ORDER_DEFAULT = "p6m"
 BN_PRE_MIN_MB = float(os.environ.get("ZSG_BN_PRE_MIN_MB", "40"))
 STAGE_INPUTS = os.environ.get("ZSG_STAGE_INPUTS", "1") != "0"      # (A/B: 0 = the separate torch copies of rounds 1-4)
 BN_TAIL = os.environ.get("ZSG_BN_TAIL", "1")
+MASKED_DOUT = os.environ.get("ZSG_MASKED_DOUT", "1") != "0"      # the completing data gradient stores the ReLU-masked dout = the residual's gradient (bn(): back)
 SK_BWD = os.environ.get("ZSG_SK_BWD", "0") != "0"      # stream-K candidates also for the backward's data gradients (measured slower: ops.autotune_conv)
 BN_TAIL_MIN_ROWS = int(os.environ.get("ZSG_BN_TAIL_MIN_ROWS", "0"))      # (A/B: only launches with more partial rows than this finalise in-kernel)
 def prep_at() -> str:
@@ -991,12 +992,6 @@ class _Plan:
             if out.grad is None:
                 return
             dx = self.grad_of(x)
-            g_out = None
-            if residual is not None and residual.requires_grad:
-                rg = self.grad_of(residual)
-                assert not rg.gfilled, "residual gradient must be produced first (tape order)"
-                g_out = rg.buf
-                rg.gfilled = True
             lw = getattr(out.grad, "last_writer", None)
             fuse = (BNB_FUSE and lw is not None and lw[0] == len(self.bwd.calls) - 1 and self.bwd.lanes[lw[0]] == 0
                     and len(out.grad.levels) == 1 and out.grad.levels[0].off == 0 and x.levels[0].off == 0 and out.grad.ld == L.c and x.ld == L.c)
@@ -1009,6 +1004,23 @@ class _Plan:
                 else:
                     chunks = igemm_partial_rows(d)
                 fuse = chunks * 2 * L.c * 4 + 2 * L.c * 4 <= self.ws_bytes
+            g_out, bits = None, rmask
+            if residual is not None and residual.requires_grad:
+                # Round 6: where the data gradient that completes dout carries this BatchNorm's backward sums anyway, it also STORES the
+                # ReLU-masked gradient (zsg_conv_desc.epi_flags bit 0) — which IS the residual branch's gradient (out = relu(bn(x) +
+                # residual)): the residual's gradient buffer becomes an alias of dout, and the apply pass below neither reads the mask nor
+                # writes a second output (16 -> 12 bytes per element on the step's sixteen bn3 passes, 645 MB per step at configs[1]).
+                alias = (fuse and MASKED_DOUT and relu and rmask is not None and residual.grad is None and len(residual.levels) == 1
+                         and residual.levels[0].off == 0 and residual.ld == L.c and residual.C == L.c and residual.buf.numel() == out.grad.buf.numel())
+                if alias:
+                    residual.grad = out.grad
+                    lw[1].epi_flags |= 1
+                    bits = None
+                else:
+                    rg = self.grad_of(residual)
+                    assert not rg.gfilled, "residual gradient must be produced first (tape order)"
+                    g_out = rg.buf
+                    rg.gfilled = True
             if fuse:
                 part = self.ws[2 * L.c:]              # (the first 2C floats of the workspace: the finalize launch's coefficients)
                 # a = (src, wt|U, out, bias=None, add_src, mask=None, partials=None)
@@ -1022,12 +1034,12 @@ class _Plan:
                     coef = self._buf(2 * L.c)
                     self.bwd.calls[idx] = (fn, marshal(fn, (d, a[0], a[1], a[2], a[4], x.buf, mean, invstd, rmask, part, tk, coef,
                                                             self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1), self.bwd.keep), what + "+bnb+fin")
-                    self.bwd.add(lib.zsg_bn_bwd_apply, self.base(out.grad), rmask, x.buf, rows, L.c, mean, invstd, gam, coef, dx.buf, g_out,
+                    self.bwd.add(lib.zsg_bn_bwd_apply, self.base(out.grad), bits, x.buf, rows, L.c, mean, invstd, gam, coef, dx.buf, g_out,
                                  what="bnbwd:" + L.name)
                 else:
                     fn = lib.zsg_conv_wino_bnb if d.use_wino else lib.zsg_conv_igemm_bnb
                     self.bwd.calls[idx] = (fn, marshal(fn, (d, a[0], a[1], a[2], a[4], x.buf, mean, invstd, rmask, part), self.bwd.keep), what + "+bnb")
-                    self.bwd.add(lib.zsg_bn_backward_from_partials, self.base(out.grad), rmask, x.buf, rows, L.c, mean, invstd, gam,
+                    self.bwd.add(lib.zsg_bn_backward_from_partials, self.base(out.grad), bits, x.buf, rows, L.c, mean, invstd, gam,
                                  dx.buf, g_out, self.G(L.name + ".weight"), self.G(L.name + ".bias"), 1, part, chunks, self.ws, self.ws_bytes,
                                  what="bnbwd:" + L.name)
             else:

@@ -737,8 +737,8 @@ def sk_cands(d: ConvDesc, rows: int) -> list:
     """Stream-K candidates of an implicit-GEMM launch whose tile grid is below one round of (256 x workgroups-per-CU) workgroups —
     layer3 / layer4's 1x1 convolutions, the strided 3x3 ones, the small pyramid levels.  The library refuses what it cannot run
     (more tiles than workgroups, several segments): a refused candidate is simply not timed."""
-    if d.nseg != 1 or d.merge_x or os.environ.get("ZSG_SK", "1") == "0":
-        return []
+    if d.nseg != 1 or d.merge_x or os.environ.get("ZSG_SK", "1") == "0" or HIP_GRAPH:
+        return []          # (hipGraph replay, opt-in: a captured range runs on the capture stream, which has no registered scratch)
     out = []
     for bm, bn, w8, k64 in ((64, 64, 0, 0), (64, 64, 1, 0), (64, 64, 1, 1), (128, 64, 1, 0), (128, 128, 1, 0), (128, 128, 0, 0)):
         if (bn == 128 and d.N <= 64) or (k64 and d.C % 64):
@@ -761,7 +761,7 @@ def _wino_cands(d: ConvDesc, allow_sk: bool = True) -> list:
     # (tiles per block, channels per block, split-K, four position groups instead of two = twice the waves per SIMD)
     cands = [tile_hint(64, 64, 1), tile_hint(32, 64, 1), tile_hint(64, 64, 1, 1), tile_hint(32, 64, 1, 1), tile_hint(32, 32, 1, 1)]
     # stream-K (csrc/wino.hip, template flag SK): the 32 x 64 four-group tile over 256 workgroups, for grids below one round
-    if allow_sk and d.nseg == 1 and ((tiles + 31) // 32) * ((d.N + 63) // 64) <= 256 and os.environ.get("ZSG_SK", "1") != "0":
+    if allow_sk and d.nseg == 1 and ((tiles + 31) // 32) * ((d.N + 63) // 64) <= 256 and os.environ.get("ZSG_SK", "1") != "0" and not HIP_GRAPH:
         cands.append(tile_hint(32, 64, 1, 1) | (1 << SK_SHIFT))
     s0 = d.seg[0]
     dense = (d.nseg == 1 and not d.relu and d.out_ld == d.N and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
