@@ -24,8 +24,16 @@ plan = next(iter(net._plans.values())) if hasattr(net, "_plans") else None
 if plan is None:
     plan = [v for v in vars(net).values() if isinstance(v, dict) and v and hasattr(next(iter(v.values())), "bwd")][0]
     plan = next(iter(plan.values()))
-for which in (sys.argv[1:] or ["bwd"]):
+for which in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["bwd"]):
     prog = getattr(plan, which)
     print(f"== {which}: {len(prog)} launches, wait_idx={getattr(plan, '_wait_idx', None)}")
     for i, ((fn, args, what), lane) in enumerate(zip(prog.calls, prog.lanes)):
         print(f"{i:4d} L{lane} {fn.__name__:34s} {what}")
+    if which == "bwd" and "--sched" in sys.argv:
+        ops, nev, busy = prog._schedule(0, len(prog), False, False)
+        print("== schedule ops with cross-stream edges")
+        for op in ops:
+            if op[0] in ("m", "s"):
+                print(f"  {op[0]} {op[1]:4d} ev{op[2]:3d} {prog.calls[op[1]][2]}")
+            else:
+                print(f"  {op[0]} ev{op[1]}")
