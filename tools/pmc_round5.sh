@@ -3,8 +3,8 @@
 # tuning table and replays ONE of its launches 8 times; the counters below are those of the LAST 8 dispatches of the named kernel —
 # the plan's own descriptor, tile hint and fused epilogue (the hint is printed beside each entry).  rocprofv3 --pmc, counters only,
 # separate passes; FETCH_SIZE x 2 per the guide (gfx950 reports half of wide streaming reads).
-# usage (GPU box): bash tools/pmc_round5.sh  -> gpurun_out/pmc_r05/{counters.json,summary.txt} (copy to profiles/r05_pmc/)
-R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/pmc_r05; mkdir -p $OUT
+# usage (GPU box): bash tools/pmc_round5.sh  -> gpurun_out/pmc_${PMC_TAG:-r05}/{counters.json,summary.txt} (copy to profiles/<tag>_pmc/; round 6: PMC_TAG=r06)
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/pmc_${PMC_TAG:-r05}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # tag program pattern kernel-substring
   tag=$1; prog=$2; pat=$3; kern=$4
@@ -35,4 +35,11 @@ run bn_apply_l1bn3           fwd "backbone.encoder.layer1.1.bn3"           "bn_a
 run bn_apply_l3bn2           fwd "backbone.encoder.layer3.1.bn2"           "bn_apply_kernel"
 run bn_bwd_apply_l1bn3       bwd "bnbwd:backbone.encoder.layer1.1.bn3"     "bn_bwd_apply_kernel"
 run bn_bwd_apply_l3bn2       bwd "bnbwd:backbone.encoder.layer3.1.bn2"     "bn_bwd_apply_kernel"
+# round 6: the launches that changed — stream-K forward candidates (whatever the table picked: the hint is printed), the data gradient that
+# stores the masked dout, and the apply pass behind it (no mask read, one output)
+run igemm_l4conv1_fwd        fwd "backbone.encoder.layer4.1.conv1"         "igemm_kernel"
+run igemm_P5_1_fwd           fwd "backbone.fpn.P5_1"                       "igemm_kernel"
+run wino_l4conv2_fwd         fwd "backbone.encoder.layer4.1.conv2"         "wino_kernel"
+run igemm_l2conv1_dgrad_mask bwd "dgrad:backbone.encoder.layer2.2.conv1"   "igemm_kernel"
+run bn_bwd_apply_l2bn3       bwd "bnbwd:backbone.encoder.layer2.1.bn3"     "bn_bwd_apply_kernel"
 cd $R && python tools/pmc_summarize.py $OUT 8 | tee $OUT/summary.txt
