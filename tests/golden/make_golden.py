@@ -155,7 +155,7 @@ def gen_resize(cfg):
     save("g14_resize", **d)
 
 
-def gen_learnable(R, S=128, B=16, steps=240, lr=1e-3, decay_at=200):
+def gen_learnable(R, S=128, B=16, steps=320, lr=5e-4, decay_at=260):
     """G15: the Acc@IoU0.5 proxy's REFERENCE side.  The reference network (mdl.py get_default_net), loss (loss.py) and evaluator
     (evaluator.py) trained on the CPU with torch.optim.Adam(betas=(0.9, 0.99)) (main_dist.py:50) on a task it can learn —
     O.learnable_batch: the annotated box is a bright rectangle — from a seeded start, a fresh batch and fresh LSTM start states

@@ -5,9 +5,8 @@ usage: ZSG_SHIPPED_TUNE=0 python tools/make_tuning_table.py [out.json] [--seed c
 After the single-launch tuning of a configuration's training plan, the near-ties are re-ranked INSIDE the step (ZSGNet.refine_tuning ->
 ops.refine_in_step: both streams, the launch's real neighbours), so the table does not depend on which of two equal-looking tiles the
 single-launch median happened to prefer (round 5: 1.1 % of the step between fresh tunings).
---seed: start from the choices of a tuning cache (ZSG_TUNE_CACHE format) instead of an empty state — tools/best_of_tunings.sh selects, among
-N complete fresh tunings of the headline configuration, the one whose STEP is fastest (the tuner ranks single launches by latency; which of
-two near-equal tiles is better inside the two-stream step it cannot see), and the table is then built around it."""
+--seed: start from the choices of a tuning cache (ZSG_TUNE_CACHE format) instead of an empty state (a development aid: round 5 seeded the
+table by hand from the fastest of six fresh tunings; the in-step refinement replaced that procedure)."""
 import json
 import os
 import sys

@@ -716,6 +716,41 @@ def _pick_best(trials, set_hint, stream, penalty):
     return best
 
 
+def _verify_candidates(kind, key, trials, set_hint, out, add_src, stream):
+    """ZSG_TUNE_VERIFY=1 (developer check; a candidate that computes something else than its siblings is a bug the timing cannot see):
+    every candidate of the launch is run once from the SAME state of the output buffer (split-K candidates of a non-accumulating launch
+    from zeros, as the plan's prepared launch would) and its stored output compared with the first candidate's: fp32 summation-order
+    differences only (2e-3 of the largest magnitude).  Prints one line per outlier and keeps a count in TUNE_INFO['verify_bad']."""
+    if not isinstance(out, torch.Tensor):
+        return
+    st = C.c_void_p(stream)
+    snap = out.clone()
+    accumulate = add_src is not None and isinstance(add_src, torch.Tensor) and add_src.data_ptr() == out.data_ptr()
+    ref, ref_h = None, 0
+    for f, conv, h, flag in trials:
+        set_hint(h)
+        out.copy_(snap)
+        if kind == "igemm" and ((h >> 16) & 0xff) > 1 and not accumulate:
+            out.zero_()
+        if f(*conv, st):
+            continue
+        torch.cuda.synchronize()
+        res = out.clone()
+        if kind == "igemm" and ((h >> 16) & 0xff) > 1 and not accumulate:
+            res = torch.where(res == 0, snap, res) if ref is None else torch.where(res == 0, ref, res)      # (elements outside the launch's region)
+        if ref is None:
+            ref, ref_h = res, h | flag
+            continue
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((res - ref).abs().max())
+        bad = not (err <= 2e-3 * scale) or bool(torch.isnan(res).any()) != bool(torch.isnan(ref).any())
+        TUNE_INFO["verify_n"] = TUNE_INFO.get("verify_n", 0) + 1
+        if bad:
+            TUNE_INFO["verify_bad"] = TUNE_INFO.get("verify_bad", 0) + 1
+            print(f"[zsg tune-verify] {kind} {key[1:6]} hint {hex(h | flag)} vs {hex(ref_h)}: max |diff| {err:.3e} (scale {scale:.3e})", flush=True)
+    out.copy_(snap)
+
+
 _LAST_RANKING = []           # [(median ms incl. penalty, hint | flag)] of the last _pick_best call, fastest first
 _TUNE_ALTS = {}              # cache key -> that ranking, for the shapes THIS process tuned: what refine_in_step() may try inside the step
 
@@ -737,7 +772,7 @@ def sk_cands(d: ConvDesc, rows: int) -> list:
     """Stream-K candidates of an implicit-GEMM launch whose tile grid is below one round of (256 x workgroups-per-CU) workgroups —
     layer3 / layer4's 1x1 convolutions, the strided 3x3 ones, the small pyramid levels.  The library refuses what it cannot run
     (more tiles than workgroups, several segments): a refused candidate is simply not timed."""
-    if d.nseg != 1 or d.merge_x or os.environ.get("ZSG_SK", "1") == "0" or HIP_GRAPH:
+    if d.nseg != 1 or d.merge_x or os.environ.get("ZSG_SK", "1") == "0" or os.environ.get("ZSG_SK_IGEMM", "1") == "0" or HIP_GRAPH:
         return []          # (hipGraph replay, opt-in: a captured range runs on the capture stream, which has no registered scratch)
     out = []
     for bm, bn, w8, k64 in ((64, 64, 0, 0), (64, 64, 1, 0), (64, 64, 1, 1), (128, 64, 1, 0), (128, 128, 1, 0), (128, 128, 0, 0)):
@@ -761,7 +796,7 @@ def _wino_cands(d: ConvDesc, allow_sk: bool = True) -> list:
     # (tiles per block, channels per block, split-K, four position groups instead of two = twice the waves per SIMD)
     cands = [tile_hint(64, 64, 1), tile_hint(32, 64, 1), tile_hint(64, 64, 1, 1), tile_hint(32, 64, 1, 1), tile_hint(32, 32, 1, 1)]
     # stream-K (csrc/wino.hip, template flag SK): the 32 x 64 four-group tile over 256 workgroups, for grids below one round
-    if allow_sk and d.nseg == 1 and ((tiles + 31) // 32) * ((d.N + 63) // 64) <= 256 and os.environ.get("ZSG_SK", "1") != "0" and not HIP_GRAPH:
+    if allow_sk and d.nseg == 1 and ((tiles + 31) // 32) * ((d.N + 63) // 64) <= 256 and os.environ.get("ZSG_SK", "1") != "0" and os.environ.get("ZSG_SK_WINO", "1") != "0" and not HIP_GRAPH:
         cands.append(tile_hint(32, 64, 1, 1) | (1 << SK_SHIFT))
     s0 = d.seg[0]
     dense = (d.nseg == 1 and not d.relu and d.out_ld == d.N and s0.out_bstride == s0.rows_y * s0.rows_x * d.N)
@@ -911,6 +946,8 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
         d.tile_hint = h
 
     best = _pick_best(trials, set_hint, stream, lambda h: split_penalty_ms if (kind == "igemm" and ((h >> 16) & 0xff) > 1) else 0.0)
+    if os.environ.get("ZSG_TUNE_VERIFY") and fn in (lib.zsg_conv_igemm, lib.zsg_conv_wgrad):
+        _verify_candidates(kind, key, trials, set_hint, args[2], args[4] if kind == "igemm" else None, stream)
     d.tile_hint, d.use_wino = best & ~WINO_FLAG, bool(best & WINO_FLAG)
     _TUNE_CACHE[key] = best
     _TUNE_ALTS[key] = list(_LAST_RANKING)
