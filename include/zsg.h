@@ -205,6 +205,13 @@ int zsg_wino_weights(const void* jobs, int32_t njobs, int32_t total_blocks, void
 size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d);
 int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                         size_t ws_bytes, void* stream);
+/* Round 6: njobs (<= 8) convolutions of ONE geometry in one launch — job j: (src[j], dy[j]) -> dw[j]; the pointer arrays are HOST arrays
+ * (read at the call).  The identical bottlenecks of a ResNet stage (/root/reference/code/fpn_resnet.py:86-100: layerN.1 .. layerN.k conv2;
+ * autograd's weight gradient of each) are leaves of the backward graph: released together they are njobs x the (n, c) blocks at a
+ * fraction of the split-K slabs.  Workspace: njobs x zsg_conv_wgrad_wino_workspace_bytes(d) is always enough; tile_hint as above
+ * (the split-K factor is per job). */
+int zsg_conv_wgrad_wino_batched(const zsg_conv_desc* d, int32_t njobs, const float* const* src, const float* const* dy, float* const* dw,
+                                int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* dst[c][t][n] = src[n][t][c]  (OHWI -> IHWO, the dgrad weight image); T = R*S; dst rows are dst_ld >= N wide
  * (columns N..dst_ld-1 are zeroed: the 45-channel head output is handled as a 48-channel GEMM operand). */

@@ -198,3 +198,60 @@ def test_dgrad_with_bn_backward_sums(Z, case):
             assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5 * float(b_.abs().max())), what
     side.synchronize()
     assert float((outs[1][3].double() - 1 - dbeta_ref).abs().max()) < 1e-4 * sc1 + 1e-5
+
+
+def test_batched_weight_gradients_in_the_plan(monkeypatch):
+    """_Plan._batch_wgrads (round 6): with ZSG_WG_BATCH the Winograd weight gradients of a stage's identical bottlenecks are ONE launch
+    at the last one's position — every gradient of the network as without batching (fp32 split-K order only), fewer launches, and the
+    launch index each parameter's gradient is complete at (DDP buckets, Adam split) points at the batch.  Reference: autograd through
+    fpn_resnet.py:86-100."""
+    from oracle import zsg_oracle as O
+    from zsgnet_pytorch_amd import config, loss, mdl
+    from zsgnet_pytorch_amd._lib import lib
+    monkeypatch.setenv("ZSG_WINO", "force")      # (every 3x3 / stride-1 convolution on the Winograd kernels whatever the tuner would time at this small size)
+    # deterministic mode for both runs (no fp32-atomic split-K, fixed-order column sums): without it two runs of ONE plan already differ
+    # by ~2e-3 on every gradient at this size (atomics reorder sums, ReLU / max-pool ties flip) and would hide what the batch changes
+    monkeypatch.setenv("ZSG_DETERMINISTIC", "1")
+    lib.zsg_set_deterministic(1)
+    try:
+        _batched_vs_not(monkeypatch, mdl, config, loss, O, lib)
+    finally:
+        lib.zsg_set_deterministic(0)
+
+
+def _batched_vs_not(monkeypatch, mdl, config, loss, O, lib):
+    grads, plans = [], []
+    for on in (False, True):
+        monkeypatch.setattr(mdl, "WG_BATCH", on)
+        cfg = config.get_cfg(resnet_arch="resnet50", resize_img=[160, 160])
+        net = mdl.get_default_net(9, cfg)
+        net.load_state_dict(O.seeded_state_dict("resnet50", 5))
+        net.to("cuda").train()
+        r, s = config.ratios_scales(cfg)
+        lf = loss.get_default_loss(r, s, cfg)
+        bt = {k: v.cuda() for k, v in O.synthetic_batch(4, 160, 160, seed=9).items()}
+        bt["h0"], bt["c0"] = torch.zeros(2, 4, 128), torch.zeros(2, 4, 128)
+        lf(net(bt), bt)["loss"].mean().backward()
+        torch.cuda.synchronize()
+        grads.append(net.store.grad.clone())
+        plans.append(next(iter(net._plans.values())))
+    p0, p1 = plans
+    nb = getattr(p1, "n_wgrad_batches", 0)
+    n_b = sum(1 for c in p1.bwd.calls if c[0] is lib.zsg_conv_wgrad_wino_batched)
+    print(f"batched plan: {nb} batches, {len(p0.bwd.calls)} -> {len(p1.bwd.calls)} backward launches")
+    assert nb >= 3 and n_b == nb and len(p1.bwd.calls) < len(p0.bwd.calls)
+    ents = p1.net.store.entries
+    worst = 0.0
+    for n in p1.net._param_names:
+        o, sz = ents[n].offset, ents[n].size
+        a, b = grads[1][o:o + sz].double(), grads[0][o:o + sz].double()
+        e_ = float((a - b).norm() / (b.norm() + 1e-30))
+        if e_ > 2e-5:
+            print(f"  {n}: rel {e_:.2e}")
+        worst = max(worst, e_)
+        i = p1.grad_ready.get(n, -1)
+        assert -1 <= i <= len(p1.bwd.calls), (n, i)
+    print(f"worst relative gradient difference batched vs not: {worst:.2e}")
+    assert worst < 2e-5
+    for n in ("backbone.encoder.layer3.1.conv2.weight", "backbone.encoder.layer3.5.conv2.weight"):
+        assert p1.bwd.calls[p1.grad_ready[n]][0] is lib.zsg_conv_wgrad_wino_batched, n

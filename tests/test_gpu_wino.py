@@ -228,3 +228,48 @@ def test_wino_wgrad_multilevel_window(Z):
         L.check(L.lib.zsg_conv_wgrad_wino(C.byref(d), packed.data_ptr(), gyd.data_ptr(), dw.data_ptr(), 1, WS.data_ptr(), WS.numel() * 4, L.stream_ptr()), "wgrad_wino")
         assert_close(dw[..., :Cf].permute(0, 3, 1, 2) - 2.0, wr.grad, 5e-4, 5e-4 * float(wr.grad.abs().max()), f"multi-level wino wgrad splits={splits}")
         assert float((dw[..., Cf:] - 2.0).abs().max()) == 0.0, "channels outside the window must stay untouched"
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 20, 17, 3, 1, 3), (3, 128, 64, 7, 10, 1, 0, 2), (16, 64, 64, 38, 38, 12, 1, 2), (2, 256, 45, 10, 10, 2, 0, 8)],
+                         ids=["b0", "b1", "b2", "b3"])
+def test_wino_wgrad_batched(Z, case):
+    """zsg_conv_wgrad_wino_batched (round 6): J convolutions of one geometry in one launch = J x zsg_conv_wgrad_wino on the same
+    operands, BIT FOR BIT at the same split-K factor (a job's blocks walk the same stages in the same order, its slabs are reduced in the
+    same order), and autograd's weight gradient within the single launch's bound; accumulate adds to what the gradient image holds.
+    Refusals: more than 8 jobs, a null operand -> -1, nothing falls back.  Reference: autograd through nn.Conv2d of
+    fpn_resnet.py:86-100's identical bottlenecks."""
+    L, ops = Z
+    from test_gpu_ops import WS
+    B, Ci, Co, H, W, splits, acc, J = case
+    g = torch.Generator().manual_seed(77 + Ci + Co + H + J)
+    cp, Cop = pad4(Ci), pad4(Co)
+    xs, gys, refs = [], [], []
+    for j in range(J):
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).requires_grad_()
+        gy = torch.randn(B, Co, H, W, generator=g)
+        F.conv2d(x, w, None, 1, 1).backward(gy)
+        xs.append(dev(nhwc(x)))
+        gys.append(dev(nhwc(gy, Cop)))
+        refs.append(w.grad)
+    src, dyv = view_of(ops, xs[0], B, H, W, cp), view_of(ops, gys[0], B, H, W, Cop)
+    d = ops.fwd_desc(src, dyv, cp, Co, 3, 1, 1, 1, wC=cp, tile_hint=ops.tile_hint(64, 64, splits))
+    st = L.stream_ptr()
+    one = [torch.full((Co, 3, 3, cp), float(acc), device="cuda") for _ in range(J)]
+    for j in range(J):
+        L.check(L.lib.zsg_conv_wgrad_wino(C.byref(d), xs[j].data_ptr(), gys[j].data_ptr(), one[j].data_ptr(), acc, WS.data_ptr(), WS.numel() * 4, st), "wgrad_wino")
+    bat = [torch.full((Co, 3, 3, cp), float(acc), device="cuda") for _ in range(J)]
+    VP = C.c_void_p * J
+    a, b, c = VP(*[t.data_ptr() for t in xs]), VP(*[t.data_ptr() for t in gys]), VP(*[t.data_ptr() for t in bat])
+    L.check(L.lib.zsg_conv_wgrad_wino_batched(C.byref(d), J, a, b, c, acc, WS.data_ptr(), WS.numel() * 4, st), "wgrad_wino_batched")
+    torch.cuda.synchronize()
+    for j in range(J):
+        assert torch.equal(bat[j], one[j]), f"job {j}: the batched launch must reproduce the single launch bit for bit"
+        assert_close(bat[j][..., :Ci].permute(0, 3, 1, 2) - acc, refs[j], 5e-4, 5e-4 * float(refs[j].abs().max()), f"batched wino wgrad job {j}")
+    # refusals
+    VP9 = C.c_void_p * 9
+    nine = VP9(*([xs[0].data_ptr()] * 9))
+    assert L.lib.zsg_conv_wgrad_wino_batched(C.byref(d), 9, nine, nine, nine, 0, WS.data_ptr(), WS.numel() * 4, st) != 0
+    hole = VP(*([xs[0].data_ptr()] * (J - 1) + [None]))
+    assert L.lib.zsg_conv_wgrad_wino_batched(C.byref(d), J, hole, b, c, 0, WS.data_ptr(), WS.numel() * 4, st) != 0
+    assert L.lib.zsg_conv_wgrad_wino_batched(C.byref(d), J, a, b, c, 0, WS.data_ptr(), 1024, st) != 0 or splits <= 1, "a workspace too small for J x splits slabs is refused"

@@ -75,6 +75,7 @@ SIGNATURES = {
     "zsg_conv_wgrad": (I32, [DP, P, P, P, I32, P, SZ, P]),
     "zsg_conv_wgrad_wino_workspace_bytes": (SZ, [DP]),
     "zsg_conv_wgrad_wino": (I32, [DP, P, P, P, I32, P, SZ, P]),
+    "zsg_conv_wgrad_wino_batched": (I32, [DP, I32, P, P, P, I32, P, SZ, P]),
     "zsg_transpose_w": (I32, [P, P, I32, I32, I32, I32, P]),
     "zsg_transpose_w_batched": (I32, [P, P, P, I32, I32, P]),
     "zsg_pad_rows": (I32, [P, I64, I32, I32, P, I32, P]),

@@ -4,6 +4,7 @@
 #include "common.h"
 
 #define WG_PAD 4
+#define ZSG_WG_MAX_JOBS 8      // jobs of one batched weight-gradient launch (zsg_conv_wgrad_wino_batched)
 
 struct WgSegDev {
     int rows_y, rows_x, rows, kt0;

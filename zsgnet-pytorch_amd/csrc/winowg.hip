@@ -35,6 +35,13 @@ struct WwParams {
     int accumulate;
     int C, N, src_ld, dy_ld, wC, wc0, wt_ld, nseg;
     int m_tiles, n_tiles, splits, st_total, st_chunk, xmap;
+    // Job batch (round 6, zsg_conv_wgrad_wino_batched): njobs convolutions of ONE geometry (a stage's identical bottlenecks) in one launch —
+    // njobs x the (n, c) blocks at the same K range, i.e. a fraction of the split-K slabs and a longer stage loop per block.  Job j reads
+    // srcj[j] / dyj[j], writes dwj[j] (or the j-th group of `splits` slabs in ws); njobs == 0: the plain launch (src / dy / dw above).
+    int njobs;
+    const float* srcj[ZSG_WG_MAX_JOBS];
+    const float* dyj[ZSG_WG_MAX_JOBS];
+    float* dwj[ZSG_WG_MAX_JOBS];
     WwSegDev seg[ZSG_MAX_SEG];
 };
 
@@ -59,7 +66,22 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     const int nmn = p.m_tiles * p.n_tiles;
     // xmap: an XCD owns WHOLE K slices (all (n, c) blocks of a slice on one L2: the slice's rows of dY / X are fetched into one L2
     // instead of eight); else the (n, c) blocks of every slice are spread over the XCDs
-    const int lb = p.xmap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int lb = p.xmap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    // job batch: the blocks of a job are consecutive (job-major), so that a job's slices share their operands' cache lines in time
+    const int per_job = nmn * p.splits;
+    const int job = p.njobs ? lb / per_job : 0;
+    lb -= job * per_job;
+    // (a select chain on the wave-uniform job index: indexing the kernel-argument arrays dynamically makes hipcc copy them to scratch)
+    const float* src_j = p.src;
+    const float* dy_j = p.dy;
+    float* dw_j = p.dw;
+#pragma unroll
+    for (int j = 0; j < ZSG_WG_MAX_JOBS; ++j)
+        if (p.njobs && job == j) {
+            src_j = p.srcj[j];
+            dy_j = p.dyj[j];
+            dw_j = p.dwj[j];
+        }
     const int split = lb / nmn;
     const int mn = p.xmap ? lb % nmn : xcd_remap(lb % nmn, nmn);
     const int mt = mn / p.n_tiles, nt = mn % p.n_tiles;
@@ -78,10 +100,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     const int a_col = m0 + 4 * g, b_col = n0 + 4 * g;
     const bool a_colok = a_col < p.N, b_colok = b_col < p.C;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const rsrc_t rs_a = make_rsrc(p.dy);
+    const rsrc_t rs_a = make_rsrc(dy_j);
     // input patches reach one row and one column above / left of pixel (2ty, 2tx): the descriptor's base sits WW_BIAS bytes below the
     // tensor so that neither the scalar nor the per-lane part of an offset is ever negative (the range check looks at the per-lane part)
-    const rsrc_t rs_b = make_rsrc((const char*)p.src - WW_BIAS);
+    const rsrc_t rs_b = make_rsrc((const char*)src_j - WW_BIAS);
     int si = 0;
 #pragma unroll
     for (int s = 1; s < ZSG_MAX_SEG; ++s)
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
     // wait -> conditional store, 144 times in half of the waves) cost 10 us per launch: 18 % of the 13-stage launches.
     float* xch = ww_smem;                           // [2 rounds in flight][2 directions][4 sub-blocks][24][64 lanes]
     const int sub = wave & 3;
-    float* dst = p.ws ? p.ws + (size_t)split * p.N * (9 * p.C) : p.dw;
+    float* dst = p.ws ? p.ws + (size_t)(job * p.splits + split) * p.N * (9 * p.C) : dw_j;
     const int ld = p.ws ? 9 * p.C : p.wt_ld;
     const int tap_ld = p.ws ? p.C : p.wC;
     const int c = n0 + wn * 32 + li;
@@ -296,8 +318,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WwParams p) {
 
 // split-K factor of a launch: tile_hint's, else enough K slices for one block per CU — ONE rule for the launch and for the
 // workspace query (so a caller that sizes its workspace from the query never gets "workspace too small")
-static int ww_pick_splits(const zsg_conv_desc* d, int stages) {
-    const int nmn = cdiv(d->N, 64) * cdiv(d->C, 64);
+static int ww_pick_splits(const zsg_conv_desc* d, int stages, int njobs = 1) {
+    const int nmn = cdiv(d->N, 64) * cdiv(d->C, 64) * njobs;
     int splits = (d->tile_hint >> 16) & 0xff;
     if (splits <= 0) splits = (ZSG_NUM_CU + nmn - 1) / nmn;
     if (splits > stages / 2) splits = stages / 2;
@@ -318,8 +340,10 @@ extern "C" size_t zsg_conv_wgrad_wino_workspace_bytes(const zsg_conv_desc* d) {
 // Same contract as zsg_conv_wgrad (forward descriptor, dy in the "out" geometry, accumulate flag, split-K workspace,
 // deterministic slab reduction); 3x3 / stride 1 / pad 1 only.  tile_hint: split_k << 16 (0: heuristic), bit 24: block order "whole K slices per XCD".
 static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
-                                size_t ws_bytes, void* stream) {
+                                size_t ws_bytes, void* stream, int njobs = 0, const float* const* srcj = nullptr, const float* const* dyj = nullptr,
+                                float* const* dwj = nullptr) {
     ZSG_REQUIRE(d && src && dy && dw, "conv_wgrad_wino: null argument");
+    ZSG_REQUIRE(njobs >= 0 && njobs <= ZSG_WG_MAX_JOBS, "conv_wgrad_wino_batched: %d jobs (at most %d)", njobs, ZSG_WG_MAX_JOBS);
     ZSG_REQUIRE(d->nseg >= 1 && d->nseg <= ZSG_MAX_SEG, "conv_wgrad_wino: nseg=%d", d->nseg);
     ZSG_REQUIRE(d->C > 0 && (d->C % 4) == 0 && (d->src_ld % 4) == 0 && (d->wC % 4) == 0 && (d->wc0 % 4) == 0 && (d->out_ld % 4) == 0,
                 "conv_wgrad_wino: C=%d src_ld=%d wC=%d wc0=%d out_ld=%d must be multiples of 4", d->C, d->src_ld, d->wC, d->wc0, d->out_ld);
@@ -327,6 +351,12 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
     WwParams p;
     memset(&p, 0, sizeof(p));
     p.src = src; p.dy = dy; p.dw = dw; p.accumulate = accumulate ? 1 : 0;
+    p.njobs = njobs;
+    for (int j = 0; j < njobs; ++j) {
+        ZSG_REQUIRE(srcj[j] && dyj[j] && dwj[j], "conv_wgrad_wino_batched: job %d has a null operand", j);
+        p.srcj[j] = srcj[j]; p.dyj[j] = dyj[j]; p.dwj[j] = dwj[j];
+    }
+    const int jn = njobs ? njobs : 1;
     p.C = d->C; p.N = d->N; p.src_ld = d->src_ld; p.dy_ld = d->out_ld; p.wC = d->wC; p.wc0 = d->wc0; p.wt_ld = d->wt_ld; p.nseg = d->nseg;
     int st = 0;
     double rows_all = 0;
@@ -357,11 +387,11 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
     p.m_tiles = cdiv(d->N, 64);
     p.n_tiles = cdiv(d->C, 64);
     const int nmn = p.m_tiles * p.n_tiles;
-    const int splits = ww_pick_splits(d, st);
+    const int splits = ww_pick_splits(d, st, jn);
     p.st_chunk = cdiv(st, splits);
     p.splits = cdiv(st, p.st_chunk);
     if (p.splits > 1) {
-        const size_t need = (size_t)p.splits * d->N * 9 * d->C * sizeof(float);
+        const size_t need = (size_t)jn * p.splits * d->N * 9 * d->C * sizeof(float);
         if (!ws || ws_bytes < need) ZSG_FAIL(-2, "conv_wgrad_wino: workspace too small (%zu < %zu bytes)", ws_bytes, need);
         p.ws = (float*)ws;
     }
@@ -378,13 +408,15 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
         attr_done[dev] = true;
     }
     {
-        ZSG_PROF("wino_wgrad_kernel", stq, 2.0 * rows_all * d->N * 9.0 * d->C, zsg_conv_alg_bytes(d, accumulate != 0));
-        ZSG_LAUNCH(wino_wgrad_kernel, dim3(nmn * p.splits), dim3(512), lds, stq, p);
+        ZSG_PROF("wino_wgrad_kernel", stq, jn * 2.0 * rows_all * d->N * 9.0 * d->C, jn * zsg_conv_alg_bytes(d, accumulate != 0));
+        ZSG_LAUNCH(wino_wgrad_kernel, dim3(jn * nmn * p.splits), dim3(512), lds, stq, p);
     }
-    if (p.splits > 1) {     // fixed-order slab sum -> dw (shared with the direct kernel)
-        WgReduceJob r;
-        wg_reduce_job_fill(r, d, p.ws, dw, p.accumulate, p.splits);
-        wg_reduce_launch(r, stq);
+    if (p.splits > 1) {     // fixed-order slab sum -> dw (shared with the direct kernel), one per job
+        for (int j = 0; j < jn; ++j) {
+            WgReduceJob r;
+            wg_reduce_job_fill(r, d, p.ws + (size_t)j * p.splits * d->N * 9 * d->C, njobs ? dwj[j] : dw, p.accumulate, p.splits);
+            wg_reduce_launch(r, stq);
+        }
     }
     ZSG_CHECK_LAUNCH("conv_wgrad_wino");
     return 0;
@@ -393,4 +425,14 @@ static int conv_wgrad_wino_impl(const zsg_conv_desc* d, const float* src, const 
 extern "C" int zsg_conv_wgrad_wino(const zsg_conv_desc* d, const float* src, const float* dy, float* dw, int32_t accumulate, void* ws,
                                    size_t ws_bytes, void* stream) {
     return conv_wgrad_wino_impl(d, src, dy, dw, accumulate, ws, ws_bytes, stream);
+}
+
+// njobs convolutions of ONE geometry (descriptor d) in one launch: job j = (src[j], dy[j]) -> dw[j]; accumulate and the workspace as above
+// (the workspace holds njobs x split-K slabs: zsg_conv_wgrad_wino_workspace_bytes(d) x njobs is always enough).  The identical
+// bottlenecks of a ResNet stage (fpn_resnet.py:86-100, layerN.1 .. layerN.k conv2): their weight gradients are leaves of the backward
+// graph, so the lowering may hold them back until the last one's operands exist and release them together.
+extern "C" int zsg_conv_wgrad_wino_batched(const zsg_conv_desc* d, int32_t njobs, const float* const* src, const float* const* dy, float* const* dw,
+                                           int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+    ZSG_REQUIRE(njobs >= 1 && src && dy && dw, "conv_wgrad_wino_batched: bad argument");
+    return conv_wgrad_wino_impl(d, src[0], dy[0], dw[0], accumulate, ws, ws_bytes, stream, njobs, src, dy, dw);
 }

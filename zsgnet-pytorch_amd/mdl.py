@@ -28,7 +28,7 @@ from torch import nn
 
 from . import anchors as anchors_mod
 from ._lib import check, lib, require_gpu, stream_ptr
-from .ops import (Level, Program, TView, WinoJobs, apply_main_priority_env, autotune_conv, conv_out, ensure_stream_scratch, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
+from .ops import (Level, Program, TView, WinoJobs, apply_main_priority_env, autotune_conv, autotune_wgrad_batch, conv_out, ensure_stream_scratch, dgrad_desc, fwd_desc, igemm_partial_rows, marshal,
                   shared_side_stream, tile_hint, wino_mode, wino_ok)
 from .params import ParamStore, pad4, register_named
 
@@ -78,6 +78,7 @@ BN_PRE_MIN_MB = float(os.environ.get("ZSG_BN_PRE_MIN_MB", "40"))
 STAGE_INPUTS = os.environ.get("ZSG_STAGE_INPUTS", "1") != "0"      # (A/B: 0 = the separate torch copies of rounds 1-4)
 BN_TAIL = os.environ.get("ZSG_BN_TAIL", "1")
 MASKED_DOUT = os.environ.get("ZSG_MASKED_DOUT", "1") != "0"      # the completing data gradient stores the ReLU-masked dout = the residual's gradient (bn(): back)
+WG_BATCH = os.environ.get("ZSG_WG_BATCH", "1") != "0"      # identical-shape Winograd weight gradients of a stage in ONE launch (_Plan._batch_wgrads)
 SK_BWD = os.environ.get("ZSG_SK_BWD", "0") != "0"      # stream-K candidates also for the backward's data gradients (measured slower: ops.autotune_conv)
 BN_TAIL_MIN_ROWS = int(os.environ.get("ZSG_BN_TAIL_MIN_ROWS", "0"))      # (A/B: only launches with more partial rows than this finalise in-kernel)
 def prep_at() -> str:
@@ -526,6 +527,7 @@ class _Plan:
         self._adam_ev, self._adam_cut_v = None, False
         self.expect_backward = False
         self._tunables = []              # convolution descriptors of this plan, as lowered (ops.refine_in_step)
+        self._wg_log = []                # (launch index, descriptor, src, dy, gradient view, parameter, name) of every convolution weight gradient
         self.g5_from_loss = None         # (fwd_id, scale): the loss kernel wrote d(loss)/d(out5) x scale into g5_in for that forward
         self.bwd = Program("bwd")
         self.bwd.side_batch = 3 if B * H * W <= (4 << 20) else 1      # (ops.SIDE_BATCH: markers vs overlap, measured)
@@ -903,6 +905,7 @@ class _Plan:
                 and dy.ld % 4 == 0 and wino_mode() != "0")       # 3x3 / stride 1 / pad 1: Winograd F(3x3,2x2) candidates
         self._tune("wgrad", lib.zsg_conv_wgrad, d, targs, stream_ptr(), self.wg_ws_bytes, wino_args=targs if wino else None)
         self.bwd.add(lib.zsg_conv_wgrad_wino if d.use_wino else lib.zsg_conv_wgrad, d, *args, what=what, lane=1)
+        self._wg_log.append((len(self.bwd.calls) - 1, d, src, dy, gw, pname, what))
 
     def dgrad(self, L: ConvL, dy: Act, src: Act, n: int, row0: int = 0, dx: Optional[Act] = None, completes_bn: bool = False):
         """dx (+)= dgrad(dy) for input channels [row0, row0+n) of L; applies src's ReLU mask when required."""
@@ -1171,7 +1174,69 @@ class _Plan:
         if self.training:
             for emit in reversed(self.tape):
                 emit()
+            if WG_BATCH:
+                self._batch_wgrads()
         self.tape = []
+
+    def _batch_wgrads(self):
+        """Round 6: the Winograd weight gradients of a stage's IDENTICAL convolutions (layerN.1 .. layerN.k conv2: fpn_resnet.py:86-100)
+        become ONE launch (zsg_conv_wgrad_wino_batched) at the position of the last of them in the backward program.  Weight gradients
+        are leaves of the backward graph and every activation / gradient buffer of a plan lives until the next forward, so holding the
+        earlier ones back changes nothing but the order in which the side stream does its work: a job batch has njobs x the (n, c)
+        blocks, i.e. a fraction of the split-K slabs and a longer stage loop per block (l3_conv2 x 5: 268 -> 205 us,
+        profiles/r06_wgrad_batching.txt).  The launch indices recorded for DDP's buckets / the Adam split (grad_ready) are re-based."""
+        import ctypes as C_
+        groups = {}
+        for rec in self._wg_log:
+            idx, d, src, dy, gw, pname, what = rec
+            if not d.use_wino or d.nseg != 1 or self.bwd.calls[idx][0] is not lib.zsg_conv_wgrad_wino:
+                continue
+            s0 = d.seg[0]
+            sig = (d.B, d.C, d.N, d.src_ld, d.out_ld, d.wC, d.wc0, d.wt_ld, s0.src_H, s0.src_W, s0.src_off, s0.src_bstride, s0.out_off, s0.out_bstride)
+            groups.setdefault(sig, []).append(rec)
+        drop, put = set(), {}
+        for sig, recs in groups.items():
+            recs.sort(key=lambda r: r[0])
+            for k in range(0, len(recs), 8):              # (at most ZSG_WG_MAX_JOBS per launch)
+                part = recs[k:k + 8]
+                if len(part) < 2:
+                    continue
+                n = len(part)
+                d0 = part[0][1]
+                db = type(d0).from_buffer_copy(d0)
+                srcs, dys, gws = [r[2].buf for r in part], [r[3].buf for r in part], [r[4] for r in part]
+                autotune_wgrad_batch(db, n, srcs, dys, self.tune_dw, self.wg_ws, self.wg_ws_bytes, stream_ptr())
+                VP = C_.c_void_p * n
+                a_src, a_dy, a_dw = VP(*[t.data_ptr() for t in srcs]), VP(*[t.data_ptr() for t in dys]), VP(*[t.data_ptr() for t in gws])
+                self.bwd.keep += [db, a_src, a_dy, a_dw] + srcs + dys + gws
+                conv = (C_.byref(db), C_.c_int32(n), C_.cast(a_src, C_.c_void_p), C_.cast(a_dy, C_.c_void_p), C_.cast(a_dw, C_.c_void_p),
+                        C_.c_int32(1), C_.c_void_p(self.wg_ws.data_ptr()), C_.c_size_t(self.wg_ws_bytes))
+                last = part[-1][0]
+                put[last] = (lib.zsg_conv_wgrad_wino_batched, conv, "wgrad x%d:" % n + part[-1][6].split(":", 1)[1] + " .. " + part[0][6].split(":", 1)[1])
+                drop.update(r[0] for r in part[:-1])
+                for r in part:
+                    self.grad_ready[r[5]] = last
+                    if r[1] in self._tunables:
+                        self._tunables.remove(r[1])
+        if not put:
+            return
+        remap, calls, lanes = {}, [], []
+        for i, (c, l) in enumerate(zip(self.bwd.calls, self.bwd.lanes)):
+            if i in drop:
+                continue
+            remap[i] = len(calls)
+            calls.append(put.get(i, c))
+            lanes.append(l)
+        # a dropped launch's index maps to the next kept one (its gradient is complete no earlier than the batch, re-based above)
+        nxt = len(calls)
+        for i in range(len(self.bwd.calls), -1, -1):
+            if i in remap:
+                nxt = remap[i]
+            else:
+                remap[i] = nxt
+        self.bwd.calls, self.bwd.lanes = calls, lanes
+        self.grad_ready = {k: remap[v] for k, v in self.grad_ready.items()}
+        self.n_wgrad_batches = len(put)
 
     def _lower_stem_fused(self, L: ConvL, Lb: BnL, x0: Act, H1: int, W1: int, H2: int, W2: int) -> Act:
         """conv1 -> bn1 -> relu -> maxpool (mdl.py:149-152) in training: the BatchNorm + ReLU + max-pool are ONE pass over the stem
