@@ -237,9 +237,9 @@ def _batched_vs_not(monkeypatch, mdl, config, loss, O, lib):
         plans.append(next(iter(net._plans.values())))
     p0, p1 = plans
     nb = getattr(p1, "n_wgrad_batches", 0)
-    n_b = sum(1 for c in p1.bwd.calls if c[0] is lib.zsg_conv_wgrad_wino_batched)
+    n_w = sum(1 for c in p1.bwd.calls if c[0] is lib.zsg_conv_wgrad_wino_batched)
     print(f"batched plan: {nb} batches, {len(p0.bwd.calls)} -> {len(p1.bwd.calls)} backward launches")
-    assert nb >= 3 and n_b == nb and len(p1.bwd.calls) < len(p0.bwd.calls)
+    assert n_w >= 3 and n_w == nb and len(p1.bwd.calls) < len(p0.bwd.calls)
     ents = p1.net.store.entries
     worst = 0.0
     for n in p1.net._param_names:

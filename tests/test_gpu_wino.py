@@ -273,3 +273,4 @@ def test_wino_wgrad_batched(Z, case):
     hole = VP(*([xs[0].data_ptr()] * (J - 1) + [None]))
     assert L.lib.zsg_conv_wgrad_wino_batched(C.byref(d), J, hole, b, c, 0, WS.data_ptr(), WS.numel() * 4, st) != 0
     assert L.lib.zsg_conv_wgrad_wino_batched(C.byref(d), J, a, b, c, 0, WS.data_ptr(), 1024, st) != 0 or splits <= 1, "a workspace too small for J x splits slabs is refused"
+

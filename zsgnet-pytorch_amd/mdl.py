@@ -1189,10 +1189,14 @@ class _Plan:
         groups = {}
         for rec in self._wg_log:
             idx, d, src, dy, gw, pname, what = rec
-            if not d.use_wino or d.nseg != 1 or self.bwd.calls[idx][0] is not lib.zsg_conv_wgrad_wino:
+            # (Winograd launches only: batching the direct 1x1 weight gradients as well was built and measured — 13.07 -> 13.08 ms, the
+            # later release of 24 launches costs what their shorter kernels save — and removed again, profiles/r06_wgrad_batching.txt)
+            if d.nseg != 1 or not d.use_wino or self.bwd.calls[idx][0] is not lib.zsg_conv_wgrad_wino:
                 continue
-            s0 = d.seg[0]
-            sig = (d.B, d.C, d.N, d.src_ld, d.out_ld, d.wC, d.wc0, d.wt_ld, s0.src_H, s0.src_W, s0.src_off, s0.src_bstride, s0.out_off, s0.out_bstride)
+            # one geometry = one descriptor, byte for byte, the tile hint aside (the jobs of a launch share everything but their pointers)
+            dz = type(d).from_buffer_copy(d)
+            dz.tile_hint = 0
+            sig = (bool(d.use_wino), bytes(dz))
             groups.setdefault(sig, []).append(rec)
         drop, put = set(), {}
         for sig, recs in groups.items():
@@ -1205,7 +1209,8 @@ class _Plan:
                 d0 = part[0][1]
                 db = type(d0).from_buffer_copy(d0)
                 srcs, dys, gws = [r[2].buf for r in part], [r[3].buf for r in part], [r[4] for r in part]
-                autotune_wgrad_batch(db, n, srcs, dys, self.tune_dw, self.wg_ws, self.wg_ws_bytes, stream_ptr())
+                wino = bool(d0.use_wino)
+                autotune_wgrad_batch(db, n, wino, srcs, dys, self.tune_dw, self.wg_ws, self.wg_ws_bytes, stream_ptr())
                 VP = C_.c_void_p * n
                 a_src, a_dy, a_dw = VP(*[t.data_ptr() for t in srcs]), VP(*[t.data_ptr() for t in dys]), VP(*[t.data_ptr() for t in gws])
                 self.bwd.keep += [db, a_src, a_dy, a_dw] + srcs + dys + gws

@@ -966,28 +966,31 @@ def autotune_conv(kind: str, fn, d: ConvDesc, args: Sequence, stream: int, ws_by
     return best
 
 
-def autotune_wgrad_batch(d: ConvDesc, njobs: int, srcs, dys, scratch_dw: torch.Tensor, ws: torch.Tensor, ws_bytes: int, stream: int) -> int:
-    """Split-K factor of a job-batched Winograd weight gradient (zsg_conv_wgrad_wino_batched: njobs convolutions of descriptor d's
-    geometry in one launch), tuned like every other launch shape: median of interleaved samples, cached under its own key (it goes into
-    ZSG_TUNE_CACHE / the shipped table with the rest).  The trial launches write `scratch_dw` (every job the same scratch image —
-    timing only), never a gradient.  Returns the tile hint (also left in d.tile_hint)."""
+def autotune_wgrad_batch(d: ConvDesc, njobs: int, wino: bool, srcs, dys, scratch_dw: torch.Tensor, ws: torch.Tensor, ws_bytes: int, stream: int) -> int:
+    """Split-K choice of a job-batched Winograd weight gradient (zsg_conv_wgrad_wino_batched: njobs convolutions of descriptor d's
+    geometry in one launch), tuned like every other launch shape: median of interleaved samples, cached under its own key
+    (it goes into ZSG_TUNE_CACHE / the shipped table with the rest).  The trial launches write `scratch_dw` (every job the same scratch
+    image — timing only), never a gradient.  Returns the tile hint (also left in d.tile_hint)."""
     global _TUNE_DIRTY
-    key = _sig("wgradb", d, (njobs, deterministic()))
+    key = _sig("wgradb", d, (njobs, bool(wino), deterministic()))
     if key in _TUNE_CACHE:
         d.tile_hint = _TUNE_CACHE[key]
         return d.tile_hint
+    assert wino, "job batches exist for the Winograd weight gradient only (the direct kernel's measured no gain in the step: profiles/r06_wgrad_batching.txt)"
+    fn = lib.zsg_conv_wgrad_wino_batched
     VP = C.c_void_p * njobs
     a_src, a_dy, a_dw = VP(*[t.data_ptr() for t in srcs]), VP(*[t.data_ptr() for t in dys]), VP(*([scratch_dw.data_ptr()] * njobs))
     conv = (C.byref(d), C.c_int32(njobs), C.cast(a_src, C.c_void_p), C.cast(a_dy, C.c_void_p), C.cast(a_dw, C.c_void_p), C.c_int32(0),
             C.c_void_p(ws.data_ptr()), C.c_size_t(ws_bytes))
-    tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
-    nmn = ((d.N + 63) // 64) * ((d.C + 63) // 64) * njobs
     trials, seen = [], set()
-    for target in (128, 192, 256, 384, 512, 768):
-        sp = max(1, min(target // nmn, tiles // 16, 255))
-        if sp not in seen and njobs * sp * d.N * 9 * d.C * 4 <= ws_bytes:
-            seen.add(sp)
-            trials.append((lib.zsg_conv_wgrad_wino_batched, conv, tile_hint(64, 64, sp), 0))
+    if wino:
+        tiles = sum(d.B * ((d.seg[i].src_H + 1) // 2) * ((d.seg[i].src_W + 1) // 2) for i in range(d.nseg))
+        nmn = ((d.N + 63) // 64) * ((d.C + 63) // 64) * njobs
+        for target in (128, 192, 256, 384, 512, 768):
+            sp = max(1, min(target // nmn, tiles // 16, 255))
+            if sp not in seen and njobs * sp * d.N * 9 * d.C * 4 <= ws_bytes:
+                seen.add(sp)
+                trials.append((fn, conv, tile_hint(64, 64, sp), 0))
 
     def set_hint(h):
         d.tile_hint = h
