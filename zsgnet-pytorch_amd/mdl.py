@@ -1242,6 +1242,12 @@ class _Plan:
         self.bwd.calls, self.bwd.lanes = calls, lanes
         self.grad_ready = {k: remap[v] for k, v in self.grad_ready.items()}
         self.n_wgrad_batches = len(put)
+        # release policy with batches (ops.SIDE_BATCH): a bottleneck stage now releases ONE large Winograd launch per stage plus its 1x1
+        # weight gradients; releasing every second main-stream convolution instead of every third gets the batch going earlier —
+        # configs[1] 13.08 -> 13.03 / 13.14 -> 13.05 ms on two boxes (1 and 4 are slower; ResNet-18's basic blocks and SSD-VGG keep 3:
+        # profiles/r06_ab_release_final.txt)
+        if self.bwd.side_batch == 3 and getattr(self.net, "block_kind", "") == "bottleneck":
+            self.bwd.side_batch = 2
 
     def _lower_stem_fused(self, L: ConvL, Lb: BnL, x0: Act, H1: int, W1: int, H2: int, W2: int) -> Act:
         """conv1 -> bn1 -> relu -> maxpool (mdl.py:149-152) in training: the BatchNorm + ReLU + max-pool are ONE pass over the stem
